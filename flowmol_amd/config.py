@@ -1,0 +1,171 @@
+"""Model configuration for the FlowMol3 sampling hot path.
+
+The reference splats the YAML ``vector_field:`` block into
+``CTMCVectorField.__init__`` (reference flowmol/models/flowmol.py:146-153) and
+the ``mol_fm:`` block into ``FlowMol.__init__`` (flowmol/model_utils/load.py:43-47).
+``VFConfig`` is the flattened, validated form of the knobs that shape the
+sampling path; it is what gets serialised into the C-ABI ``fm_config`` struct
+(include/flowmol_hip.h).
+
+Only the configurations the HIP kernels implement are accepted; anything else
+raises ``NotImplementedError`` loudly (no silent fallback).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+from typing import List, Optional, Union
+
+
+@dataclass
+class VFConfig:
+    # ---- categorical sizes (reference flowmol.py:57-80, vector_field.py:93-97)
+    atom_type_map: List[str] = field(default_factory=lambda: ['C', 'H', 'N', 'O', 'F', 'P', 'S', 'Cl', 'Br', 'I'])
+    fake_atoms: bool = True            # fake_atom_p > 0  -> one extra atom type (flowmol.py:76-80)
+    n_charges: int = 6
+    n_bond_types: int = 4              # 5 with explicit aromaticity (flowmol.py:59)
+    # ---- network dims (configs/flowmol3.yml:80-106)
+    n_vec_channels: int = 32
+    n_cp_feats: int = 4
+    n_hidden_scalars: int = 256
+    n_hidden_edge_feats: int = 128
+    n_molecule_updates: int = 6
+    convs_per_update: int = 1
+    n_message_gvps: int = 3
+    n_update_gvps: int = 3
+    separate_mol_updaters: bool = True
+    message_norm: Union[float, str] = 'sum'
+    update_edge_w_distance: bool = True
+    rbf_dmax: float = 10.0
+    rbf_dim: int = 32
+    time_embedding_dim: int = 64
+    a_token_dim: int = 64
+    c_token_dim: int = 64
+    e_token_dim: int = 64
+    self_conditioning: bool = True
+    use_dst_feats: bool = False
+    n_recycles: int = 1
+    # ---- CTMC integrator defaults (ctmc_vector_field.py:23-34)
+    stochasticity: float = 30.0
+    high_confidence_threshold: float = 0.9
+    cat_temperature: float = 0.05
+    dfm_type: str = 'campbell'
+    # ---- sampling defaults (flowmol.py:46)
+    default_n_timesteps: int = 250
+    # name of the size histogram shipped in flowmol_amd/data/n_atoms_hist.json
+    n_atoms_hist: str = 'geom_full_kekulized'
+    explicit_aromaticity: bool = False
+
+    # ------------------------------------------------------------------ derived
+    @property
+    def n_atom_types(self) -> int:
+        """Number of real categories for 'a' (incl. the fake-atom type, excl. mask)."""
+        return len(self.atom_type_map) + (1 if self.fake_atoms else 0)
+
+    @property
+    def n_convs(self) -> int:
+        return self.convs_per_update * self.n_molecule_updates
+
+    @property
+    def n_updaters(self) -> int:
+        return self.n_molecule_updates if self.separate_mol_updaters else 1
+
+    @property
+    def token_dims(self):
+        """Width of the token features fed to the embedding MLPs.
+
+        token_dim == 0 -> raw one-hot incl. mask column (vector_field.py:102-119)."""
+        a = self.a_token_dim if self.a_token_dim else self.n_atom_types + 1
+        c = self.c_token_dim if self.c_token_dim else self.n_charges + 1
+        e = self.e_token_dim if self.e_token_dim else self.n_bond_types + 1
+        return a, c, e
+
+    @property
+    def msg_z(self) -> float:
+        """Divisor applied to the aggregated messages (gvp.py:495-501)."""
+        if isinstance(self.message_norm, str):
+            if self.message_norm == 'sum':
+                return 1.0
+            raise NotImplementedError("message_norm='mean' is not enabled by any shipped config")
+        return float(self.message_norm)
+
+    def update_schedule(self):
+        """For each conv index, the updater index run after it or -1.
+
+        Reproduces vector_field.py:320-326: an update follows conv ``i`` iff
+        ``i != 0 and (i+1) % convs_per_update == 0``; with separate updaters the
+        index is ``i // convs_per_update`` (so updater 0 is dead when
+        convs_per_update == 1)."""
+        out = []
+        for i in range(self.n_convs):
+            if i != 0 and (i + 1) % self.convs_per_update == 0:
+                out.append(i // self.convs_per_update if self.separate_mol_updaters else 0)
+            else:
+                out.append(-1)
+        return out
+
+    def validate(self) -> "VFConfig":
+        if self.n_hidden_scalars != 256 or self.n_hidden_edge_feats != 128 or self.rbf_dim != 32:
+            raise NotImplementedError(
+                f"HIP kernels are built for S=256,F=128,R=32; got S={self.n_hidden_scalars} "
+                f"F={self.n_hidden_edge_feats} R={self.rbf_dim}")
+        if self.n_vec_channels not in (16, 32):
+            raise NotImplementedError(f"n_vec_channels must be 16 or 32, got {self.n_vec_channels}")
+        if self.n_cp_feats != 4 or self.n_message_gvps != 3 or self.n_update_gvps != 3:
+            raise NotImplementedError("only n_cp_feats=4 and 3/3 message/update GVPs are implemented")
+        if self.use_dst_feats:
+            raise NotImplementedError("use_dst_feats (configs/dev.yml) is outside the round-1 hot path")
+        if self.n_recycles != 1:
+            raise NotImplementedError("n_recycles>1 is never enabled by a shipped config")
+        if not self.update_edge_w_distance:
+            raise NotImplementedError("update_edge_w_distance=False is never enabled by a shipped config")
+        if self.dfm_type != 'campbell':
+            raise NotImplementedError("only dfm_type='campbell' is implemented")
+        tok = (self.a_token_dim > 0, self.c_token_dim > 0, self.e_token_dim > 0)
+        if len(set(tok)) != 1:
+            raise NotImplementedError("token dims must be all zero or all non-zero")
+        if self.n_atom_types + 1 > 16 or self.n_charges + 1 > 8 or self.n_bond_types + 1 > 8:
+            raise NotImplementedError("categorical widths exceed kernel limits (a<=16, c<=8, e<=8 incl. mask)")
+        self.msg_z  # raises for 'mean'
+        return self
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def from_reference_hparams(hp: dict) -> VFConfig:
+    """Build a VFConfig from a Lightning checkpoint's ``hyper_parameters`` dict
+    (the kwargs of reference ``FlowMol.__init__``, flowmol.py:29-55,169)."""
+    vf = dict(hp.get('vector_field_config', {}))
+    cfg = VFConfig(
+        atom_type_map=list(hp['atom_type_map']),
+        fake_atoms=float(hp.get('fake_atom_p', 0.0)) > 0,
+        n_charges=int(hp.get('n_atom_charges', 6)),
+        n_bond_types=5 if hp.get('explicit_aromaticity', False) else 4,
+        explicit_aromaticity=bool(hp.get('explicit_aromaticity', False)),
+        default_n_timesteps=int(hp.get('default_n_timesteps', 250)),
+    )
+    # defaults of EndpointVectorField/CTMCVectorField.__init__ for keys absent from the YAML
+    ref_defaults = dict(
+        n_vec_channels=16, n_cp_feats=0, n_hidden_scalars=64, n_hidden_edge_feats=64,
+        n_molecule_updates=2, convs_per_update=2, n_message_gvps=3, n_update_gvps=3,
+        separate_mol_updaters=False, message_norm=100, update_edge_w_distance=False,
+        rbf_dmax=20, rbf_dim=16, time_embedding_dim=1, a_token_dim=0, c_token_dim=0,
+        e_token_dim=0, self_conditioning=False, use_dst_feats=False, n_recycles=1,
+        stochasticity=0.0, high_confidence_threshold=0.0, dfm_type='campbell',
+    )
+    for k, dflt in ref_defaults.items():
+        setattr(cfg, k, vf.get(k, dflt))
+    ct = vf.get('cat_temperature_schedule', 0.05)
+    if not isinstance(ct, (int, float)):
+        raise NotImplementedError("only a constant categorical temperature is implemented")
+    cfg.cat_temperature = float(ct)
+    for unsupported in ('attention', 'dropout', 's_message_dim', 'v_message_dim'):
+        v = vf.get(unsupported)
+        if v not in (None, False, 0, 0.0):
+            raise NotImplementedError(f"vector_field.{unsupported}={v!r} is not implemented")
+    nah = str(hp.get('n_atoms_hist_file', ''))
+    for name in ('geom_full_kekulized', 'geom_5_kekulized', 'geom_5_aromatic', 'qm9', 'geom'):
+        if f'/{name}/' in nah or nah.startswith(f'data/{name}'):
+            cfg.n_atoms_hist = name
+            break
+    return cfg.validate()

@@ -1,0 +1,126 @@
+"""The CPU oracle (oracle/cpu_ref.py) against golden vectors produced by the REFERENCE's own
+modules (oracle/make_golden.py, run in the build container).  Runs anywhere (no /root/reference)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from flowmol_amd import presets, weights
+from oracle import cpu_ref
+
+torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+TOL = dict(rtol=1e-6, atol=1e-6)   # same ops on the same CPU; observed bitwise-equal in the build container
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(golden_dir / name).items()}
+
+
+def _onehots(cfg, batch, a, c, eu):
+    m = batch.upper_edge_mask
+    e = torch.zeros(batch.E, cfg.n_bond_types + 1)
+    e[m] = F.one_hot(eu, cfg.n_bond_types + 1).float()
+    e[~m] = F.one_hot(eu, cfg.n_bond_types + 1).float()
+    return F.one_hot(a, cfg.n_atom_types + 1).float(), F.one_hot(c, cfg.n_charges + 1).float(), e
+
+
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9'])
+def test_forward_matches_reference(golden_dir, name):
+    cfg = presets.PRESETS[name]()
+    g = _load(golden_dir, f'forward_{name}.npz')
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    with torch.no_grad():
+        for tag, tval in (('t0', 0.0), ('th', 0.5)):
+            a, c, e = _onehots(cfg, batch, g[f'{tag}.a'], g[f'{tag}.c'], g[f'{tag}.e_upper'])
+            prev = None
+            if tag == 'th' and cfg.self_conditioning:
+                prev = {k: g[f'th.prev.{k}'] for k in 'xace'}
+            out = orc.forward(batch, g[f'{tag}.x_t'], a, c, e, torch.full((batch.B,), tval), prev=prev,
+                              apply_softmax=True, remove_com=True)
+            for k in 'xace':
+                torch.testing.assert_close(out[k], g[f'{tag}.out.{k}'], **TOL)
+
+
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc'])
+def test_modules_match_reference(golden_dir, name):
+    cfg = presets.PRESETS[name]()
+    g = _load(golden_dir, f'modules_{name}.npz')
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    with torch.no_grad():
+        xd, d = orc.distances(batch, g['x'])
+        torch.testing.assert_close(xd, g['x_diff'], **TOL)
+        torch.testing.assert_close(d, g['d'], **TOL)
+        s2, v2 = orc.conv(0, batch, g['s'], g['v'], g['ef'], xd, d)
+        torch.testing.assert_close(s2, g['conv0.s'], **TOL)
+        torch.testing.assert_close(v2, g['conv0.v'], **TOL)
+        torch.testing.assert_close(orc.position_update(1, g['s'], g['x'], g['v']), g['pos1.x'], **TOL)
+        torch.testing.assert_close(orc.edge_update(1, batch, g['s'], g['ef'], d), g['edge1.ef'], **TOL)
+        os_, ov = orc.gvp('conv_layers.0.edge_message.0', g['gvp0.in_s'], g['gvp0.in_v'])
+        torch.testing.assert_close(os_, g['gvp0.out_s'], **TOL)
+        torch.testing.assert_close(ov, g['gvp0.out_v'], **TOL)
+        if cfg.self_conditioning:
+            prev = {k: g[f'sc.prev.{k}'] for k in 'xace'}
+            so, eo = orc.self_conditioning(batch, g['s'], g['x'], g['sc.ef_in'], prev)
+            torch.testing.assert_close(so, g['sc.s'], **TOL)
+            torch.testing.assert_close(eo, g['sc.ef'], **TOL)
+
+
+@pytest.mark.parametrize('fname,name', [('integrate_flowmol3_F7.npz', 'flowmol3'),
+                                        ('integrate_qm9_C1.npz', 'qm9'),
+                                        ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc')])
+def test_integrate_matches_reference(golden_dir, fname, name):
+    """Free-running trajectory with the reference's recorded noise: categorical outcomes bit-exact,
+    coordinates to 1e-5 (config C1 of BASELINE.json is the qm9 case)."""
+    cfg = presets.PRESETS[name]()
+    g = _load(golden_dir, fname)
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
+    prior = {'x_0': g['x_0'], 'a_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_atom_types),
+             'c_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_charges),
+             'e_0': cpu_ref.edge_prior(batch.upper_edge_mask, cfg.n_bond_types)}
+    noise = cpu_ref.TapeNoise(tape)
+    with torch.no_grad():
+        out, frames = orc.integrate(batch, prior, int(g['T']), noise=noise, visualize=True)
+    assert noise.pos == len(tape)                      # same number/order of draws as the reference
+    m = batch.upper_edge_mask
+    assert torch.equal(out['a_1'].argmax(-1), g['a_1'])
+    assert torch.equal(out['c_1'].argmax(-1), g['c_1'])
+    assert torch.equal(out['e_1'][m].argmax(-1), g['e_1_upper'])
+    assert torch.equal(out['e_1'][m], out['e_1'][~m])
+    torch.testing.assert_close(out['x_1'], g['x_1'], rtol=1e-5, atol=1e-5)
+    n0 = int(g['n_atoms'][0])
+    x_traj0 = torch.stack([f[:n0] for f in frames['x']])
+    torch.testing.assert_close(x_traj0, g['traj0.x'], rtol=1e-5, atol=1e-5)
+    # no mask tokens survive the last step
+    assert (out['a_1'].argmax(-1) != cfg.n_atom_types).all()
+    assert (out['e_1'].argmax(-1) != cfg.n_bond_types).all()
+
+
+def test_misc_matches_reference(golden_dir):
+    g = _load(golden_dir, 'misc.npz')
+    torch.testing.assert_close(cpu_ref.time_embedding(g['temb.t'], 64), g['temb.out'], **TOL)
+    torch.testing.assert_close(cpu_ref.rbf(g['rbf.d'], 10, 32), g['rbf.out10'], **TOL)
+    torch.testing.assert_close(cpu_ref.rbf(g['rbf.d'], 12, 32), g['rbf.out12'], **TOL)
+    for n in (2, 3, 7):
+        assert torch.equal(cpu_ref.build_edge_idxs(n), g[f'edges.{n}'])
+    a, ap = cpu_ref.alpha_tables(g['alpha.t'])
+    assert torch.equal(a, g['alpha.a']) and torch.equal(ap, g['alpha.ap'])
+
+
+@pytest.mark.parametrize('case', [0, 1, 2, 3])
+def test_campbell_step_matches_reference(golden_dir, case):
+    """purity-sampling edge cases: a molecule with h=0, one with m=h, hc=0 branch, last step."""
+    g = _load(golden_dir, 'misc.npz')
+    cfg = presets.flowmol3()
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    hc, last, eta, alpha, dt = [float(v) for v in g[f'ctmc.{case}.params']]
+    sizes = g['ctmc.sizes']
+    bidx = torch.arange(sizes.shape[0]).repeat_interleave(sizes)
+    tape = [g[f'ctmc.{case}.noise{i}'] for i in range(3 if not last else 2)]
+    xt1h, x11h = orc.campbell_step(g['ctmc.p'], g['ctmc.xt'].clone(), eta, hc, torch.tensor(alpha), torch.tensor(1.0),
+                                   torch.tensor(dt), sizes.shape[0], 12, 11, bool(last), bidx, cpu_ref.TapeNoise(tape))
+    assert torch.equal(xt1h.argmax(-1), g[f'ctmc.{case}.xt_new'])
+    assert torch.equal(x11h.argmax(-1), g[f'ctmc.{case}.x1'])
