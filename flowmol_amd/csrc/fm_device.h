@@ -1,0 +1,237 @@
+// Device-side building blocks for the FlowMol3 sampling hot path on gfx950 (MI355X, CDNA4).
+//
+// Everything here is written for 64-wide wavefronts and the f32-input matrix instruction
+// v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, 32-cycle issue per SIMD, the f32
+// vector rate).  A workgroup is 512 threads = 8 waves (2 per SIMD) working on a tile of TM = 64
+// rows (edges, nodes or pairs) whose activations stay in LDS between the fused stages; weights are
+// pre-packed on the host into MFMA B-fragment order and streamed from L2.
+//
+// Layout conventions
+//   * LDS activation tiles are row-major [row][ld] f32 with (ld/4) odd, so that the A-fragment read
+//     (lane (i=l&15,h=l>>4) reads float2 at row i, col 8*ks+2*h -> one ds_read_b64) is bank-conflict
+//     free: rows i=0..15 start on distinct multiples of 4 banks and the two lane halves cover
+//     disjoint 4-bank groups (MI355X_MICROARCH.md §LDS, ds_read_b64 = 2 x 32-lane groups, 64 banks).
+//   * packed weights Wp[(ks*NT + nt)*64 + lane] = (W[8ks+2h][16nt+j], W[8ks+2h+1][16nt+j]),
+//     j=lane&15, h=lane>>4: one coalesced 512-B global_load_dwordx2 per (ks, nt) per wave.
+//   * the MFMA k-slots of lane-group h within k-superstep ks are k = 8ks+2h (x) and 8ks+2h+1 (y);
+//     A and B use the same assignment, so the dot product is complete (summation order is a
+//     permutation of k, which f32 parity tolerates: SURVEY.md §7 "hard parts").
+//   * C/D fragment: acc[r] <-> row = 4*(lane>>4)+r, col = lane&15 (cdna_hip_programming.md §3).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FM_TM 64          // rows per workgroup tile
+#define FM_THREADS 512    // 8 waves
+#define FM_WAVES 8
+#define FM_LDX 300        // scalar tile leading dim: >= 296, (300/4)=75 odd
+#define FM_LDG 33         // gate tile leading dim
+
+__device__ __forceinline__ float fm_silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float fm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Gaussian RBF, reference flowmol/utils/embedding.py:19-34: mu_k = k*Dmax/(R-1), sigma = Dmax/R
+__device__ __forceinline__ float fm_rbf(float d, int k, float mu_step, float inv_sigma) {
+    float z = (d - (float)k * mu_step) * inv_sigma;
+    return expf(-(z * z));
+}
+
+// distance with the reference's clamps: sqrt(max(|dx|^2,1e-8)) (+1e-8 added by the caller where the reference does)
+__device__ __forceinline__ float fm_norm3(float dx, float dy, float dz) {
+    float s = dx * dx + dy * dy + dz * dz;
+    return sqrtf(fmaxf(s, 1e-8f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level GEMM: acc[MT][NT] += A(lds rows m0.., K) * Wp(cols of tiles nt0..nt0+NT-1)
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* A, int lda, int K8,
+                                             const float2* __restrict__ Wp, int ntiles, int nt0, int lane) {
+    const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
+    const float2* wp = Wp + (size_t)nt0 * 64 + lane;
+    const size_t wstep = (size_t)ntiles * 64;
+#pragma unroll 2
+    for (int ks = 0; ks < K8; ++ks) {
+        float2 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(ap + mt * 16 * lda + 8 * ks);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = wp[(size_t)ks * wstep + (size_t)nt * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+            }
+    }
+}
+
+// block-level GEMM over an (mtiles x ntiles) grid of 16x16 output tiles: super-tiles of MT x NT tiles
+// are dealt round-robin to the 8 waves; epi(row, col, value) is called for every output element.
+// No barriers inside: the caller orders LDS hazards.
+template <int MT, int NT, class Epi>
+__device__ __forceinline__ void fm_block_gemm(const float* X, int ldx, int mtiles, int K8,
+                                              const float2* __restrict__ Wp, int ntiles, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sm = mtiles / MT, sn = ntiles / NT;
+    for (int st = wave; st < sm * sn; st += FM_WAVES) {
+        const int m0 = (st / sn) * MT, n0 = (st % sn) * NT;
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fm_wave_gemm<MT, NT>(acc, X + (size_t)m0 * 16 * ldx, ldx, K8, Wp, ntiles, n0, lane);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epi((m0 + i) * 16 + 4 * (lane >> 4) + r, (n0 + j) * 16 + (lane & 15), acc[i][j][r]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One Geometric Vector Perceptron on a 64-row tile (reference flowmol/models/gvp.py:90-133)
+// ---------------------------------------------------------------------------------------------
+struct FmGvpW {
+    const float2* Wv1;   // [Wh | Wcp] packed, K = V, N = V+16          (unused when FIRST)
+    const float2* Wu;    // packed, K = V+8, N = VOUT padded to 16
+    const float2* Ws;    // scalar linear packed, K = (FIRST ? 160 : 256) + V + 8, N = 256
+    const float* bs;     // (256)
+    const float2* Wg;    // gates packed, K = 256, N = VOUT padded to 16
+    const float* bg;     // (VOUT padded)
+};
+
+// LDS tile geometry shared by every GVP-based kernel
+template <int V>
+struct FmGvpTile {
+    static constexpr int LDVI = V + 4;       // Vin  [3*TM][LDVI]   (36 | 20: /4 odd)
+    static constexpr int LDVH = V + 20;      // Vh   [3*TM][LDVH]   (52 | 36: /4 odd)
+    static constexpr int KU = V + 8;         // K of the Wu GEMM    (hidden h + 4 cp (+pad) <= V+8)
+    static constexpr int X_FLOATS = FM_TM * FM_LDX;
+    static constexpr int VIN_FLOATS = 3 * FM_TM * LDVI;
+    static constexpr int VH_FLOATS = 3 * FM_TM * LDVH;
+    static constexpr int G_FLOATS = FM_TM * FM_LDG;
+    static constexpr int TOTAL_FLOATS = X_FLOATS + VIN_FLOATS + VH_FLOATS + G_FLOATS;
+};
+
+// State on entry
+//   FIRST : Vh[xyz*TM+r][0..V]    = hidden vectors (h = V+1), Vh[..][V+1..V+7] = 0, Vh[..][V+8..V+15] = Vcp (8),
+//           X[r][0..159]          = [rbf(32) | ef(128)]
+//   !FIRST: Vin[xyz*TM+r][0..V-1] = input vectors,  X[r][0..255] = input scalars
+// State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
+// `addend`/`arows` (optional): per-row gather added before the SiLU (the hoisted W_s * s[src] term).
+// All 512 threads must call it (it contains barriers); it ends with a barrier.
+template <int V, int VOUT, bool FIRST, bool SIGMOID>
+__device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
+                                            const float* __restrict__ addend, const int* arows) {
+    typedef FmGvpTile<V> T;
+    constexpr int H = FIRST ? V + 1 : V;                 // hidden vector channels
+    constexpr int SOFF = FIRST ? 160 : 256;              // where sh goes in X
+    constexpr int K8S = (SOFF + V + 8) / 8;
+    constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
+    constexpr int CPSRC = FIRST ? V + 8 : V;             // where the 8 Vcp channels sit in Vh
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (!FIRST) {
+        // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
+        fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * FM_TM / 16, V / 8, w.Wv1, (V + 16) / 16,
+                            [&](int row, int col, float v) { Vh[row * T::LDVH + col] = v; });
+        __syncthreads();
+    }
+    // cross products cp_p = a_p x b_p, (a,b) = Vcp[0..3], Vcp[4..7]  (gvp.py:105-112); written at
+    // columns H..H+3.  Each thread touches only its own columns, so no barrier is needed inside.
+    if (tid < FM_TM * 4) {
+        const int r = tid >> 2, p = tid & 3;
+        float a[3], b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[c] = Vh[(c * FM_TM + r) * T::LDVH + CPSRC + p];
+            b[c] = Vh[(c * FM_TM + r) * T::LDVH + CPSRC + 4 + p];
+        }
+        const float cx = a[1] * b[2] - a[2] * b[1];
+        const float cy = a[2] * b[0] - a[0] * b[2];
+        const float cz = a[0] * b[1] - a[1] * b[0];
+        if (!FIRST) {   // the b-channels sit inside the K range of the Wu GEMM: clear them
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Vh[(c * FM_TM + r) * T::LDVH + V + 4 + p] = 0.f;
+        }
+        Vh[(0 * FM_TM + r) * T::LDVH + H + p] = cx;
+        Vh[(1 * FM_TM + r) * T::LDVH + H + p] = cy;
+        Vh[(2 * FM_TM + r) * T::LDVH + H + p] = cz;
+    }
+    __syncthreads();
+    // sh = |Vh_full| per channel with the reference's clamp (gvp.py:116, _norm_no_nan) -> X[:, SOFF..]
+    for (int idx = tid; idx < FM_TM * (V + 8); idx += FM_THREADS) {
+        const int r = idx / (V + 8), c = idx % (V + 8);
+        float val = 0.f;
+        if (c < H + 4) {
+            const float vx = Vh[(0 * FM_TM + r) * T::LDVH + c];
+            const float vy = Vh[(1 * FM_TM + r) * T::LDVH + c];
+            const float vz = Vh[(2 * FM_TM + r) * T::LDVH + c];
+            val = fm_norm3(vx, vy, vz);
+        }
+        X[r * FM_LDX + SOFF + c] = val;
+    }
+    __syncthreads();
+    // Vu = Vh_full * Wu -> Vin (the input vectors are dead by now)
+    fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * FM_TM / 16, T::KU / 8, w.Wu, VOP / 16,
+                        [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
+    // scalar linear: 64 x K -> 256, wave w owns column tiles 2w, 2w+1 for all 4 row tiles
+    {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fm_wave_gemm<4, 2>(acc, X, FM_LDX, K8S, w.Ws, 16, 2 * wave, lane);
+        __syncthreads();                      // every wave has finished reading X (and Vh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = (2 * wave + j) * 16 + (lane & 15);
+                const float bias = w.bs[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + 4 * (lane >> 4) + r;
+                    float v = acc[i][j][r] + bias;
+                    if (addend != nullptr) {
+                        const int ar = arows[row];
+                        if (ar >= 0) v += addend[(size_t)ar * 256 + col];
+                    }
+                    X[row * FM_LDX + col] = fm_silu(v);
+                }
+            }
+        __syncthreads();
+    }
+    // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128)
+    fm_block_gemm<1, 1>(X, FM_LDX, FM_TM / 16, 256 / 8, w.Wg, VOP / 16, [&](int row, int col, float v) {
+        v += w.bg[col];
+        G[row * FM_LDG + col] = SIGMOID ? fm_sigmoid(v) : v;
+    });
+    __syncthreads();
+    for (int idx = tid; idx < 3 * FM_TM * VOUT; idx += FM_THREADS) {
+        const int row = idx / VOUT, u = idx % VOUT;
+        Vin[row * T::LDVI + u] *= G[(row % FM_TM) * FM_LDG + u];
+    }
+    __syncthreads();
+}
+
+// LayerNorm statistics of one LDS row handled by a group of 8 consecutive lanes (n = 256 or 128):
+// two-pass mean / biased variance like torch.nn.functional.layer_norm.
+__device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {
+    float s = 0.f;
+    for (int c = sub; c < n; c += 8) s += row[c];
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    mean = s / (float)n;
+    float q = 0.f;
+    for (int c = sub; c < n; c += 8) { const float d = row[c] - mean; q += d * d; }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    rstd = 1.0f / sqrtf(q / (float)n + 1e-5f);
+}

@@ -1,0 +1,805 @@
+// Host side of libflowmol_hip.so: the C ABI of include/flowmol_hip.h.
+//  - fm_create    : looks the reference's state-dict tensors up by name, repacks them into MFMA
+//                   B-fragment order (fm_device.h) with the algebraic hoists of SURVEY.md §7, uploads once
+//  - fm_batch_bind: carves the caller's workspace, builds the destination-sorted edge layout on device
+//  - fm_forward / fm_ctmc_step / fm_integrate: enqueue the kernel sequence on the caller's stream
+// Compiled as HIP for gfx950 (flowmol_amd/build.py).  No host synchronisation on the hot path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/flowmol_hip.h"
+#include "fm_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ProfEvent { int kid; hipEvent_t a, b; };
+
+struct MlpW { const float2* W1; const float* b1; const float2* W2; const float* b2; int K1p, H, O; };
+
+struct ConvW {
+    const float2* Wps; const float2* Wpv; const float* w0;
+    FmGvpW msg[3]; FmGvpW upd[3];
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+struct UpdW {
+    FmGvpW pos[3];
+    const float2* Wasd; const float2* W1; const float* b1; const float2* W2; const float* b2;
+    const float *ln_g, *ln_b;
+};
+
+}  // namespace
+
+struct fm_ctx {
+    fm_config cfg{};
+    std::string err;
+    int V = 32, na = 0, nc = 0, ne = 0;
+    float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
+    // ---- weights (one device arena)
+    char* arena = nullptr; size_t arena_bytes = 0;
+    const float *emb_a = nullptr, *emb_c = nullptr;
+    MlpW node_embed{}, edge_embed{}, sc_node{}, sc_edge{}, node_head{}, edge_head{};
+    const float *node_ln_g = nullptr, *node_ln_b = nullptr;
+    const float *ef_tab = nullptr, *T1 = nullptr;          // (ne+1,128) each
+    std::vector<ConvW> conv;
+    std::vector<UpdW> upd;
+    int tab_rows = 0, tab_kp = 0;
+    // ---- batch binding
+    bool bound = false;
+    FmBatch b{};
+    int n_tiles_e = 0, n_tiles_n = 0, n_tiles_u = 0;
+    float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
+    float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *tab_in = nullptr;
+    fm_dst boot{};
+    int *cnt = nullptr; unsigned char* hc_flag = nullptr;
+    int32_t *sa1 = nullptr, *sc1 = nullptr, *se1 = nullptr;
+    // ---- taps / profiling
+    std::map<std::string, void*> taps;
+    bool prof = false;
+    std::vector<ProfEvent> prof_events;
+    std::vector<std::string> prof_names;
+    std::map<std::string, std::pair<double, int64_t>> prof_acc;
+};
+
+namespace {
+
+int fail(fm_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define FM_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail((c), FM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+inline int pad8(int k) { return (k + 7) / 8 * 8; }
+inline int pad16(int k) { return (k + 15) / 16 * 16; }
+inline int ld_for(int k) { int ld = (k + 3) / 4 * 4; while (((ld / 4) & 1) == 0) ld += 4; return ld; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------- weight blob access
+struct Blob {
+    const float* base; const fm_tensor_desc* t; int n;
+    std::string err;
+    const float* get(const std::string& name, int64_t d0, int64_t d1 = -1) {
+        for (int i = 0; i < n; ++i)
+            if (name == t[i].name) {
+                const bool ok = (d1 < 0) ? (t[i].ndim == 1 && t[i].shape[0] == d0)
+                                         : (t[i].ndim == 2 && t[i].shape[0] == d0 && t[i].shape[1] == d1);
+                if (!ok) {
+                    char b[256];
+                    snprintf(b, sizeof b, "tensor %s: shape (%lld,%lld) != expected (%lld,%lld)", name.c_str(),
+                             (long long)t[i].shape[0], (long long)(t[i].ndim > 1 ? t[i].shape[1] : -1), (long long)d0, (long long)d1);
+                    if (err.empty()) err = b;
+                    return nullptr;
+                }
+                return base + t[i].offset;
+            }
+        if (err.empty()) err = "missing tensor " + name;
+        return nullptr;
+    }
+};
+
+// host-side staging arena; device pointers are offsets into the final device arena
+struct Arena {
+    std::vector<float> h;
+    size_t add(const std::vector<float>& v) {
+        size_t off = align_up(h.size(), 64);
+        h.resize(off, 0.f);
+        h.insert(h.end(), v.begin(), v.end());
+        return off;
+    }
+    size_t add_raw(const float* p, size_t n) { return add(std::vector<float>(p, p + n)); }
+};
+
+// pack W_logical[k][n] (K x N, K%8==0, N%16==0) into fragment order
+std::vector<float> pack(int K, int N, const std::function<float(int, int)>& w) {
+    const int K8 = K / 8, NT = N / 16;
+    std::vector<float> out((size_t)K8 * NT * 64 * 2);
+    for (int ks = 0; ks < K8; ++ks)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int j = lane & 15, h = lane >> 4;
+                const size_t o = (((size_t)ks * NT + nt) * 64 + lane) * 2;
+                out[o] = w(8 * ks + 2 * h, 16 * nt + j);
+                out[o + 1] = w(8 * ks + 2 * h + 1, 16 * nt + j);
+            }
+    return out;
+}
+
+struct Fix { const void** slot; size_t off; };
+
+struct Builder {
+    Arena A; std::vector<Fix> fix;
+    template <class T> void put(const T*& slot, const std::vector<float>& v) { fix.push_back({(const void**)&slot, A.add(v)}); }
+};
+
+// Linear weight W (out,in) row-major -> packed with K = Kp (logical input index remapped by kmap), N = Np
+void pack_linear(Builder& B, const float2*& slot, const float* W, int out, int in, int Kp, int Np,
+                 const std::function<int(int)>& kmap) {
+    B.put(slot, pack(Kp, Np, [&](int k, int n) -> float {
+        if (n >= out) return 0.f;
+        const int kk = kmap(k);
+        return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
+    }));
+}
+void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
+    std::vector<float> t(np, 0.f);
+    for (int i = 0; i < n; ++i) t[i] = v[i];
+    B.put(slot, t);
+}
+
+// one non-first GVP (vin = V, hidden = V): reference gvp.py:30-88 parameter shapes
+bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int vout, FmGvpW& g) {
+    const int vop = vout < 16 ? 16 : vout;
+    const float* Wh = bl.get(key + ".Wh", V, V);
+    const float* Wcp = bl.get(key + ".Wcp", V, 8);
+    const float* Wu = bl.get(key + ".Wu", V + 4, vout);
+    const float* Ws = bl.get(key + ".to_feats_out.0.weight", 256, V + 4 + 256);
+    const float* bs = bl.get(key + ".to_feats_out.0.bias", 256);
+    const float* Wg = bl.get(key + ".scalar_to_vector_gates.weight", vout, 256);
+    const float* bg = bl.get(key + ".scalar_to_vector_gates.bias", vout);
+    if (!Wh || !Wcp || !Wu || !Ws || !bs || !Wg || !bg) return false;
+    B.put(g.Wv1, pack(V, V + 16, [&](int k, int n) -> float {
+        if (n < V) return Wh[k * V + n];
+        if (n < V + 8) return Wcp[k * 8 + (n - V)];
+        return 0.f; }));
+    B.put(g.Wu, pack(V + 8, vop, [&](int k, int n) -> float { return (k < V + 4 && n < vout) ? Wu[k * vout + n] : 0.f; }));
+    pack_linear(B, g.Ws, Ws, 256, V + 4 + 256, 256 + V + 8, 256, [&](int k) { return k < 256 + V + 4 ? k : -1; });
+    pad_vec(B, g.bs, bs, 256, 256);
+    pack_linear(B, g.Wg, Wg, vout, 256, 256, vop, [](int k) { return k; });
+    pad_vec(B, g.bg, bg, vout, vop);
+    return true;
+}
+
+template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
+
+size_t lds_gvp(int V, bool with_meta) {
+    size_t fl = (size_t)FM_TM * FM_LDX + 3 * FM_TM * (V + 4) + 3 * FM_TM * (V + 20) + FM_TM * FM_LDG;
+    return fl * 4 + (with_meta ? (size_t)FM_TM * 6 * 4 : 0);
+}
+size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 4 * FM_TM * 4; }
+size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }
+size_t lds_edge_upd() { return ((size_t)FM_TM * 164 + FM_TM * 132) * 4 + FM_TM * 3 * 4; }
+
+// ---------------------------------------------------------------------------------------- launch helper
+int kid_of(fm_ctx* c, const char* name) {
+    for (size_t i = 0; i < c->prof_names.size(); ++i) if (c->prof_names[i] == name) return (int)i;
+    c->prof_names.push_back(name);
+    return (int)c->prof_names.size() - 1;
+}
+
+struct Launch {
+    fm_ctx* c; hipStream_t st; int rc = FM_OK;
+    template <class K, class... Args>
+    void operator()(const char* name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
+        if (rc != FM_OK || grid.x == 0) return;
+        ProfEvent pe{};
+        if (c->prof) {
+            pe.kid = kid_of(c, name);
+            (void)hipEventCreate(&pe.a); (void)hipEventCreate(&pe.b);
+            (void)hipEventRecord(pe.a, st);
+        }
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+        hipError_t e = hipGetLastError();
+        if (c->prof) { (void)hipEventRecord(pe.b, st); c->prof_events.push_back(pe); }
+        if (e != hipSuccess) rc = fail(c, FM_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e));
+    }
+    void copy(void* dst, const void* src, size_t bytes) {
+        if (rc != FM_OK || bytes == 0) return;
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = fail(c, FM_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    }
+    void zero(void* dst, size_t bytes) {
+        if (rc != FM_OK || bytes == 0) return;
+        hipError_t e = hipMemsetAsync(dst, 0, bytes, st);
+        if (e != hipSuccess) rc = fail(c, FM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    void tap(const std::string& name, const void* src, size_t bytes) {
+        auto it = c->taps.find(name);
+        if (it != c->taps.end()) copy(it->second, src, bytes);
+    }
+};
+
+template <int MODE>
+void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows) {
+    a.rows = rows; a.K1p = w.K1p; a.H = w.H; a.O = w.O;
+    a.W1 = w.W1; a.b1 = w.b1; a.W2 = w.W2; a.b2 = w.b2;
+    a.ldx = ld_for(w.K1p > w.O ? w.K1p : w.O); a.ldh = ld_for(w.H);
+    L(name, fm_k_mlp2<MODE>, dim3((rows + FM_TM - 1) / FM_TM), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
+}
+
+// ---------------------------------------------------------------------------------------- one network evaluation
+template <int V>
+int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
+             bool taps_on) {
+    Launch L{c, st};
+    const FmBatch& b = c->b;
+    const int N = b.N, E = b.E, U = b.U;
+    const fm_config& cf = c->cfg;
+    const int nc1 = c->nc + 1;
+    auto tap = [&](const std::string& n, const void* p, size_t bytes) { if (taps_on) L.tap(n, p, bytes); };
+
+    FmMlpArgs ma{};
+    ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
+    ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
+    if (prev) {
+        FmMlpArgs a = ma;
+        a.s_tab = c->s_tab; a.tok_a = state->a_t; a.tok_c = state->c_t; a.n_c1 = nc1;
+        a.prev_a = prev->a; a.prev_c = prev->c; a.prev_x = prev->x; a.x_t = state->x_t;
+        a.out = c->s;
+        launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N);
+        FmMlpArgs e = ma;
+        e.e_src = b.e_src; e.e_dst = b.e_dst; e.e_pair = b.e_pair; e.tok_e = state->e_t;
+        e.prev_e = prev->e; e.prev_x = prev->x; e.x_t = state->x_t; e.T1 = c->T1; e.ef_tab = c->ef_tab;
+        e.out = c->ef;
+        launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, E);
+        tap("sc.s", c->s, (size_t)N * 256 * 4);
+        tap("sc.ef", c->ef, (size_t)E * 128 * 4);
+    } else {
+        L("gather_s", fm_k_gather_rows, dim3(std::min(2048, (N * 64 + 255) / 256)), dim3(256), 0, c->s, (const float*)c->s_tab, 256, N,
+          (const int*)state->a_t, (const int*)state->c_t, nc1, (const int*)nullptr);
+        L("gather_ef", fm_k_gather_rows, dim3(std::min(4096, (int)(((size_t)E * 32 + 255) / 256))), dim3(256), 0, c->ef, c->ef_tab, 128, E,
+          (const int*)state->e_t, (const int*)nullptr, 0, (const int*)b.e_pair);
+        tap("embed.s", c->s, (size_t)N * 256 * 4);
+        tap("embed.ef", c->ef, (size_t)E * 128 * 4);
+    }
+    L.zero(c->v, (size_t)N * 3 * V * 4);
+    L.copy(c->xw, state->x_t, (size_t)N * 3 * 4);
+
+    const dim3 blk(FM_THREADS);
+    const dim3 gn(c->n_tiles_n), ge(c->n_tiles_e);
+    for (int i = 0; i < cf.n_convs; ++i) {
+        const ConvW& cw = c->conv[i];
+        FmProjArgs pa{};
+        pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV;
+        L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
+        FmMsgArgs m{};
+        m.b = b; m.x = c->xw; m.ef = c->ef; m.Ps = c->Ps; m.PV = c->PV; m.w0 = cw.w0;
+        m.g0 = cw.msg[0]; m.g1 = cw.msg[1]; m.g2 = cw.msg[2];
+        m.part_s = c->part_s; m.part_v = c->part_v;
+        m.rbf_mu_step = c->rbf_mu_step; m.rbf_inv_sigma = c->rbf_inv_sigma;
+        // per-edge message taps are written straight into the caller's buffers (both must be registered)
+        const bool dbg = taps_on && i == 0 && c->taps.count("conv0.msg.s") && c->taps.count("conv0.msg.v");
+        m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
+        L("edge_message", fm_k_edge_message<V>, ge, blk, lds_gvp(V, true), m);
+        FmNodeUpdArgs nu{};
+        nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
+        nu.g0 = cw.upd[0]; nu.g1 = cw.upd[1]; nu.g2 = cw.upd[2];
+        nu.ln1_g = cw.ln1_g; nu.ln1_b = cw.ln1_b; nu.ln2_g = cw.ln2_g; nu.ln2_b = cw.ln2_b;
+        const std::string ci = "conv" + std::to_string(i);
+        const bool tagg = taps_on && (c->taps.count(ci + ".agg.s") || c->taps.count(ci + ".agg.v"));
+        nu.agg_s = tagg ? c->Ps : nullptr;        // Ps / PV are dead until the next conv: reuse as tap scratch
+        nu.agg_v = tagg ? c->PV : nullptr;
+        L("node_update", fm_k_node_update<V>, gn, blk, lds_gvp(V, false), nu);
+        if (tagg) { tap(ci + ".agg.s", c->Ps, (size_t)N * 256 * 4); tap(ci + ".agg.v", c->PV, (size_t)N * 3 * V * 4); }
+        tap(ci + ".s", c->s, (size_t)N * 256 * 4);
+        tap(ci + ".v", c->v, (size_t)N * 3 * V * 4);
+        const int u = cf.update_after[i];
+        if (u >= 0) {
+            const UpdW& uw = c->upd[u];
+            FmPosArgs pp{};
+            pp.N = N; pp.s = c->s; pp.v = c->v; pp.x = c->xw; pp.g0 = uw.pos[0]; pp.g1 = uw.pos[1]; pp.g2 = uw.pos[2];
+            L("pos_update", fm_k_pos_update<V>, gn, blk, lds_gvp(V, false), pp);
+            FmProjArgs pa2{};
+            pa2.N = N; pa2.s = c->s; pa2.v = c->v; pa2.Wasd = uw.Wasd; pa2.Asd = c->Asd;
+            L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
+            FmEdgeUpdArgs eu{};
+            eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
+            eu.ln_g = uw.ln_g; eu.ln_b = uw.ln_b; eu.rbf_mu_step = c->rbf_mu_step; eu.rbf_inv_sigma = c->rbf_inv_sigma;
+            L("edge_update", fm_k_edge_update, ge, blk, lds_edge_upd(), eu);
+            const std::string ui = "upd" + std::to_string(i);
+            tap(ui + ".x", c->xw, (size_t)N * 3 * 4);
+            tap(ui + ".ef", c->ef, (size_t)E * 128 * 4);
+        }
+    }
+    {
+        FmMlpArgs a = ma;
+        a.in = c->s; a.out = out->a; a.out2 = out->c;
+        launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N);
+        FmMlpArgs e = ma;
+        e.ef = c->ef; e.p_e0 = b.p_e0; e.p_e1 = b.p_e1; e.out = out->e;
+        launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U);
+    }
+    L.copy(out->x, c->xw, (size_t)N * 3 * 4);
+    if (remove_com) L("remove_com", fm_k_remove_com, dim3(b.B), dim3(64), 0, out->x, (const int*)b.mol_node_off);
+    return L.rc;
+}
+
+int embed_table(fm_ctx* c, hipStream_t st, const float* temb) {
+    Launch L{c, st};
+    const fm_config& cf = c->cfg;
+    const int ta = cf.a_token_dim ? cf.a_token_dim : c->na + 1, tc = cf.c_token_dim ? cf.c_token_dim : c->nc + 1;
+    L("embed_in", fm_k_embed_in, dim3((c->tab_rows * c->tab_kp + 255) / 256), dim3(256), 0, c->tab_in, c->tab_kp, c->na + 1, c->nc + 1,
+      ta, tc, cf.time_embedding_dim, c->emb_a, c->emb_c, temb);
+    FmMlpArgs a{};
+    a.in = c->tab_in; a.in_ld = c->tab_kp; a.out = c->s_tab; a.out_ld = 256; a.ln_g = c->node_ln_g; a.ln_b = c->node_ln_b;
+    launch_mlp<FM_MLP_TABLE>(L, "embed_table", a, c->node_embed, c->tab_rows);
+    return L.rc;
+}
+
+int forward_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const float* temb, const fm_dst* prev, int bootstrap,
+                 int remove_com, const fm_dst* out) {
+    int rc = embed_table(c, st, temb);
+    if (rc) return rc;
+    const bool sc = c->cfg.self_conditioning != 0;
+    if (sc && !prev && bootstrap) {
+        rc = (c->V == 32) ? evaluate<32>(c, st, state, nullptr, 0, &c->boot, false) : evaluate<16>(c, st, state, nullptr, 0, &c->boot, false);
+        if (rc) return rc;
+        if (c->taps.count("boot.x")) { Launch L{c, st}; L.tap("boot.x", c->boot.x, (size_t)c->b.N * 12); L.tap("boot.a", c->boot.a, (size_t)c->b.N * c->na * 4);
+            L.tap("boot.c", c->boot.c, (size_t)c->b.N * c->nc * 4); L.tap("boot.e", c->boot.e, (size_t)c->b.U * c->ne * 4); if (L.rc) return L.rc; }
+        prev = &c->boot;
+    }
+    if (!sc) prev = nullptr;
+    return (c->V == 32) ? evaluate<32>(c, st, state, prev, remove_com, out, true) : evaluate<16>(c, st, state, prev, remove_com, out, true);
+}
+
+int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* dst, const fm_step_noise* nz,
+              const fm_step_scalars* sc, const fm_sampled* smp) {
+    Launch L{c, st};
+    const FmBatch& b = c->b;
+    L("x_step", fm_k_x_step, dim3((b.N * 3 + 255) / 256), dim3(256), 0, state->x_t, (const float*)dst->x, sc->x_coef, sc->dt, b.N * 3);
+    struct Mod { int rows, K; const float* p; const int* mol; int* xt; int* x1; const float *q, *u1, *u2; };
+    Mod mods[3] = {
+        {b.N, c->na, dst->a, b.node_mol, state->a_t, (smp && smp->a1) ? smp->a1 : c->sa1, nz->q_a, nz->u1_a, nz->u2_a},
+        {b.N, c->nc, dst->c, b.node_mol, state->c_t, (smp && smp->c1) ? smp->c1 : c->sc1, nz->q_c, nz->u1_c, nz->u2_c},
+        {b.U, c->ne, dst->e, b.pair_mol, state->e_t, (smp && smp->e1) ? smp->e1 : c->se1, nz->q_e, nz->u1_e, nz->u2_e},
+    };
+    L.zero(c->cnt, (size_t)6 * b.B * 4);
+    for (int m = 0; m < 3; ++m) {
+        if (mods[m].rows == 0) continue;
+        FmCtmcArgs a{};
+        a.rows = mods[m].rows; a.K = mods[m].K; a.B = b.B; a.p = mods[m].p; a.row_mol = mods[m].mol; a.xt = mods[m].xt; a.x1 = mods[m].x1;
+        a.q = mods[m].q; a.u1 = mods[m].u1; a.u2 = mods[m].u2; a.inv_temp_div = sc->cat_temperature; a.hc_thresh = sc->hc_thresh;
+        a.unmask_prob = sc->unmask_prob[m]; a.mask_prob = sc->mask_prob[m]; a.last_step = sc->last_step;
+        a.cnt_m = c->cnt + 2 * m * b.B; a.cnt_h = c->cnt + (2 * m + 1) * b.B; a.hc_flag = c->hc_flag;
+        const dim3 g((a.rows + 255) / 256);
+        L("ctmc_pass1", fm_k_ctmc_pass1, g, dim3(256), 0, a);
+        L("ctmc_pass2", fm_k_ctmc_pass2, g, dim3(256), 0, a);
+    }
+    return L.rc;
+}
+
+}  // namespace
+
+// ================================================================================================= C ABI
+extern "C" {
+
+const char* fm_last_error(const fm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+int fm_abi_version(void) { return FM_ABI_VERSION; }
+
+int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors, const float* host_blob, fm_ctx** out) {
+    if (!cfg || !tensors || !host_blob || !out) return fail(nullptr, FM_ERR_INVALID, "fm_create: null argument");
+    if (cfg->abi_version != FM_ABI_VERSION) return fail(nullptr, FM_ERR_INVALID, "fm_create: ABI version %d != %d", cfg->abi_version, FM_ABI_VERSION);
+    if (cfg->n_hidden_scalars != 256 || cfg->n_hidden_edge_feats != 128 || cfg->rbf_dim != 32)
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: kernels are built for S=256,F=128,R=32");
+    if (cfg->n_vec_channels != 16 && cfg->n_vec_channels != 32) return fail(nullptr, FM_ERR_INVALID, "fm_create: n_vec_channels must be 16 or 32");
+    if (cfg->n_convs < 1 || cfg->n_convs > FM_MAX_CONVS) return fail(nullptr, FM_ERR_INVALID, "fm_create: bad n_convs");
+    if (cfg->n_atom_types + 1 > 16 || cfg->n_charges + 1 > 16 || cfg->n_bond_types + 1 > 16 || cfg->n_atom_types + cfg->n_charges > 32)
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: categorical widths exceed kernel limits");
+    const bool tok = cfg->a_token_dim > 0;
+    if ((cfg->c_token_dim > 0) != tok || (cfg->e_token_dim > 0) != tok) return fail(nullptr, FM_ERR_INVALID, "fm_create: token dims must be all zero or all non-zero");
+
+    fm_ctx* c = new fm_ctx();
+    c->cfg = *cfg;
+    const int V = c->V = cfg->n_vec_channels;
+    const int na = c->na = cfg->n_atom_types, nc = c->nc = cfg->n_charges, ne = c->ne = cfg->n_bond_types;
+    c->rbf_mu_step = cfg->rbf_dmax / (float)(cfg->rbf_dim - 1);
+    c->rbf_inv_sigma = 1.0f / (cfg->rbf_dmax / (float)cfg->rbf_dim);
+    Blob bl{host_blob, tensors, n_tensors, {}};
+    Builder B;
+    auto bail = [&](const std::string& m) { std::string mm = m; delete c; return fail(nullptr, FM_ERR_WEIGHTS, "fm_create: %s", mm.c_str()); };
+    auto ident = [](int k) { return k; };
+
+    // ---- input embeddings
+    const int ta = tok ? cfg->a_token_dim : na + 1, tc = tok ? cfg->c_token_dim : nc + 1, te = tok ? cfg->e_token_dim : ne + 1;
+    const int tt = cfg->time_embedding_dim;
+    const float* emb_e = nullptr;
+    if (tok) {
+        const float* ea = bl.get("token_embeddings.a.weight", na + 1, ta);
+        const float* ec = bl.get("token_embeddings.c.weight", nc + 1, tc);
+        emb_e = bl.get("token_embeddings.e.weight", ne + 1, te);
+        if (!ea || !ec || !emb_e) return bail(bl.err);
+        B.put(c->emb_a, std::vector<float>(ea, ea + (na + 1) * ta));
+        B.put(c->emb_c, std::vector<float>(ec, ec + (nc + 1) * tc));
+    }
+    {
+        const int kin = ta + tc + tt;
+        const float* W1 = bl.get("scalar_embedding.0.weight", 256, kin); const float* b1 = bl.get("scalar_embedding.0.bias", 256);
+        const float* W2 = bl.get("scalar_embedding.2.weight", 256, 256); const float* b2 = bl.get("scalar_embedding.2.bias", 256);
+        const float* g = bl.get("scalar_embedding.4.weight", 256); const float* be = bl.get("scalar_embedding.4.bias", 256);
+        if (!W1 || !b1 || !W2 || !b2 || !g || !be) return bail(bl.err);
+        c->node_embed.K1p = pad8(kin); c->node_embed.H = 256; c->node_embed.O = 256;
+        pack_linear(B, c->node_embed.W1, W1, 256, kin, pad8(kin), 256, ident);
+        pad_vec(B, c->node_embed.b1, b1, 256, 256);
+        pack_linear(B, c->node_embed.W2, W2, 256, 256, 256, 256, ident);
+        pad_vec(B, c->node_embed.b2, b2, 256, 256);
+        pad_vec(B, c->node_ln_g, g, 256, 256); pad_vec(B, c->node_ln_b, be, 256, 256);
+        c->tab_rows = (na + 1) * (nc + 1); c->tab_kp = pad8(kin);
+    }
+    const float *ee_W1, *ee_b1, *ee_W2, *ee_b2, *ee_g, *ee_b;
+    {
+        ee_W1 = bl.get("edge_embedding.0.weight", 128, te); ee_b1 = bl.get("edge_embedding.0.bias", 128);
+        ee_W2 = bl.get("edge_embedding.2.weight", 128, 128); ee_b2 = bl.get("edge_embedding.2.bias", 128);
+        ee_g = bl.get("edge_embedding.4.weight", 128); ee_b = bl.get("edge_embedding.4.bias", 128);
+        if (!ee_W1 || !ee_b1 || !ee_W2 || !ee_b2 || !ee_g || !ee_b) return bail(bl.err);
+    }
+    // edge-embedding table (ne+1 rows): the edge embedding has only ne+1 distinct inputs;
+    // evaluated once here on the host in f32 (same op order as a row of the device MLP is not required: 1e-7 class)
+    std::vector<float> ef_tab((size_t)(ne + 1) * 128), T1((size_t)(ne + 1) * 128, 0.f);
+    for (int t = 0; t <= ne; ++t) {
+        std::vector<float> in(te, 0.f), h1(128), h2(128);
+        if (tok) for (int k = 0; k < te; ++k) in[k] = emb_e[t * te + k]; else in[t] = 1.f;
+        for (int n = 0; n < 128; ++n) { float acc = ee_b1[n]; for (int k = 0; k < te; ++k) acc = fmaf(ee_W1[n * te + k], in[k], acc); h1[n] = acc / (1.0f + expf(-acc)); }
+        for (int n = 0; n < 128; ++n) { float acc = ee_b2[n]; for (int k = 0; k < 128; ++k) acc = fmaf(ee_W2[n * 128 + k], h1[k], acc); h2[n] = acc / (1.0f + expf(-acc)); }
+        double mean = 0; for (float x : h2) mean += x; mean /= 128;
+        double var = 0; for (float x : h2) var += (x - mean) * (x - mean); var /= 128;
+        const float rstd = (float)(1.0 / std::sqrt(var + 1e-5));
+        for (int n = 0; n < 128; ++n) ef_tab[(size_t)t * 128 + n] = (h2[n] - (float)mean) * rstd * ee_g[n] + ee_b[n];
+    }
+    // ---- self-conditioning
+    if (cfg->self_conditioning) {
+        const std::string p = "self_conditioning_residual_layer.";
+        const int kin = 256 + na + nc + 32;
+        const float* W1 = bl.get(p + "node_residual_mlp.0.weight", 256, kin); const float* b1 = bl.get(p + "node_residual_mlp.0.bias", 256);
+        const float* W2 = bl.get(p + "node_residual_mlp.2.weight", 256, 256); const float* b2 = bl.get(p + "node_residual_mlp.2.bias", 256);
+        const int kie = 128 + ne + 32;
+        const float* E1 = bl.get(p + "edge_residual_mlp.0.weight", 128, kie); const float* eb1 = bl.get(p + "edge_residual_mlp.0.bias", 128);
+        const float* E2 = bl.get(p + "edge_residual_mlp.2.weight", 128, 128); const float* eb2 = bl.get(p + "edge_residual_mlp.2.bias", 128);
+        if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
+        c->sc_node.K1p = pad8(kin); c->sc_node.H = 256; c->sc_node.O = 256;
+        pack_linear(B, c->sc_node.W1, W1, 256, kin, pad8(kin), 256, ident);
+        pad_vec(B, c->sc_node.b1, b1, 256, 256);
+        pack_linear(B, c->sc_node.W2, W2, 256, 256, 256, 256, ident);
+        pad_vec(B, c->sc_node.b2, b2, 256, 256);
+        c->sc_edge.K1p = pad8(ne + 32); c->sc_edge.H = 128; c->sc_edge.O = 128;
+        pack_linear(B, c->sc_edge.W1, E1, 128, kie, pad8(ne + 32), 128, [&](int k) { return k < ne + 32 ? 128 + k : -1; });
+        pad_vec(B, c->sc_edge.b1, eb1, 128, 128);
+        pack_linear(B, c->sc_edge.W2, E2, 128, 128, 128, 128, ident);
+        pad_vec(B, c->sc_edge.b2, eb2, 128, 128);
+        for (int t = 0; t <= ne; ++t)
+            for (int n = 0; n < 128; ++n) {
+                float acc = eb1[n];
+                for (int k = 0; k < 128; ++k) acc = fmaf(E1[(size_t)n * kie + k], ef_tab[(size_t)t * 128 + k], acc);
+                T1[(size_t)t * 128 + n] = acc;
+            }
+    }
+    B.put(c->ef_tab, ef_tab);
+    B.put(c->T1, T1);
+    // ---- convolutions
+    c->conv.resize(cfg->n_convs);
+    for (int i = 0; i < cfg->n_convs; ++i) {
+        ConvW& cw = c->conv[i];
+        const std::string p = "conv_layers." + std::to_string(i) + ".";
+        const std::string k0 = p + "edge_message.0";
+        const int kin0 = 256 + 32 + 128 + V + 5;
+        const float* Wh = bl.get(k0 + ".Wh", V + 1, V + 1);
+        const float* Wcp = bl.get(k0 + ".Wcp", V + 1, 8);
+        const float* Wu = bl.get(k0 + ".Wu", V + 5, V);
+        const float* Ws = bl.get(k0 + ".to_feats_out.0.weight", 256, kin0);
+        const float* bs = bl.get(k0 + ".to_feats_out.0.bias", 256);
+        const float* Wg = bl.get(k0 + ".scalar_to_vector_gates.weight", V, 256);
+        const float* bg = bl.get(k0 + ".scalar_to_vector_gates.bias", V);
+        if (!Wh || !Wcp || !Wu || !Ws || !bs || !Wg || !bg) return bail(bl.err);
+        // hoisted per-node parts (input vector 0 is the displacement; 1.. are v_src)
+        pack_linear(B, cw.Wps, Ws, 256, kin0, 256, 256, ident);
+        B.put(cw.Wpv, pack(V, V + 16, [&](int k, int n) -> float {
+            if (n < V + 1) return Wh[(1 + k) * (V + 1) + n];
+            if (n < V + 8) return 0.f;
+            return Wcp[(1 + k) * 8 + (n - V - 8)]; }));
+        {
+            std::vector<float> w0(V + 16, 0.f);
+            for (int n = 0; n < V + 1; ++n) w0[n] = Wh[n];
+            for (int n = 0; n < 8; ++n) w0[V + 8 + n] = Wcp[n];
+            B.put(cw.w0, w0);
+        }
+        FmGvpW& g0 = cw.msg[0];
+        g0.Wv1 = nullptr;
+        B.put(g0.Wu, pack(V + 8, V, [&](int k, int n) -> float { return k < V + 5 ? Wu[k * V + n] : 0.f; }));
+        // K order of the first scalar linear: [rbf(32) | ef(128) | sh(V+5) | 0]; reference column order
+        // [s_src(256) | rbf(32) | ef(128) | sh(V+5)] (gvp.py:532-539,118)
+        pack_linear(B, g0.Ws, Ws, 256, kin0, 160 + V + 8, 256, [&](int k) { return k < 160 + V + 5 ? 256 + k : -1; });
+        pad_vec(B, g0.bs, bs, 256, 256);
+        pack_linear(B, g0.Wg, Wg, V, 256, 256, V, ident);
+        pad_vec(B, g0.bg, bg, V, V);
+        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, V, cw.msg[g])) return bail(bl.err);
+        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, V, cw.upd[g])) return bail(bl.err);
+        const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", 256); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", 256);
+        const float* l2g = bl.get(p + "update_layer_norm.feat_norm.weight", 256); const float* l2b = bl.get(p + "update_layer_norm.feat_norm.bias", 256);
+        if (!l1g || !l1b || !l2g || !l2b) return bail(bl.err);
+        pad_vec(B, cw.ln1_g, l1g, 256, 256); pad_vec(B, cw.ln1_b, l1b, 256, 256);
+        pad_vec(B, cw.ln2_g, l2g, 256, 256); pad_vec(B, cw.ln2_b, l2b, 256, 256);
+    }
+    // ---- molecule updaters (only those the schedule uses; index 0 is dead when convs_per_update == 1)
+    c->upd.resize(cfg->n_updaters);
+    for (int u = 0; u < cfg->n_updaters; ++u) {
+        bool used = false;
+        for (int i = 0; i < cfg->n_convs; ++i) used |= cfg->update_after[i] == u;
+        if (!used) continue;
+        UpdW& uw = c->upd[u];
+        const std::string p = "node_position_updaters." + std::to_string(u) + ".gvps.";
+        if (!pack_gvp(B, bl, p + "0", V, V, uw.pos[0]) || !pack_gvp(B, bl, p + "1", V, V, uw.pos[1]) || !pack_gvp(B, bl, p + "2", V, 1, uw.pos[2]))
+            return bail(bl.err);
+        const std::string q = "edge_updaters." + std::to_string(u) + ".";
+        const int kin = 2 * 256 + 128 + 32;
+        const float* W1 = bl.get(q + "edge_update_fn.0.weight", 128, kin); const float* b1 = bl.get(q + "edge_update_fn.0.bias", 128);
+        const float* W2 = bl.get(q + "edge_update_fn.2.weight", 128, 128); const float* b2 = bl.get(q + "edge_update_fn.2.bias", 128);
+        const float* g = bl.get(q + "edge_norm.weight", 128); const float* be = bl.get(q + "edge_norm.bias", 128);
+        if (!W1 || !b1 || !W2 || !b2 || !g || !be) return bail(bl.err);
+        // input order [s_src(256) | s_dst(256) | ef(128) | d(32)] (vector_field.py:870-877)
+        B.put(uw.Wasd, pack(256, 256, [&](int k, int n) -> float { return n < 128 ? W1[(size_t)n * kin + k] : W1[(size_t)(n - 128) * kin + 256 + k]; }));
+        pack_linear(B, uw.W1, W1, 128, kin, 160, 128, [&](int k) { return 512 + k; });
+        pad_vec(B, uw.b1, b1, 128, 128);
+        pack_linear(B, uw.W2, W2, 128, 128, 128, 128, ident);
+        pad_vec(B, uw.b2, b2, 128, 128);
+        pad_vec(B, uw.ln_g, g, 128, 128); pad_vec(B, uw.ln_b, be, 128, 128);
+    }
+    // ---- output heads
+    {
+        const float* W1 = bl.get("node_output_head.0.weight", 256, 256); const float* b1 = bl.get("node_output_head.0.bias", 256);
+        const float* W2 = bl.get("node_output_head.2.weight", na + nc, 256); const float* b2 = bl.get("node_output_head.2.bias", na + nc);
+        const float* E1 = bl.get("to_edge_logits.0.weight", 128, 128); const float* eb1 = bl.get("to_edge_logits.0.bias", 128);
+        const float* E2 = bl.get("to_edge_logits.2.weight", ne, 128); const float* eb2 = bl.get("to_edge_logits.2.bias", ne);
+        if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
+        c->node_head.K1p = 256; c->node_head.H = 256; c->node_head.O = pad16(na + nc);
+        pack_linear(B, c->node_head.W1, W1, 256, 256, 256, 256, ident); pad_vec(B, c->node_head.b1, b1, 256, 256);
+        pack_linear(B, c->node_head.W2, W2, na + nc, 256, 256, pad16(na + nc), ident); pad_vec(B, c->node_head.b2, b2, na + nc, pad16(na + nc));
+        c->edge_head.K1p = 128; c->edge_head.H = 128; c->edge_head.O = 16;
+        pack_linear(B, c->edge_head.W1, E1, 128, 128, 128, 128, ident); pad_vec(B, c->edge_head.b1, eb1, 128, 128);
+        pack_linear(B, c->edge_head.W2, E2, ne, 128, 128, 16, ident); pad_vec(B, c->edge_head.b2, eb2, ne, 16);
+    }
+    // ---- upload
+    c->arena_bytes = B.A.h.size() * sizeof(float);
+    hipError_t e = hipMalloc((void**)&c->arena, c->arena_bytes);
+    if (e != hipSuccess) { delete c; return fail(nullptr, FM_ERR_NOMEM, "fm_create: hipMalloc(%zu) failed: %s", B.A.h.size() * 4, hipGetErrorString(e)); }
+    e = hipMemcpy(c->arena, B.A.h.data(), c->arena_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_HIP, "fm_create: weight upload failed: %s", hipGetErrorString(e)); }
+    for (const Fix& f : B.fix) *f.slot = c->arena + f.off * sizeof(float);
+    // ---- dynamic LDS opt-in (up to 160 KiB per workgroup on gfx950)
+    if (V == 32) {
+        set_lds(fm_k_edge_message<32>, lds_gvp(32, true)); set_lds(fm_k_node_update<32>, lds_gvp(32, false));
+        set_lds(fm_k_pos_update<32>, lds_gvp(32, false)); set_lds(fm_k_node_proj<32>, lds_proj(32));
+    } else {
+        set_lds(fm_k_edge_message<16>, lds_gvp(16, true)); set_lds(fm_k_node_update<16>, lds_gvp(16, false));
+        set_lds(fm_k_pos_update<16>, lds_gvp(16, false)); set_lds(fm_k_node_proj<16>, lds_proj(16));
+    }
+    set_lds(fm_k_edge_update, lds_edge_upd());
+    const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
+    set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
+    set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max);
+    *out = c;
+    return FM_OK;
+}
+
+int fm_destroy(fm_ctx* c) {
+    if (!c) return FM_OK;
+    for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    if (c->arena) (void)hipFree(c->arena);
+    delete c;
+    return FM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- workspace
+struct WsLayout {
+    int B, N, E, U, P, tab_rows, tab_kp;
+    size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
+        off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_stab, off_tabin, off_bx, off_ba,
+        off_bc, off_be, off_cnt, off_hc, off_sa1, off_sc1, off_se1, total;
+};
+
+static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
+    if (B <= 0) return fail(c, FM_ERR_INVALID, "batch of %d molecules", B);
+    long long N = 0, E = 0;
+    int nmax = 0;
+    for (int i = 0; i < B; ++i) {
+        const int n = n_atoms[i];
+        if (n < 2) return fail(c, FM_ERR_INVALID, "molecule %d has %d atoms; the fully-connected graph needs >= 2", i, n);
+        N += n; E += (long long)n * (n - 1); nmax = n > nmax ? n : nmax;
+    }
+    if (E > 0x7fffffffLL / 4) return fail(c, FM_ERR_INVALID, "batch too large for int32 edge indexing (%lld edges)", E);
+    const int V = c->V;
+    w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
+    w.P = (nmax - 2) / FM_TM + 2;
+    w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    w.off_mol_node = take((size_t)(B + 1) * 4); w.off_mol_edge = take((size_t)(B + 1) * 4); w.off_mol_pair = take((size_t)(B + 1) * 4);
+    w.off_node_mol = take((size_t)N * 4); w.off_first_edge = take((size_t)N * 4);
+    w.off_esrc = take((size_t)E * 4); w.off_edst = take((size_t)E * 4); w.off_epair = take((size_t)E * 4);
+    w.off_pe0 = take((size_t)w.U * 4); w.off_pe1 = take((size_t)w.U * 4); w.off_pair_mol = take((size_t)w.U * 4);
+    w.off_s = take((size_t)N * 256 * 4); w.off_v = take((size_t)N * 3 * V * 4); w.off_xw = take((size_t)N * 3 * 4);
+    w.off_ef = take((size_t)E * 128 * 4);
+    w.off_Ps = take((size_t)N * 256 * 4); w.off_Asd = take((size_t)N * 256 * 4); w.off_PV = take((size_t)N * 3 * (V + 16) * 4);
+    w.off_part_s = take((size_t)N * w.P * 256 * 4); w.off_part_v = take((size_t)N * w.P * 3 * V * 4);
+    w.off_stab = take((size_t)align_up(w.tab_rows, FM_TM) * 256 * 4); w.off_tabin = take((size_t)w.tab_rows * w.tab_kp * 4);
+    w.off_bx = take((size_t)N * 3 * 4); w.off_ba = take((size_t)N * c->na * 4); w.off_bc = take((size_t)N * c->nc * 4); w.off_be = take((size_t)w.U * c->ne * 4);
+    w.off_cnt = take((size_t)6 * B * 4); w.off_hc = take((size_t)(N > w.U ? N : w.U));
+    w.off_sa1 = take((size_t)N * 4); w.off_sc1 = take((size_t)N * 4); w.off_se1 = take((size_t)w.U * 4);
+    w.total = o;
+    return FM_OK;
+}
+
+int fm_workspace_bytes(fm_ctx* c, const int32_t* n_atoms, int B, size_t* bytes) {
+    if (!c || !n_atoms || !bytes) return fail(c, FM_ERR_INVALID, "fm_workspace_bytes: null argument");
+    WsLayout w;
+    int rc = ws_layout(c, n_atoms, B, w);
+    if (rc) return rc;
+    *bytes = w.total;
+    return FM_OK;
+}
+
+int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* workspace, size_t bytes) {
+    if (!c || !n_atoms || !workspace) return fail(c, FM_ERR_INVALID, "fm_batch_bind: null argument");
+    WsLayout w;
+    int rc = ws_layout(c, n_atoms, B, w);
+    if (rc) return rc;
+    if (bytes < w.total) return fail(c, FM_ERR_INVALID, "fm_batch_bind: workspace of %zu bytes < required %zu", bytes, w.total);
+    if ((uintptr_t)workspace % 256) return fail(c, FM_ERR_INVALID, "fm_batch_bind: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    std::vector<int32_t> off(3 * (size_t)(B + 1));
+    int32_t* no = off.data(); int32_t* eo = no + (B + 1); int32_t* po = eo + (B + 1);
+    no[0] = eo[0] = po[0] = 0;
+    for (int i = 0; i < B; ++i) { const int n = n_atoms[i]; no[i + 1] = no[i] + n; eo[i + 1] = eo[i] + n * (n - 1); po[i + 1] = po[i] + n * (n - 1) / 2; }
+    // pageable host memory: hipMemcpyAsync stages it before returning, so the vector may die afterwards
+    FM_HIP(c, hipMemcpyAsync(base + w.off_mol_node, no, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
+    FM_HIP(c, hipMemcpyAsync(base + w.off_mol_edge, eo, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
+    FM_HIP(c, hipMemcpyAsync(base + w.off_mol_pair, po, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
+    FM_HIP(c, hipStreamSynchronize(st));
+    FmBatch& b = c->b;
+    b.B = B; b.N = w.N; b.E = w.E; b.U = w.U; b.P = w.P;
+    b.mol_node_off = (const int*)(base + w.off_mol_node); b.mol_edge_off = (const int*)(base + w.off_mol_edge); b.mol_pair_off = (const int*)(base + w.off_mol_pair);
+    b.node_mol = (int*)(base + w.off_node_mol); b.node_first_edge = (int*)(base + w.off_first_edge);
+    b.e_src = (int*)(base + w.off_esrc); b.e_dst = (int*)(base + w.off_edst); b.e_pair = (int*)(base + w.off_epair);
+    b.p_e0 = (int*)(base + w.off_pe0); b.p_e1 = (int*)(base + w.off_pe1); b.pair_mol = (int*)(base + w.off_pair_mol);
+    c->s = (float*)(base + w.off_s); c->v = (float*)(base + w.off_v); c->xw = (float*)(base + w.off_xw); c->ef = (float*)(base + w.off_ef);
+    c->Ps = (float*)(base + w.off_Ps); c->Asd = (float*)(base + w.off_Asd); c->PV = (float*)(base + w.off_PV);
+    c->part_s = (float*)(base + w.off_part_s); c->part_v = (float*)(base + w.off_part_v);
+    c->s_tab = (float*)(base + w.off_stab); c->tab_in = (float*)(base + w.off_tabin);
+    c->boot.x = (float*)(base + w.off_bx); c->boot.a = (float*)(base + w.off_ba); c->boot.c = (float*)(base + w.off_bc); c->boot.e = (float*)(base + w.off_be);
+    c->cnt = (int*)(base + w.off_cnt); c->hc_flag = (unsigned char*)(base + w.off_hc);
+    c->sa1 = (int32_t*)(base + w.off_sa1); c->sc1 = (int32_t*)(base + w.off_sc1); c->se1 = (int32_t*)(base + w.off_se1);
+    c->n_tiles_e = (w.E + FM_TM - 1) / FM_TM; c->n_tiles_n = (w.N + FM_TM - 1) / FM_TM; c->n_tiles_u = (w.U + FM_TM - 1) / FM_TM;
+    Launch L{c, st};
+    const int work = w.E > w.N ? w.E : w.N;
+    L("batch_setup", fm_k_batch_setup, dim3((work + 255) / 256), dim3(256), 0, b);
+    if (L.rc) return L.rc;
+    c->bound = true;
+    return FM_OK;
+}
+
+int fm_forward(fm_ctx* c, void* stream, const fm_state* state, const float* temb, const fm_dst* prev, int bootstrap, int remove_com,
+               const fm_dst* out) {
+    if (!c || !state || !temb || !out) return fail(c, FM_ERR_INVALID, "fm_forward: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_forward: no batch bound");
+    return forward_impl(c, (hipStream_t)stream, state, temb, prev, bootstrap, remove_com, out);
+}
+
+int fm_ctmc_step(fm_ctx* c, void* stream, const fm_state* state, const fm_dst* dst, const fm_step_noise* noise, const fm_step_scalars* sc,
+                 const fm_sampled* sampled) {
+    if (!c || !state || !dst || !noise || !sc) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_ctmc_step: no batch bound");
+    return ctmc_impl(c, (hipStream_t)stream, state, dst, noise, sc, sampled);
+}
+
+int fm_integrate(fm_ctx* c, void* stream, const fm_state* state, int n_steps, const fm_step_scalars* steps, const float* temb,
+                 const fm_step_noise* noise, const fm_dst* prev0, const fm_dst* dst_a, const fm_dst* dst_b, const fm_traj_sink* sink,
+                 int* final_dst) {
+    if (!c || !state || !steps || !temb || !noise || !dst_a || !dst_b) return fail(c, FM_ERR_INVALID, "fm_integrate: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_integrate: no batch bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int tt = c->cfg.time_embedding_dim;
+    const FmBatch& b = c->b;
+    const fm_dst* prev = prev0;
+    int cur = (prev0 && prev0->x == dst_a->x) ? 1 : 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const fm_dst* out = cur == 0 ? dst_a : dst_b;
+        const int boot = (!prev && steps[i].t == 0.0f) ? 1 : 0;      // prev is None and (t == 0).all(), vector_field.py:269-272
+        int rc = forward_impl(c, st, state, temb + (size_t)i * tt, prev, boot, 1, out);
+        if (rc) return rc;
+        fm_sampled smp{};
+        if (sink) {
+            smp.a1 = sink->a1 ? sink->a1 + (size_t)i * b.N : nullptr;
+            smp.c1 = sink->c1 ? sink->c1 + (size_t)i * b.N : nullptr;
+            smp.e1 = sink->e1 ? sink->e1 + (size_t)i * b.U : nullptr;
+        }
+        rc = ctmc_impl(c, st, state, out, &noise[i], &steps[i], &smp);
+        if (rc) return rc;
+        if (sink) {
+            Launch L{c, st};
+            if (sink->x) L.copy(sink->x + (size_t)i * b.N * 3, state->x_t, (size_t)b.N * 12);
+            if (sink->a) L.copy(sink->a + (size_t)i * b.N, state->a_t, (size_t)b.N * 4);
+            if (sink->c) L.copy(sink->c + (size_t)i * b.N, state->c_t, (size_t)b.N * 4);
+            if (sink->e) L.copy(sink->e + (size_t)i * b.U, state->e_t, (size_t)b.U * 4);
+            if (sink->x1) L.copy(sink->x1 + (size_t)i * b.N * 3, out->x, (size_t)b.N * 12);
+            if (L.rc) return L.rc;
+        }
+        prev = out;
+        cur ^= 1;
+    }
+    if (final_dst) *final_dst = cur ^ 1;
+    return FM_OK;
+}
+
+int fm_set_tap(fm_ctx* c, const char* name, void* dst) {
+    if (!c || !name) return fail(c, FM_ERR_INVALID, "fm_set_tap: null argument");
+    if (dst) c->taps[name] = dst; else c->taps.erase(name);
+    return FM_OK;
+}
+int fm_clear_taps(fm_ctx* c) { if (c) c->taps.clear(); return FM_OK; }
+
+int fm_batch_query(fm_ctx* c, void* stream, const char* name, int32_t* dst) {
+    if (!c || !name || !dst) return fail(c, FM_ERR_INVALID, "fm_batch_query: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_batch_query: no batch bound");
+    const FmBatch& b = c->b;
+    const std::string n = name;
+    const int* src = nullptr; size_t cnt = 0;
+    if (n == "e_src") { src = b.e_src; cnt = b.E; } else if (n == "e_dst") { src = b.e_dst; cnt = b.E; }
+    else if (n == "e_pair") { src = b.e_pair; cnt = b.E; } else if (n == "p_e0") { src = b.p_e0; cnt = b.U; }
+    else if (n == "p_e1") { src = b.p_e1; cnt = b.U; } else if (n == "node_mol") { src = b.node_mol; cnt = b.N; }
+    else if (n == "pair_mol") { src = b.pair_mol; cnt = b.U; }
+    else return fail(c, FM_ERR_INVALID, "fm_batch_query: unknown array %s", name);
+    FM_HIP(c, hipMemcpyAsync(dst, src, cnt * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FM_OK;
+}
+
+int fm_profile_enable(fm_ctx* c, int on) {
+    if (!c) return FM_ERR_INVALID;
+    c->prof = on != 0;
+    if (on) {
+        for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+        c->prof_events.clear(); c->prof_acc.clear();
+    }
+    return FM_OK;
+}
+
+int fm_profile_get(fm_ctx* c, const char* kernel, double* total_ms, int64_t* launches) {
+    if (!c || !kernel || !total_ms || !launches) return fail(c, FM_ERR_INVALID, "fm_profile_get: null argument");
+    for (auto& pe : c->prof_events) {       // fold finished events into the accumulators
+        FM_HIP(c, hipEventSynchronize(pe.b));
+        float ms = 0.f;
+        FM_HIP(c, hipEventElapsedTime(&ms, pe.a, pe.b));
+        auto& acc = c->prof_acc[c->prof_names[pe.kid]];
+        acc.first += ms; acc.second += 1;
+        (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b);
+    }
+    c->prof_events.clear();
+    auto it = c->prof_acc.find(kernel);
+    if (it == c->prof_acc.end()) { *total_ms = 0; *launches = 0; return FM_OK; }
+    *total_ms = it->second.first; *launches = it->second.second;
+    return FM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,736 @@
+// __global__ kernels of the FlowMol3 sampling hot path for gfx950.  See DESIGN.md for the map
+// kernel -> reference function and the HBM data layout.  All kernels use 512-thread workgroups
+// over 64-row tiles unless noted; weights come pre-packed (fm_device.h).
+#pragma once
+#include "fm_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// batch descriptor (all device pointers; built by fm_k_batch_setup from the per-molecule offsets)
+// ------------------------------------------------------------------------------------------------
+struct FmBatch {
+    int B, N, E, U;          // molecules, nodes, directed edges, unordered pairs (E = 2U)
+    int P;                   // max number of 64-edge tiles one destination's in-edges can span
+    const int* mol_node_off; // [B+1]
+    const int* mol_edge_off; // [B+1]  (internal, dst-major directed edges)
+    const int* mol_pair_off; // [B+1]  (reference upper-triangle order)
+    int* node_mol;           // [N]
+    int* node_first_edge;    // [N]  internal index of the first in-edge of the node
+    int* e_src;              // [E]  global node id of the source
+    int* e_dst;              // [E]
+    int* e_pair;             // [E]  global pair id (reference order) of the unordered pair
+    int* p_e0;               // [U]  internal edge id of (src=a -> dst=b), a<b   ("upper" edge)
+    int* p_e1;               // [U]  internal edge id of (src=b -> dst=a)        ("lower" edge)
+    int* pair_mol;           // [U]
+};
+
+// Internal edge order: per molecule, destination-major: edge (dst=i, src=j), j != i, sits at
+// off + i*(n-1) + (j - (j>i)).  The reference's order (upper triangle row-major, then the same pairs
+// swapped; flowmol/data_processing/utils.py:4-17) only matters at the boundary, where edge state is
+// exchanged per unordered pair p(a,b) = a*(2n-a-1)/2 + (b-a-1), a<b.
+__global__ void __launch_bounds__(256) fm_k_batch_setup(FmBatch b) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < b.N) {
+        int lo = 0, hi = b.B;               // largest m with node_off[m] <= gid
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.mol_node_off[mid] <= gid) lo = mid; else hi = mid; }
+        b.node_mol[gid] = lo;
+        const int n = b.mol_node_off[lo + 1] - b.mol_node_off[lo];
+        b.node_first_edge[gid] = b.mol_edge_off[lo] + (gid - b.mol_node_off[lo]) * (n - 1);
+    }
+    if (gid < b.E) {
+        int lo = 0, hi = b.B;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.mol_edge_off[mid] <= gid) lo = mid; else hi = mid; }
+        const int noff = b.mol_node_off[lo];
+        const int n = b.mol_node_off[lo + 1] - noff;
+        const int local = gid - b.mol_edge_off[lo];
+        const int i = local / (n - 1), k = local % (n - 1);
+        const int j = k + (k >= i ? 1 : 0);
+        b.e_dst[gid] = noff + i;
+        b.e_src[gid] = noff + j;
+        const int a = i < j ? i : j, c = i < j ? j : i;
+        const int pair = b.mol_pair_off[lo] + a * (2 * n - a - 1) / 2 + (c - a - 1);
+        b.e_pair[gid] = pair;
+        if (j < i) { b.p_e0[pair] = gid; b.pair_mol[pair] = lo; }   // src=a<b=dst : the reference's upper edge
+        else b.p_e1[pair] = gid;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic two-layer MLP on 64-row tiles:  Y = post( act2( W2 * silu(W1 * x + b1) + b2 ) )
+// The prologue that builds x and the epilogue are selected by MODE.
+// ------------------------------------------------------------------------------------------------
+enum FmMlpMode {
+    FM_MLP_TABLE = 0,     // x = rows of a dense matrix; out = LayerNorm(silu(.))          (input embeddings)
+    FM_MLP_SC_NODE = 1,   // x = [s_tab | p_a | p_c | rbf(|x_t - x1_prev|)]; out = s_tab + silu(.)
+    FM_MLP_NODE_HEAD = 2, // x = s; out = softmax over [0,na) and [na,na+nc) of the logits
+    FM_MLP_EDGE_HEAD = 3, // x = ef[e0]+ef[e1] per pair; out = softmax over ne logits
+    FM_MLP_SC_EDGE = 4,   // x = [p_e | rbf(d(x1_prev)) - rbf(d(x_t))]; layer-1 adds T1[token]; out = ef_tab[token] + silu(.)
+};
+
+struct FmMlpArgs {
+    int rows;                 // number of valid rows
+    int K1p;                  // padded input width (multiple of 8)
+    int H;                    // hidden width (multiple of 16, <= 256)
+    int O;                    // padded output width (multiple of 16, <= 256)
+    int ldx, ldh;             // LDS leading dims ((ld/4) odd, ldx >= max(K1p, O), ldh >= H)
+    const float2* W1; const float* b1;
+    const float2* W2; const float* b2;
+    const float* ln_g; const float* ln_b;     // TABLE
+    // generic sources / destinations
+    const float* in;  int in_ld;              // TABLE: dense input
+    float* out; int out_ld;                   // TABLE / SC_NODE / heads
+    // node-side
+    const float* s_tab; const int* tok_a; const int* tok_c; int n_c1;   // s_tab row = tok_a*(n_c1)+tok_c
+    const float* prev_a; const float* prev_c; const float* prev_x; const float* x_t;
+    int na, nc, ne;
+    float rbf_mu_step, rbf_inv_sigma;
+    float* out2;                              // NODE_HEAD: charges
+    // edge-side
+    const float* ef; const int* p_e0; const int* p_e1;                   // EDGE_HEAD
+    const int* e_src; const int* e_dst; const int* e_pair; const int* tok_e;   // SC_EDGE
+    const float* prev_e; const float* T1; const float* ef_tab;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* X = lds;                         // [64][ldx]
+    float* Hb = lds + FM_TM * a.ldx;        // [64][ldh]
+    int* meta = reinterpret_cast<int*>(Hb + FM_TM * a.ldh);   // [64] token / row ids
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * FM_TM;
+
+    // ---------------- prologue: fill X[:, 0..K1p)
+    if (MODE == FM_MLP_TABLE) {
+        for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
+            const int r = idx / a.K1p, c = idx % a.K1p;
+            X[r * a.ldx + c] = (row0 + r < a.rows) ? a.in[(size_t)(row0 + r) * a.in_ld + c] : 0.f;
+        }
+    } else if (MODE == FM_MLP_SC_NODE) {
+        if (tid < FM_TM) {
+            const int n = row0 + tid;
+            meta[tid] = (n < a.rows) ? a.tok_a[n] * a.n_c1 + a.tok_c[n] : -1;
+        }
+        __syncthreads();
+        const int kin = 256 + a.na + a.nc + 32;
+        for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
+            const int r = idx / a.K1p, c = idx % a.K1p;
+            const int n = row0 + r;
+            float v = 0.f;
+            if (n < a.rows && c < kin) {
+                if (c < 256) v = a.s_tab[(size_t)meta[r] * 256 + c];
+                else if (c < 256 + a.na) v = a.prev_a[(size_t)n * a.na + (c - 256)];
+                else if (c < 256 + a.na + a.nc) v = a.prev_c[(size_t)n * a.nc + (c - 256 - a.na)];
+                else {
+                    const float d = fm_norm3(a.x_t[n * 3 + 0] - a.prev_x[n * 3 + 0], a.x_t[n * 3 + 1] - a.prev_x[n * 3 + 1],
+                                             a.x_t[n * 3 + 2] - a.prev_x[n * 3 + 2]);
+                    v = fm_rbf(d, c - 256 - a.na - a.nc, a.rbf_mu_step, a.rbf_inv_sigma);
+                }
+            }
+            X[r * a.ldx + c] = v;
+        }
+    } else if (MODE == FM_MLP_NODE_HEAD) {
+        for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+            const int r = idx >> 8, c = idx & 255;
+            X[r * a.ldx + c] = (row0 + r < a.rows) ? a.in[(size_t)(row0 + r) * 256 + c] : 0.f;
+        }
+    } else if (MODE == FM_MLP_EDGE_HEAD) {
+        for (int idx = tid; idx < FM_TM * 128; idx += FM_THREADS) {
+            const int r = idx >> 7, c = idx & 127;
+            const int p = row0 + r;
+            float v = 0.f;
+            if (p < a.rows) v = a.ef[(size_t)a.p_e0[p] * 128 + c] + a.ef[(size_t)a.p_e1[p] * 128 + c];
+            X[r * a.ldx + c] = v;
+        }
+    } else {   // FM_MLP_SC_EDGE: per directed edge
+        float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64][2]: d(x_t), d(x1_prev)
+        int* pr = meta + 3 * FM_TM;                              // [64] pair id
+        if (tid < FM_TM) {
+            const int e = row0 + tid;
+            int tok = -1, pair = 0;
+            float dt_ = 0.f, d1_ = 0.f;
+            if (e < a.rows) {
+                const int i = a.e_src[e], j = a.e_dst[e];
+                pair = a.e_pair[e];
+                tok = a.tok_e[pair];
+                dt_ = fm_norm3(a.x_t[i * 3] - a.x_t[j * 3], a.x_t[i * 3 + 1] - a.x_t[j * 3 + 1], a.x_t[i * 3 + 2] - a.x_t[j * 3 + 2]) + 1e-8f;
+                d1_ = fm_norm3(a.prev_x[i * 3] - a.prev_x[j * 3], a.prev_x[i * 3 + 1] - a.prev_x[j * 3 + 1],
+                               a.prev_x[i * 3 + 2] - a.prev_x[j * 3 + 2]) + 1e-8f;
+            }
+            meta[tid] = tok; pr[tid] = pair; dd[2 * tid] = dt_; dd[2 * tid + 1] = d1_;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
+            const int r = idx / a.K1p, c = idx % a.K1p;
+            float v = 0.f;
+            if (meta[r] >= 0) {
+                if (c < a.ne) v = a.prev_e[(size_t)pr[r] * a.ne + c];
+                else if (c < a.ne + 32)
+                    v = fm_rbf(dd[2 * r + 1], c - a.ne, a.rbf_mu_step, a.rbf_inv_sigma) -
+                        fm_rbf(dd[2 * r], c - a.ne, a.rbf_mu_step, a.rbf_inv_sigma);
+            }
+            X[r * a.ldx + c] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- layer 1 -> Hb
+    fm_block_gemm<4, 1>(X, a.ldx, FM_TM / 16, a.K1p / 8, a.W1, a.H / 16, [&](int row, int col, float v) {
+        if (MODE == FM_MLP_SC_EDGE) { const int t = meta[row]; v += (t >= 0) ? a.T1[t * 128 + col] : 0.f; }
+        else v += a.b1[col];
+        Hb[row * a.ldh + col] = fm_silu(v);
+    });
+    __syncthreads();
+    // ---------------- layer 2 -> X[:, 0..O)
+    fm_block_gemm<4, 1>(Hb, a.ldh, FM_TM / 16, a.H / 8, a.W2, a.O / 16, [&](int row, int col, float v) {
+        v += a.b2[col];
+        if (MODE == FM_MLP_TABLE || MODE == FM_MLP_SC_NODE || MODE == FM_MLP_SC_EDGE) v = fm_silu(v);
+        X[row * a.ldx + col] = v;
+    });
+    __syncthreads();
+
+    // ---------------- epilogue
+    const int r = tid >> 3, sub = tid & 7;          // 8 lanes per row
+    const int grow = row0 + r;
+    if (MODE == FM_MLP_TABLE) {
+        float mean, rstd;
+        fm_row_stats8(X + r * a.ldx, a.O, sub, mean, rstd);
+        if (grow < a.rows)
+            for (int c = sub; c < a.O; c += 8)
+                a.out[(size_t)grow * a.out_ld + c] = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
+    } else if (MODE == FM_MLP_SC_NODE) {
+        if (grow < a.rows)
+            for (int c = sub; c < 256; c += 8)
+                a.out[(size_t)grow * 256 + c] = a.s_tab[(size_t)meta[r] * 256 + c] + X[r * a.ldx + c];
+    } else if (MODE == FM_MLP_SC_EDGE) {
+        if (grow < a.rows)
+            for (int c = sub; c < 128; c += 8)
+                a.out[(size_t)grow * 128 + c] = a.ef_tab[meta[r] * 128 + c] + X[r * a.ldx + c];
+    } else {
+        // softmax heads (vector_field.py:336-344,364-367): one lane per (row, head)
+        if (sub == 0 && grow < a.rows) {
+            const float* lg = X + r * a.ldx;
+            if (MODE == FM_MLP_NODE_HEAD) {
+                float m = lg[0];
+                for (int c = 1; c < a.na; ++c) m = fmaxf(m, lg[c]);
+                float s = 0.f;
+                for (int c = 0; c < a.na; ++c) s += expf(lg[c] - m);
+                for (int c = 0; c < a.na; ++c) a.out[(size_t)grow * a.na + c] = expf(lg[c] - m) / s;
+                m = lg[a.na];
+                for (int c = 1; c < a.nc; ++c) m = fmaxf(m, lg[a.na + c]);
+                s = 0.f;
+                for (int c = 0; c < a.nc; ++c) s += expf(lg[a.na + c] - m);
+                for (int c = 0; c < a.nc; ++c) a.out2[(size_t)grow * a.nc + c] = expf(lg[a.na + c] - m) / s;
+            } else {
+                float m = lg[0];
+                for (int c = 1; c < a.ne; ++c) m = fmaxf(m, lg[c]);
+                float s = 0.f;
+                for (int c = 0; c < a.ne; ++c) s += expf(lg[c] - m);
+                for (int c = 0; c < a.ne; ++c) a.out[(size_t)grow * a.ne + c] = expf(lg[c] - m) / s;
+            }
+        }
+    }
+}
+
+// gather-only initialisation when there is no self-conditioning input (bootstrap pass / non-SC models)
+__global__ void __launch_bounds__(256) fm_k_gather_rows(float* __restrict__ out, const float* __restrict__ tab, int width,
+                                                         int rows, const int* __restrict__ tok_a, const int* __restrict__ tok_c,
+                                                         int n_c1, const int* __restrict__ e_pair) {
+    // node rows: tok = tok_a*n_c1+tok_c ; edge rows (e_pair != null): tok = tok_a[e_pair[row]]
+    const int w4 = width / 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)rows * w4; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / w4), c4 = (int)(idx % w4);
+        const int tok = e_pair ? tok_a[e_pair[row]] : tok_a[row] * n_c1 + tok_c[row];
+        reinterpret_cast<float4*>(out)[idx] = reinterpret_cast<const float4*>(tab)[(size_t)tok * w4 + c4];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-node projections hoisted out of the per-edge linear layers (SURVEY.md §7 "hard parts"):
+//   Ps  = s * Ws_src          (256)   first edge-message GVP, scalar part of s[src]
+//   Asd = s * [W1_src|W1_dst] (256)   EdgeUpdate first layer, node parts
+//   PV  = v * [Wh[1:] | 0 | Wcp[1:]]  (per xyz: V+16)   first edge-message GVP, vector part of v[src]
+// ------------------------------------------------------------------------------------------------
+struct FmProjArgs {
+    int N;
+    const float* s; const float* v;
+    const float2* Wps; float* Ps;         // null -> skip
+    const float2* Wasd; float* Asd;       // null -> skip
+    const float2* Wpv; float* PV;         // null -> skip
+};
+
+template <int V>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int LDS_ = 260;                 // 260/4 = 65 odd
+    constexpr int LDV = V + 4;
+    float* X = lds;                            // [64][260]
+    float* Vt = lds + FM_TM * LDS_;            // [192][V+4]
+    const int tid = threadIdx.x, row0 = blockIdx.x * FM_TM;
+    for (int idx = tid; idx < FM_TM * 64; idx += FM_THREADS) {
+        const int r = idx >> 6, c4 = idx & 63;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < a.N) val = reinterpret_cast<const float4*>(a.s)[(size_t)(row0 + r) * 64 + c4];
+        float* d = X + r * LDS_ + 4 * c4;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    if (a.PV) {
+        for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+            const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, ch = rem % V;
+            Vt[(c * FM_TM + r) * LDV + ch] = (row0 + r < a.N) ? a.v[((size_t)(row0 + r) * 3 + c) * V + ch] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (a.Ps)
+        fm_block_gemm<4, 2>(X, LDS_, 4, 32, a.Wps, 16, [&](int row, int col, float v) {
+            if (row0 + row < a.N) a.Ps[(size_t)(row0 + row) * 256 + col] = v;
+        });
+    if (a.Asd)
+        fm_block_gemm<4, 2>(X, LDS_, 4, 32, a.Wasd, 16, [&](int row, int col, float v) {
+            if (row0 + row < a.N) a.Asd[(size_t)(row0 + row) * 256 + col] = v;
+        });
+    if (a.PV)
+        fm_block_gemm<1, 1>(Vt, LDV, 12, V / 8, a.Wpv, (V + 16) / 16, [&](int row, int col, float v) {
+            const int c = row / FM_TM, r = row % FM_TM;
+            if (row0 + r < a.N) a.PV[((size_t)(row0 + r) * 3 + c) * (V + 16) + col] = v;
+        });
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused GVPConv edge message + aggregation  (reference gvp.py:476-492, 523-543)
+//   per directed edge j->i: GVP0([s_j|rbf|ef], [xhat_ji|v_j]) -> GVP1 -> GVP2, summed over j per destination i.
+//   Output: per (destination, piece) partial sums; a destination's in-edges are contiguous in the
+//   internal order and span at most P tiles, piece = tile - first_tile(dst).  No atomics -> deterministic.
+// ------------------------------------------------------------------------------------------------
+struct FmMsgArgs {
+    FmBatch b;
+    const float* x;           // (N,3) positions used for distances
+    const float* ef;          // (E,128)
+    const float* Ps;          // (N,256)
+    const float* PV;          // (N,3,V+16)
+    const float* w0;          // (V+16): [Wh[0,:] | 0.. | Wcp[0,:]]  row of the displacement vector
+    FmGvpW g0, g1, g2;
+    float* part_s;            // (N, P, 256)
+    float* part_v;            // (N, P, 3, V)
+    float rbf_mu_step, rbf_inv_sigma;
+    float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
+};
+
+template <int V>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
+    typedef FmGvpTile<V> T;
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* X = lds;
+    float* Vin = X + T::X_FLOATS;
+    float* Vh = Vin + T::VIN_FLOATS;
+    float* G = Vh + T::VH_FLOATS;
+    int* m_src = reinterpret_cast<int*>(G + T::G_FLOATS);   // [64]
+    int* m_dst = m_src + FM_TM;                              // [64]
+    float* m_geo = reinterpret_cast<float*>(m_dst + FM_TM);  // [64][4]: xhat(3), dist
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * FM_TM;
+
+    if (tid < FM_TM) {
+        const int e = e0 + tid;
+        int s = -1, d = -1;
+        float gx = 0.f, gy = 0.f, gz = 0.f, dist = 0.f;
+        if (e < a.b.E) {
+            s = a.b.e_src[e]; d = a.b.e_dst[e];
+            // x_diff = x[src] - x[dst]; d = sqrt(max(|.|^2,1e-8)) + 1e-8; xhat = x_diff / d  (vector_field.py:381-383)
+            const float dx = a.x[s * 3] - a.x[d * 3], dy = a.x[s * 3 + 1] - a.x[d * 3 + 1], dz = a.x[s * 3 + 2] - a.x[d * 3 + 2];
+            dist = fm_norm3(dx, dy, dz) + 1e-8f;
+            gx = dx / dist; gy = dy / dist; gz = dz / dist;
+        }
+        m_src[tid] = s; m_dst[tid] = d;
+        m_geo[4 * tid] = gx; m_geo[4 * tid + 1] = gy; m_geo[4 * tid + 2] = gz; m_geo[4 * tid + 3] = dist;
+    }
+    __syncthreads();
+    // X[:, 0..31] = rbf(d), X[:, 32..159] = ef
+    for (int idx = tid; idx < FM_TM * 32; idx += FM_THREADS) {
+        const int r = idx >> 5, k = idx & 31;
+        X[r * FM_LDX + k] = (m_src[r] >= 0) ? fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
+    }
+    for (int idx = tid; idx < FM_TM * 32; idx += FM_THREADS) {
+        const int r = idx >> 5, c4 = idx & 31;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m_src[r] >= 0) val = reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4];
+        float* d = X + r * FM_LDX + 32 + 4 * c4;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    // hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c] * w0[:]
+    for (int idx = tid; idx < 3 * FM_TM * (V + 16); idx += FM_THREADS) {
+        const int row = idx / (V + 16), col = idx % (V + 16);
+        const int c = row / FM_TM, r = row % FM_TM;
+        float val = 0.f;
+        if (m_src[r] >= 0) val = a.PV[((size_t)m_src[r] * 3 + c) * (V + 16) + col] + m_geo[4 * r + c] * a.w0[col];
+        Vh[row * T::LDVH + col] = val;
+    }
+    __syncthreads();
+    fm_gvp_core<V, V, true, true>(X, Vin, Vh, G, a.g0, a.Ps, m_src);
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+
+    if (a.dbg_s) {
+        for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+            const int r = idx >> 8, c = idx & 255;
+            if (m_src[r] >= 0) a.dbg_s[(size_t)(e0 + r) * 256 + c] = X[r * FM_LDX + c];
+        }
+        for (int idx = tid; idx < 3 * FM_TM * V; idx += FM_THREADS) {
+            const int row = idx / V, u = idx % V, c = row / FM_TM, r = row % FM_TM;
+            if (m_src[r] >= 0) a.dbg_v[((size_t)(e0 + r) * 3 + c) * V + u] = Vin[row * T::LDVI + u];
+        }
+    }
+    // segmented sum over the rows of each destination (rows are dst-sorted)
+    const int ncols = 256 + 3 * V;
+    if (tid < ncols) {
+        const bool is_s = tid < 256;
+        const int vc = (tid - 256) / V, vu = (tid - 256) % V;        // vector column -> (xyz, channel)
+        float run = 0.f;
+        for (int r = 0; r < FM_TM; ++r) {
+            const int d = m_dst[r];
+            if (d < 0) break;
+            run += is_s ? X[r * FM_LDX + tid] : Vin[(vc * FM_TM + r) * T::LDVI + vu];
+            const bool last = (r == FM_TM - 1) || (m_dst[r + 1] != d);
+            if (last) {
+                const int piece = (int)blockIdx.x - (a.b.node_first_edge[d] >> 6);
+                if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + tid] = run;
+                else a.part_v[(((size_t)d * a.b.P + piece) * 3 + vc) * V + vu] = run;
+                run = 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node update of a GVPConv (gvp.py:494-519): sum pieces, /z, residual + GVPLayerNorm, 3 node GVPs,
+// residual + GVPLayerNorm.
+// ------------------------------------------------------------------------------------------------
+struct FmNodeUpdArgs {
+    FmBatch b;
+    float* s; float* v;              // (N,256), (N,3,V) updated in place
+    const float* part_s; const float* part_v;
+    float inv_z;
+    FmGvpW g0, g1, g2;
+    const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+    float* agg_s; float* agg_v;      // optional debug taps of the aggregated messages, else null
+};
+
+// GVPLayerNorm of a tile held in X[:, 0..255] / Vin (gvp.py:169-184); result written to LDS in place and,
+// when out_s/out_v are given, to HBM.
+template <int V>
+__device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, const float* g, const float* b_,
+                                                      int row0, int nrows, float* out_s, float* out_v) {
+    typedef FmGvpTile<V> T;
+    const int tid = threadIdx.x, r = tid >> 3, sub = tid & 7;
+    float mean, rstd;
+    fm_row_stats8(X + r * FM_LDX, 256, sub, mean, rstd);
+    // vector norm: vn = sqrt(mean_c max(|v_c|^2, 1e-8) + eps) + eps
+    float q = 0.f;
+    for (int u = sub; u < V; u += 8) {
+        const float vx = Vin[(0 * FM_TM + r) * T::LDVI + u], vy = Vin[(1 * FM_TM + r) * T::LDVI + u], vz = Vin[(2 * FM_TM + r) * T::LDVI + u];
+        q += fmaxf(vx * vx + vy * vy + vz * vz, 1e-8f);
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    const float vn = sqrtf(q / (float)V + 1e-5f) + 1e-5f;
+    const bool valid = row0 + r < nrows;
+    for (int c = sub; c < 256; c += 8) {
+        const float y = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
+        X[r * FM_LDX + c] = y;
+        if (out_s && valid) out_s[(size_t)(row0 + r) * 256 + c] = y;
+    }
+    for (int u = sub; u < V; u += 8)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float y = Vin[(c * FM_TM + r) * T::LDVI + u] / vn;
+            Vin[(c * FM_TM + r) * T::LDVI + u] = y;
+            if (out_v && valid) out_v[((size_t)(row0 + r) * 3 + c) * V + u] = y;
+        }
+    __syncthreads();
+}
+
+template <int V>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) {
+    typedef FmGvpTile<V> T;
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* X = lds;
+    float* Vin = X + T::X_FLOATS;
+    float* Vh = Vin + T::VIN_FLOATS;
+    float* G = Vh + T::VH_FLOATS;
+    const int tid = threadIdx.x, row0 = blockIdx.x * FM_TM;
+    const int N = a.b.N;
+    // s + sum(pieces)/z
+    for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+        const int r = idx >> 8, c = idx & 255, n = row0 + r;
+        float val = 0.f;
+        if (n < N) {
+            const int m = a.b.node_mol[n];
+            const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
+            float acc = 0.f;
+            if (deg > 0) {
+                const int fe = a.b.node_first_edge[n];
+                const int np = ((fe + deg - 1) >> 6) - (fe >> 6) + 1;
+                for (int p = 0; p < np; ++p) acc += a.part_s[((size_t)n * a.b.P + p) * 256 + c];
+            }
+            acc *= a.inv_z;
+            if (a.agg_s) a.agg_s[(size_t)n * 256 + c] = acc;
+            val = a.s[(size_t)n * 256 + c] + acc;
+        }
+        X[r * FM_LDX + c] = val;
+    }
+    for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+        const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
+        float val = 0.f;
+        if (n < N) {
+            const int m = a.b.node_mol[n];
+            const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
+            float acc = 0.f;
+            if (deg > 0) {
+                const int fe = a.b.node_first_edge[n];
+                const int np = ((fe + deg - 1) >> 6) - (fe >> 6) + 1;
+                for (int p = 0; p < np; ++p) acc += a.part_v[(((size_t)n * a.b.P + p) * 3 + c) * V + u];
+            }
+            acc *= a.inv_z;
+            if (a.agg_v) a.agg_v[((size_t)n * 3 + c) * V + u] = acc;
+            val = a.v[((size_t)n * 3 + c) * V + u] + acc;
+        }
+        Vin[(c * FM_TM + r) * T::LDVI + u] = val;
+    }
+    __syncthreads();
+    fm_gvp_layernorm_tile<V>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v);     // s1, v1 -> HBM (needed for the residual)
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+        const int r = idx >> 8, c = idx & 255, n = row0 + r;
+        if (n < N) X[r * FM_LDX + c] += a.s[(size_t)n * 256 + c];
+    }
+    for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+        const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
+        if (n < N) Vin[(c * FM_TM + r) * T::LDVI + u] += a.v[((size_t)n * 3 + c) * V + u];
+    }
+    __syncthreads();
+    fm_gvp_layernorm_tile<V>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NodePositionUpdate (vector_field.py:813-842): x += GVP3(GVP2(GVP1(s, v))).v[:, 0]
+// ------------------------------------------------------------------------------------------------
+struct FmPosArgs {
+    int N;
+    const float* s; const float* v;
+    float* x;                   // (N,3) updated in place
+    FmGvpW g0, g1, g2;
+};
+
+template <int V>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_pos_update(FmPosArgs a) {
+    typedef FmGvpTile<V> T;
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* X = lds;
+    float* Vin = X + T::X_FLOATS;
+    float* Vh = Vin + T::VIN_FLOATS;
+    float* G = Vh + T::VH_FLOATS;
+    const int tid = threadIdx.x, row0 = blockIdx.x * FM_TM;
+    for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+        const int r = idx >> 8, c = idx & 255, n = row0 + r;
+        X[r * FM_LDX + c] = (n < a.N) ? a.s[(size_t)n * 256 + c] : 0.f;
+    }
+    for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+        const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
+        Vin[(c * FM_TM + r) * T::LDVI + u] = (n < a.N) ? a.v[((size_t)n * 3 + c) * V + u] : 0.f;
+    }
+    __syncthreads();
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
+    fm_gvp_core<V, 1, false, false>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    if (tid < FM_TM * 3) {
+        const int r = tid / 3, c = tid % 3, n = row0 + r;
+        if (n < a.N) a.x[n * 3 + c] += Vin[(c * FM_TM + r) * T::LDVI];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EdgeUpdate (vector_field.py:864-880): ef = LN(ef + silu(W2 silu(W1 [s_src|s_dst|ef|rbf(d)] + b1) + b2))
+// with the node parts of W1 hoisted into Asd (fm_k_node_proj).
+// ------------------------------------------------------------------------------------------------
+struct FmEdgeUpdArgs {
+    FmBatch b;
+    const float* x;            // updated positions
+    const float* Asd;          // (N,256): [:128] = W1_src s, [128:] = W1_dst s
+    float* ef;                 // (E,128) in place
+    const float2* W1; const float* b1;      // K = 160 ([ef|rbf]), N = 128
+    const float2* W2; const float* b2;      // K = 128, N = 128
+    const float* ln_g; const float* ln_b;
+    float rbf_mu_step, rbf_inv_sigma;
+};
+
+__global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int LDX = 164, LDH = 132;
+    float* X = lds;                       // [64][164]: ef(128) | rbf(32)
+    float* Hb = lds + FM_TM * LDX;        // [64][132]
+    int* m_src = reinterpret_cast<int*>(Hb + FM_TM * LDH);
+    int* m_dst = m_src + FM_TM;
+    float* m_d = reinterpret_cast<float*>(m_dst + FM_TM);
+    const int tid = threadIdx.x, e0 = blockIdx.x * FM_TM;
+    if (tid < FM_TM) {
+        const int e = e0 + tid;
+        int s = -1, d = -1; float dist = 0.f;
+        if (e < a.b.E) {
+            s = a.b.e_src[e]; d = a.b.e_dst[e];
+            dist = fm_norm3(a.x[s * 3] - a.x[d * 3], a.x[s * 3 + 1] - a.x[d * 3 + 1], a.x[s * 3 + 2] - a.x[d * 3 + 2]) + 1e-8f;
+        }
+        m_src[tid] = s; m_dst[tid] = d; m_d[tid] = dist;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < FM_TM * 32; idx += FM_THREADS) {
+        const int r = idx >> 5, c4 = idx & 31;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m_src[r] >= 0) val = reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4];
+        float* d = X + r * LDX + 4 * c4;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        X[r * LDX + 128 + c4] = (m_src[r] >= 0) ? fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
+    }
+    __syncthreads();
+    fm_block_gemm<4, 1>(X, LDX, 4, 160 / 8, a.W1, 8, [&](int row, int col, float v) {
+        v += a.b1[col];
+        const int s = m_src[row];
+        if (s >= 0) v += a.Asd[(size_t)s * 256 + col] + a.Asd[(size_t)m_dst[row] * 256 + 128 + col];
+        Hb[row * LDH + col] = fm_silu(v);
+    });
+    __syncthreads();
+    fm_block_gemm<4, 1>(Hb, LDH, 4, 128 / 8, a.W2, 8, [&](int row, int col, float v) {
+        X[row * LDX + col] += fm_silu(v + a.b2[col]);      // own element only: ef + update
+    });
+    __syncthreads();
+    const int r = tid >> 3, sub = tid & 7;
+    float mean, rstd;
+    fm_row_stats8(X + r * LDX, 128, sub, mean, rstd);
+    if (m_src[r] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (j * 8 + sub) * 4;
+            float4 o;
+            o.x = (X[r * LDX + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
+            o.y = (X[r * LDX + c + 1] - mean) * rstd * a.ln_g[c + 1] + a.ln_b[c + 1];
+            o.z = (X[r * LDX + c + 2] - mean) * rstd * a.ln_g[c + 2] + a.ln_b[c + 2];
+            o.w = (X[r * LDX + c + 3] - mean) * rstd * a.ln_g[c + 3] + a.ln_b[c + 3];
+            reinterpret_cast<float4*>(a.ef)[(size_t)(e0 + r) * 32 + (c >> 2)] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small element-wise kernels
+// ------------------------------------------------------------------------------------------------
+// rows of the (a,c) embedding-table input: [emb_a[a] | emb_c[c] | temb]  or  [onehot(a) | onehot(c) | t]
+__global__ void __launch_bounds__(256) fm_k_embed_in(float* __restrict__ out, int ld, int n_a1, int n_c1, int ta, int tc, int tt,
+                                                      const float* __restrict__ emb_a, const float* __restrict__ emb_c,
+                                                      const float* __restrict__ temb) {
+    const int rows = n_a1 * n_c1;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rows * ld; idx += gridDim.x * blockDim.x) {
+        const int row = idx / ld, c = idx % ld;
+        const int ia = row / n_c1, ic = row % n_c1;
+        float v = 0.f;
+        if (c < ta) v = emb_a ? emb_a[ia * ta + c] : (c == ia ? 1.f : 0.f);
+        else if (c < ta + tc) v = emb_c ? emb_c[ic * tc + (c - ta)] : ((c - ta) == ic ? 1.f : 0.f);
+        else if (c < ta + tc + tt) v = temb[c - ta - tc];
+        out[idx] = v;
+    }
+}
+
+// x -= per-molecule mean (vector_field.py:347-350); one 64-lane workgroup per molecule
+__global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, const int* __restrict__ mol_node_off) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const int n0 = mol_node_off[m], n1 = mol_node_off[m + 1];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int n = n0 + lane; n < n1; n += 64) { sx += x[n * 3]; sy += x[n * 3 + 1]; sz += x[n * 3 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    const float inv = 1.0f / (float)(n1 - n0);
+    sx *= inv; sy *= inv; sz *= inv;
+    for (int n = n0 + lane; n < n1; n += 64) { x[n * 3] -= sx; x[n * 3 + 1] -= sy; x[n * 3 + 2] -= sz; }
+}
+
+// Euler step for positions (ctmc_vector_field.py:331-334): x_t += dt * (coef * (x1 - x_t)), coef = alpha'/(1-alpha)
+__global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, const float* __restrict__ x1, float coef, float dt, int n3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) {
+        const float vf = __fmul_rn(coef, __fsub_rn(x1[i], x_t[i]));
+        x_t[i] = __fadd_rn(x_t[i], __fmul_rn(dt, vf));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CTMC categorical update (ctmc_vector_field.py:349-357,414-461; ctmc_utils.py:4-34)
+//   pass 1: p~ = softmax(log p / T); x1 = argmax((p~/sum p~)/q) (== torch.multinomial n=1 fast path);
+//           per-molecule counts of masked rows (m) and high-confidence masked rows (h).
+//   pass 2: per-row unmask / re-mask decisions and the new token.
+// ------------------------------------------------------------------------------------------------
+struct FmCtmcArgs {
+    int rows, K, B;                 // K real categories; mask index = K
+    const float* p;                 // (rows,K) endpoint probabilities (un-tempered softmax)
+    const int* row_mol;             // (rows)
+    int* xt;                        // (rows) tokens, updated in place
+    int* x1;                        // (rows) sampled endpoint tokens (output, also "x_1_pred")
+    const float* q;                 // (rows,K) Exp(1) noise
+    const float* u1;                // (rows) unmask uniform
+    const float* u2;                // (rows) re-mask uniform (unused on the last step)
+    float inv_temp_div;             // temperature T (log p is DIVIDED by it like the reference)
+    float hc_thresh, unmask_prob, mask_prob;
+    int last_step;
+    int* cnt_m; int* cnt_h;         // (B) zeroed before pass 1
+    unsigned char* hc_flag;         // (rows) scratch
+};
+
+__global__ void __launch_bounds__(256) fm_k_ctmc_pass1(FmCtmcArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.rows) return;
+    float lp[16];
+    float mx = -INFINITY;
+    for (int k = 0; k < a.K; ++k) { lp[k] = __fdiv_rn(logf(a.p[(size_t)i * a.K + k]), a.inv_temp_div); mx = fmaxf(mx, lp[k]); }
+    float sum = 0.f;
+    for (int k = 0; k < a.K; ++k) { lp[k] = expf(__fsub_rn(lp[k], mx)); sum = __fadd_rn(sum, lp[k]); }
+    float purity = 0.f, psum = 0.f;
+    for (int k = 0; k < a.K; ++k) { lp[k] = __fdiv_rn(lp[k], sum); purity = fmaxf(purity, lp[k]); psum = __fadd_rn(psum, lp[k]); }
+    int best = 0; float bestv = -1.f;
+    for (int k = 0; k < a.K; ++k) {
+        const float v = __fdiv_rn(__fdiv_rn(lp[k], psum), a.q[(size_t)i * a.K + k]);
+        if (v > bestv) { bestv = v; best = k; }
+    }
+    a.x1[i] = best;
+    const bool masked = a.xt[i] == a.K;
+    const bool hc = masked && (purity >= a.hc_thresh);
+    a.hc_flag[i] = hc ? 1 : 0;
+    if (a.hc_thresh > 0.f && masked) {
+        atomicAdd(&a.cnt_m[a.row_mol[i]], 1);
+        if (hc) atomicAdd(&a.cnt_h[a.row_mol[i]], 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) fm_k_ctmc_pass2(FmCtmcArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.rows) return;
+    const int tok = a.xt[i];
+    const bool masked = tok == a.K;
+    bool will_unmask;
+    if (a.hc_thresh > 0.f) {
+        float prob = 0.f;
+        if (masked) {
+            const int mol = a.row_mol[i];
+            const float m = (float)a.cnt_m[mol], h = (float)a.cnt_h[mol];
+            // ph = min(unmask_prob*m/h, 1) (inf when h == 0); pl = (unmask_prob*m - ph*h)/(m-h)
+            const float um = __fmul_rn(a.unmask_prob, m);
+            float ph = (a.cnt_h[mol] == 0) ? INFINITY : __fdiv_rn(um, h);
+            ph = fminf(ph, 1.0f);
+            if (a.hc_flag[i]) prob = ph;
+            else prob = __fdiv_rn(__fsub_rn(um, __fmul_rn(ph, h)), __fsub_rn(m, h));
+        }
+        will_unmask = a.u1[i] < prob;           // comparisons against NaN are false, as in torch
+    } else {
+        will_unmask = (a.u1[i] < a.unmask_prob) && masked;
+    }
+    int nt = tok;
+    if (!a.last_step) { if ((a.u2[i] < a.mask_prob) && !masked) nt = a.K; }
+    if (will_unmask) nt = a.x1[i];
+    a.xt[i] = nt;
+}

@@ -1,0 +1,353 @@
+"""Python host side of the HIP engine: owns the ``fm_ctx``, the per-batch workspace and the state
+tensors, and mirrors the call structure of the reference's ``CTMCVectorField`` for the sampling path
+(reference flowmol/models/ctmc_vector_field.py:145-411, flowmol/models/vector_field.py:212-293).
+
+PyTorch is used for device memory, the current stream and (optionally) noise generation only; all
+arithmetic of the hot path happens in libflowmol_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (FlowMolHipError, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
+                   fm_tensor_desc, fm_traj_sink)
+from .config import VFConfig
+from .weights import check_state_dict, state_dict_shapes
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def time_embedding_host(t: float, dim: int) -> torch.Tensor:
+    """Sinusoidal time embedding of one scalar t, float32 on the host
+    (reference flowmol/utils/embedding.py:5-17; max_positions=1000).  dim == 1 -> raw t."""
+    tt = torch.tensor([t], dtype=torch.float32)
+    if dim == 1:
+        return tt.clone()
+    ts = tt * 1000
+    half = dim // 2
+    emb = math.log(1000) / (half - 1)
+    emb = torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
+    emb = ts.float()[:, None] * emb[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+    if dim % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1))
+    return emb[0].contiguous()
+
+
+@dataclass
+class StepPlan:
+    """Per-step scalars computed with the reference's float32 tensor arithmetic
+    (ctmc_vector_field.py:170-176,205-233,331-334,430-434)."""
+    t: torch.Tensor                # (T,) float32 time points
+    scalars: List[fm_step_scalars]
+
+
+def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperature: float,
+                   tspan: Optional[torch.Tensor] = None) -> StepPlan:
+    t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32)
+    alpha = t          # linear schedule: alpha_t = t, alpha_t' = 1 for x, a, c, e (interpolant_scheduler.py:148-153)
+    one = torch.ones(())
+    out = []
+    for s_idx in range(1, t.shape[0]):
+        s_i, t_i = t[s_idx], t[s_idx - 1]
+        a_i = alpha[s_idx - 1]
+        dt = s_i - t_i
+        sc = fm_step_scalars()
+        sc.t = float(t_i)
+        sc.dt = float(dt)
+        sc.x_coef = float(one / (1 - a_i))
+        unmask = torch.clamp(dt * (one + eta * a_i) / (1 - a_i), min=0, max=1)
+        mask = torch.clamp(dt * eta, min=0, max=1)
+        for k in range(3):
+            sc.unmask_prob[k] = float(unmask)
+            sc.mask_prob[k] = float(mask)
+        sc.hc_thresh = float(torch.tensor(hc_thresh, dtype=torch.float32))
+        sc.cat_temperature = float(torch.tensor(cat_temperature, dtype=torch.float32))
+        sc.last_step = 1 if s_idx == t.shape[0] - 1 else 0
+        out.append(sc)
+    return StepPlan(t, out)
+
+
+class StepNoise:
+    """The nine noise tensors of one CTMC step, in the reference's draw order
+    (per modality a, c, e: Exp(1) (rows,K) -> rand(rows) -> rand(rows) [not drawn on the last step])."""
+    __slots__ = ('q_a', 'u1_a', 'u2_a', 'q_c', 'u1_c', 'u2_c', 'q_e', 'u1_e', 'u2_e')
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+    @staticmethod
+    def draw(N: int, U: int, na: int, nc: int, ne: int, last_step: bool, device, generator=None) -> "StepNoise":
+        """Draw with torch's generator on ``device`` exactly as the reference's ops would
+        (torch.multinomial's Exp(1) draw, then the two torch.rand calls)."""
+        out = {}
+        for tag, rows, k in (('a', N, na), ('c', N, nc), ('e', U, ne)):
+            out[f'q_{tag}'] = torch.empty(rows, k, device=device, dtype=torch.float32).exponential_(1, generator=generator)
+            out[f'u1_{tag}'] = torch.rand(rows, device=device, generator=generator)
+            out[f'u2_{tag}'] = None if last_step else torch.rand(rows, device=device, generator=generator)
+        return StepNoise(**out)
+
+    @staticmethod
+    def from_tape(tape: Sequence[torch.Tensor], pos: int, last_step: bool, device) -> "tuple[StepNoise, int]":
+        out = {}
+        for tag in 'ace':
+            out[f'q_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1
+            out[f'u1_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1
+            if last_step:
+                out[f'u2_{tag}'] = None
+            else:
+                out[f'u2_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1
+        return StepNoise(**out), pos
+
+    def c_struct(self) -> fm_step_noise:
+        s = fm_step_noise()
+        for k in self.__slots__:
+            setattr(s, k, _ptr(getattr(self, k)))
+        return s
+
+
+class Engine:
+    """One ``fm_ctx`` on one device."""
+
+    def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], device='cuda:0', prefix: str = '', lib=None):
+        cfg.validate()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.lib = lib if lib is not None else _lib.get_lib()
+        check_state_dict(cfg, state_dict, prefix)
+        shapes = state_dict_shapes(cfg)
+        # ---- flat host blob + descriptors, keys named as in the reference state dict
+        descs = (fm_tensor_desc * len(shapes))()
+        chunks, off = [], 0
+        self._names = []
+        for i, (key, shape) in enumerate(shapes.items()):
+            t = state_dict[prefix + key].detach().to('cpu', torch.float32).contiguous().reshape(-1)
+            chunks.append(t)
+            nm = key.encode()
+            self._names.append(nm)
+            descs[i].name = nm
+            descs[i].offset = off
+            descs[i].ndim = len(shape)
+            descs[i].shape[0] = shape[0]
+            descs[i].shape[1] = shape[1] if len(shape) > 1 else 0
+            off += t.numel()
+        blob = torch.cat(chunks) if chunks else torch.zeros(0)
+        c = fm_config()
+        c.abi_version = _lib.FM_ABI_VERSION
+        c.n_atom_types, c.n_charges, c.n_bond_types = cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types
+        c.n_vec_channels, c.n_hidden_scalars, c.n_hidden_edge_feats = cfg.n_vec_channels, cfg.n_hidden_scalars, cfg.n_hidden_edge_feats
+        c.rbf_dim, c.n_convs, c.n_updaters = cfg.rbf_dim, cfg.n_convs, cfg.n_updaters
+        sched = cfg.update_schedule()
+        if len(sched) > _lib.FM_MAX_CONVS:
+            raise NotImplementedError(f'more than {_lib.FM_MAX_CONVS} convolutions')
+        for i in range(_lib.FM_MAX_CONVS):
+            c.update_after[i] = sched[i] if i < len(sched) else -1
+        c.self_conditioning = int(cfg.self_conditioning)
+        c.time_embedding_dim = cfg.time_embedding_dim
+        c.a_token_dim, c.c_token_dim, c.e_token_dim = cfg.a_token_dim, cfg.c_token_dim, cfg.e_token_dim
+        c.rbf_dmax = float(cfg.rbf_dmax)
+        c.msg_z = float(cfg.msg_z)
+        self._ctx = C.c_void_p()
+        with self._dev():
+            rc = self.lib.fm_create(C.byref(c), descs, len(shapes), C.c_void_p(blob.data_ptr()), C.byref(self._ctx))
+        if rc != 0:
+            raise FlowMolHipError(f'fm_create failed ({rc}): {self.lib.fm_last_error(None).decode()}')
+        self._keep = []          # tensors referenced by raw pointer inside the library
+        self.N = self.E = self.U = self.B = 0
+        self._ws = None
+        self.n_atoms = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _dev(self):
+        if self.device.type == 'cuda':
+            return torch.cuda.device(self.device)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _stream(self):
+        if self.device.type == 'cuda':
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FlowMolHipError(f'{what} failed ({rc}): {self.lib.fm_last_error(self._ctx).decode()}')
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            if self.device.type == 'cuda':
+                torch.cuda.synchronize(self.device)
+            self.lib.fm_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ batch
+    def bind(self, n_atoms: torch.Tensor):
+        """Bind a batch of molecules given their sizes (order preserved).  Replaces the reference's
+        dgl.graph / dgl.batch / upper-edge-mask / batch-index construction (flowmol.py:509-529)."""
+        n = n_atoms.detach().to('cpu', torch.int32).contiguous()
+        if n.dim() != 1 or n.numel() == 0:
+            raise ValueError('n_atoms must be a non-empty 1-D tensor')
+        need = C.c_size_t()
+        self._check(self.lib.fm_workspace_bytes(self._ctx, C.c_void_p(n.data_ptr()), n.numel(), C.byref(need)), 'fm_workspace_bytes')
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value + 256, dtype=torch.uint8, device=self.device)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        with self._dev():
+            self._check(self.lib.fm_batch_bind(self._ctx, self._stream(), C.c_void_p(n.data_ptr()), n.numel(),
+                                               C.c_void_p(aligned), need.value), 'fm_batch_bind')
+        n64 = n.to(torch.int64)
+        self.n_atoms = n64
+        self.B = int(n.numel())
+        self.N = int(n64.sum())
+        self.E = int((n64 * (n64 - 1)).sum())
+        self.U = self.E // 2
+        self.workspace_bytes = int(need.value)
+        return self
+
+    def query(self, name: str) -> torch.Tensor:
+        cnt = {'e_src': self.E, 'e_dst': self.E, 'e_pair': self.E, 'p_e0': self.U, 'p_e1': self.U,
+               'node_mol': self.N, 'pair_mol': self.U}[name]
+        out = torch.empty(cnt, dtype=torch.int32, device=self.device)
+        with self._dev():
+            self._check(self.lib.fm_batch_query(self._ctx, self._stream(), name.encode(), _ptr(out)), 'fm_batch_query')
+        self.synchronize()
+        return out
+
+    # ------------------------------------------------------------------ tensors
+    def new_dst(self) -> Dict[str, torch.Tensor]:
+        d = self.device
+        return {'x': torch.empty(self.N, 3, device=d), 'a': torch.empty(self.N, self.cfg.n_atom_types, device=d),
+                'c': torch.empty(self.N, self.cfg.n_charges, device=d), 'e': torch.empty(self.U, self.cfg.n_bond_types, device=d)}
+
+    @staticmethod
+    def _dst_struct(d) -> fm_dst:
+        s = fm_dst()
+        s.x, s.a, s.c, s.e = _ptr(d['x']), _ptr(d['a']), _ptr(d['c']), _ptr(d['e'])
+        return s
+
+    @staticmethod
+    def _state_struct(st) -> fm_state:
+        s = fm_state()
+        s.x_t, s.a_t, s.c_t, s.e_t = _ptr(st['x_t']), _ptr(st['a_t']), _ptr(st['c_t']), _ptr(st['e_t'])
+        return s
+
+    def make_state(self, x_t, a_t, c_t, e_t) -> Dict[str, torch.Tensor]:
+        """x_t (N,3) float; a_t, c_t (N) and e_t (U, per unordered pair in reference upper-edge order) int tokens."""
+        d = self.device
+        st = {'x_t': x_t.detach().to(d, torch.float32).contiguous().clone(),
+              'a_t': a_t.detach().to(d, torch.int32).contiguous().clone(),
+              'c_t': c_t.detach().to(d, torch.int32).contiguous().clone(),
+              'e_t': e_t.detach().to(d, torch.int32).contiguous().clone()}
+        assert st['x_t'].shape == (self.N, 3) and st['a_t'].shape == (self.N,) and st['e_t'].shape == (self.U,)
+        return st
+
+    def prior_state(self, x_0: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """CTMC masked prior for a, c, e (priors.py:101-107,305-316) around given positions."""
+        d = self.device
+        return self.make_state(x_0, torch.full((self.N,), self.cfg.n_atom_types, dtype=torch.int32),
+                               torch.full((self.N,), self.cfg.n_charges, dtype=torch.int32),
+                               torch.full((self.U,), self.cfg.n_bond_types, dtype=torch.int32))
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, state, t: float, prev=None, bootstrap=False, remove_com=True, out=None, taps: Optional[Dict[str, torch.Tensor]] = None):
+        """One network evaluation -> dst dict of probabilities (EndpointVectorField.forward with
+        apply_softmax=True)."""
+        out = out if out is not None else self.new_dst()
+        temb = time_embedding_host(float(t), self.cfg.time_embedding_dim).to(self.device)
+        st = self._state_struct(state)
+        o = self._dst_struct(out)
+        p = self._dst_struct(prev) if prev is not None else None
+        self.lib.fm_clear_taps(self._ctx)
+        if taps:
+            for k, v in taps.items():
+                self._check(self.lib.fm_set_tap(self._ctx, k.encode(), _ptr(v)), 'fm_set_tap')
+        with self._dev():
+            rc = self.lib.fm_forward(self._ctx, self._stream(), C.byref(st), _ptr(temb), C.byref(p) if p is not None else None,
+                                     int(bool(bootstrap)), int(bool(remove_com)), C.byref(o))
+        self._check(rc, 'fm_forward')
+        if taps:
+            self.lib.fm_clear_taps(self._ctx)
+        self._keep = [temb, state, out, prev]
+        return out
+
+    def ctmc_step(self, state, dst, noise: StepNoise, sc: fm_step_scalars, sampled: Optional[Dict[str, torch.Tensor]] = None):
+        st = self._state_struct(state)
+        d = self._dst_struct(dst)
+        nz = noise.c_struct()
+        smp = fm_sampled()
+        if sampled is not None:
+            smp.a1, smp.c1, smp.e1 = _ptr(sampled['a1']), _ptr(sampled['c1']), _ptr(sampled['e1'])
+        with self._dev():
+            rc = self.lib.fm_ctmc_step(self._ctx, self._stream(), C.byref(st), C.byref(d), C.byref(nz), C.byref(sc), C.byref(smp))
+        self._check(rc, 'fm_ctmc_step')
+        self._keep = [state, dst, noise, sampled]
+        return state
+
+    def integrate(self, state, plan: StepPlan, noise_for_step, chunk: int = 32, traj: Optional[Dict[str, torch.Tensor]] = None):
+        """Run all steps of ``plan`` (CTMCVectorField.integrate).  ``noise_for_step(i, last)`` returns the
+        StepNoise of step i; noise is produced ``chunk`` steps ahead and each chunk is one fm_integrate
+        call (no host synchronisation in between).  Returns the final endpoint prediction dict."""
+        n_steps = len(plan.scalars)
+        tt = self.cfg.time_embedding_dim
+        temb_all = torch.stack([time_embedding_host(sc.t, tt) for sc in plan.scalars]).to(self.device).contiguous()
+        dst = [self.new_dst(), self.new_dst()]
+        dsts = [self._dst_struct(dst[0]), self._dst_struct(dst[1])]
+        st = self._state_struct(state)
+        final = C.c_int(0)
+        prev_idx = None
+        keep = []
+        for lo in range(0, n_steps, chunk):
+            hi = min(n_steps, lo + chunk)
+            k = hi - lo
+            scal = (fm_step_scalars * k)(*plan.scalars[lo:hi])
+            noises = [noise_for_step(i, bool(plan.scalars[i].last_step)) for i in range(lo, hi)]
+            nzs = (fm_step_noise * k)(*[nz.c_struct() for nz in noises])
+            sink = None
+            if traj is not None:
+                sink = fm_traj_sink()
+                for name in ('x', 'a', 'c', 'e', 'x1', 'a1', 'c1', 'e1'):
+                    tsr = traj.get(name)
+                    setattr(sink, name, _ptr(tsr[lo:]) if tsr is not None else None)
+            with self._dev():
+                rc = self.lib.fm_integrate(self._ctx, self._stream(), C.byref(st), k, scal, _ptr(temb_all[lo:]), nzs,
+                                           C.byref(dsts[prev_idx]) if prev_idx is not None else None,
+                                           C.byref(dsts[0]), C.byref(dsts[1]), C.byref(sink) if sink is not None else None,
+                                           C.byref(final))
+            self._check(rc, 'fm_integrate')
+            prev_idx = final.value
+            keep.append((noises, scal, nzs))
+            if len(keep) > 2:        # bound the noise kept alive: make sure older chunks have been consumed
+                self.synchronize()
+                keep = keep[-1:]
+        self.synchronize()
+        return dst[final.value]
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, on: bool):
+        self._check(self.lib.fm_profile_enable(self._ctx, int(on)), 'fm_profile_enable')
+
+    def profile_get(self, kernel: str):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.fm_profile_get(self._ctx, kernel.encode(), C.byref(ms), C.byref(n)), 'fm_profile_get')
+        return ms.value, n.value

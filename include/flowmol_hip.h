@@ -1,0 +1,174 @@
+/* C ABI of libflowmol_hip.so -- the MI355X-native replacement for the FlowMol3 sampling hot path.
+ *
+ * The reference (Dunni3/FlowMol) is pure Python and has NO FFI; this header declares the boundary a
+ * maintainer would bind with ctypes (INTEGRATION.md shows the stub).  Each entry point cites the
+ * reference code it replaces (paths are into the reference tree):
+ *
+ *   fm_create           weights of flowmol/models/ctmc_vector_field.py:CTMCVectorField (state-dict keys
+ *                       "vector_field.*"), repacked for MFMA
+ *   fm_batch_bind       graph batching: flowmol/models/flowmol.py:509-529 (dgl.graph/dgl.batch),
+ *                       flowmol/data_processing/utils.py:4-46 (edge list, upper-edge mask, batch idxs)
+ *   fm_forward          EndpointVectorField.forward, flowmol/models/vector_field.py:212-369
+ *                       (incl. GVPConv gvp.py:435-543, NodePositionUpdate/EdgeUpdate vector_field.py:813-880,
+ *                       SelfConditioningResidualLayer self_conditioning.py:37-85)
+ *   fm_ctmc_step        the part of CTMCVectorField.step after the network evaluation,
+ *                       ctmc_vector_field.py:328-411 + campbell_step :414-461 + purity_sampling ctmc_utils.py:4-34
+ *   fm_integrate        CTMCVectorField.integrate, ctmc_vector_field.py:145-285
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative fm_status; the message is available from
+ *     fm_last_error(ctx) (ctx may be NULL for errors of fm_create).  Nothing throws across the ABI.
+ *   - all tensor arguments are DEVICE pointers to caller-owned memory (torch tensors passed as
+ *     data_ptr()); the library never frees caller memory.  After fm_create the library allocates
+ *     nothing: per-batch scratch lives in the caller-provided workspace of fm_batch_bind.
+ *   - kernels are enqueued on the hipStream_t passed in (as void*); no call synchronises the stream.
+ *   - a context is bound to the device current at fm_create and is not thread-safe.
+ *   - categorical state is exchanged as int32 token indices (mask token = number of real categories);
+ *     edge state is per UNORDERED pair in the reference's upper-triangle order
+ *     (torch.triu_indices(n,n,1) row-major per molecule, molecules concatenated) -- both directed
+ *     edges of a pair always carry the same token in the reference (ctmc_vector_field.py:397-409).
+ *   - probabilities ("dst") are float32: x (N,3), a (N,n_atom_types), c (N,n_charges), e (U,n_bond_types).
+ */
+#ifndef FLOWMOL_HIP_H
+#define FLOWMOL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FM_ABI_VERSION 1
+#define FM_MAX_CONVS 16
+
+typedef enum fm_status {
+    FM_OK = 0,
+    FM_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    FM_ERR_WEIGHTS = -2,      /* missing tensor or wrong shape */
+    FM_ERR_HIP = -3,          /* a HIP runtime call or kernel launch failed */
+    FM_ERR_STATE = -4,        /* call order (no batch bound, ...) */
+    FM_ERR_NOMEM = -5
+} fm_status;
+
+typedef struct fm_ctx fm_ctx;
+
+/* mirrors flowmol_amd.config.VFConfig (the reference's vector_field: YAML block) */
+typedef struct fm_config {
+    int32_t abi_version;          /* FM_ABI_VERSION */
+    int32_t n_atom_types;         /* real atom categories incl. the fake-atom type, excl. mask */
+    int32_t n_charges;
+    int32_t n_bond_types;
+    int32_t n_vec_channels;       /* 16 or 32 */
+    int32_t n_hidden_scalars;     /* 256 */
+    int32_t n_hidden_edge_feats;  /* 128 */
+    int32_t rbf_dim;              /* 32 */
+    int32_t n_convs;
+    int32_t n_updaters;
+    int32_t update_after[FM_MAX_CONVS];   /* updater index run after conv i, or -1 (vector_field.py:320-326) */
+    int32_t self_conditioning;
+    int32_t time_embedding_dim;   /* 1 = raw t */
+    int32_t a_token_dim, c_token_dim, e_token_dim;   /* 0 = one-hot input */
+    float rbf_dmax;
+    float msg_z;                  /* divisor of the aggregated messages (1 for 'sum') */
+} fm_config;
+
+/* one tensor of the reference state dict inside the host weight blob */
+typedef struct fm_tensor_desc {
+    const char* name;             /* reference state-dict key without the "vector_field." prefix */
+    int64_t offset;               /* in floats from the start of the blob */
+    int32_t ndim;
+    int64_t shape[2];
+} fm_tensor_desc;
+
+typedef struct fm_dst {           /* endpoint prediction ("dst_dict" of the reference) */
+    float* x;                     /* (N,3) */
+    float* a;                     /* (N,n_atom_types) probabilities */
+    float* c;                     /* (N,n_charges) */
+    float* e;                     /* (U,n_bond_types) */
+} fm_dst;
+
+typedef struct fm_state {         /* g.ndata['x_t','a_t','c_t'], g.edata['e_t'] of the reference */
+    float* x_t;                   /* (N,3) */
+    int32_t* a_t;                 /* (N) */
+    int32_t* c_t;                 /* (N) */
+    int32_t* e_t;                 /* (U) */
+} fm_state;
+
+typedef struct fm_step_noise {    /* draws of one CTMC step, in the reference's order and shapes */
+    const float* q_a;  const float* u1_a;  const float* u2_a;    /* (N,na) Exp(1), (N) U, (N) U */
+    const float* q_c;  const float* u1_c;  const float* u2_c;
+    const float* q_e;  const float* u1_e;  const float* u2_e;    /* (U,ne), (U), (U) */
+} fm_step_noise;
+
+typedef struct fm_step_scalars {  /* host-computed with the reference's float32 arithmetic */
+    float t;                      /* t_i */
+    float dt;                     /* s_i - t_i */
+    float x_coef;                 /* alpha'_x / (1 - alpha_x) */
+    float unmask_prob[3];         /* a, c, e: clamp(dt*(alpha' + eta*alpha)/(1-alpha), 0, 1) */
+    float mask_prob[3];           /* clamp(dt*eta, 0, 1) */
+    float hc_thresh;              /* purity threshold; 0 = uniform unmasking branch */
+    float cat_temperature;        /* 0.05 by default */
+    int32_t last_step;
+} fm_step_scalars;
+
+typedef struct fm_sampled {       /* sampled endpoint tokens of a step ("*_1_pred"), optional (may be NULL) */
+    int32_t* a1; int32_t* c1; int32_t* e1;
+} fm_sampled;
+
+typedef struct fm_traj_sink {     /* optional per-step frames (xt_traj / ep_traj); any pointer may be NULL */
+    float* x;  int32_t* a;  int32_t* c;  int32_t* e;             /* (n_steps, ...) state after each step */
+    float* x1; int32_t* a1; int32_t* c1; int32_t* e1;            /* (n_steps, ...) endpoint predictions */
+} fm_traj_sink;
+
+const char* fm_last_error(const fm_ctx* ctx);
+int fm_abi_version(void);
+
+int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors, const float* host_blob,
+              fm_ctx** out);
+int fm_destroy(fm_ctx* ctx);
+
+/* bytes of caller-provided device workspace needed for a batch of molecules with the given sizes */
+int fm_workspace_bytes(fm_ctx* ctx, const int32_t* n_atoms_host, int n_mols, size_t* bytes);
+/* bind a batch: builds the internal destination-sorted edge layout inside `workspace` */
+int fm_batch_bind(fm_ctx* ctx, void* stream, const int32_t* n_atoms_host, int n_mols, void* workspace, size_t bytes);
+
+/* one network evaluation.  temb: device (time_embedding_dim) floats (raw t when dim == 1).
+ * prev: previous endpoint for self-conditioning or NULL.  bootstrap != 0 reproduces the reference's
+ * first-step behaviour (vector_field.py:269-282): an extra evaluation with remove_com=False whose
+ * result is used as `prev`.  out.a/c/e receive softmax probabilities, out.x is COM-free iff remove_com. */
+int fm_forward(fm_ctx* ctx, void* stream, const fm_state* state, const float* temb, const fm_dst* prev,
+               int bootstrap, int remove_com, const fm_dst* out);
+
+/* Euler step for x and the CTMC update of a, c, e given the endpoint prediction `dst` */
+int fm_ctmc_step(fm_ctx* ctx, void* stream, const fm_state* state, const fm_dst* dst,
+                 const fm_step_noise* noise, const fm_step_scalars* sc, const fm_sampled* sampled);
+
+/* n_steps Euler/CTMC steps: per step fm_forward (+bootstrap on step 0 for self-conditioned models when
+ * steps[0].t == 0) then fm_ctmc_step.  temb: device (n_steps, time_embedding_dim); noise: host array of
+ * n_steps fm_step_noise (device pointers); prev0: endpoint of the step before the first one (NULL at the
+ * start of a trajectory; dst_a or dst_b when a trajectory is integrated in several calls);
+ * dst_a/dst_b: two caller-provided endpoint buffers used alternately (the one holding the final
+ * prediction is returned in *final_dst, 0 or 1). */
+int fm_integrate(fm_ctx* ctx, void* stream, const fm_state* state, int n_steps, const fm_step_scalars* steps,
+                 const float* temb, const fm_step_noise* noise, const fm_dst* prev0, const fm_dst* dst_a,
+                 const fm_dst* dst_b, const fm_traj_sink* sink, int* final_dst);
+
+/* debugging / parity taps: copy an internal buffer to `dst` (device) after the next fm_forward stages.
+ * name: "embed.s", "sc.s", "sc.ef", "conv<i>.s", "conv<i>.v", "conv<i>.agg.s", "conv<i>.agg.v",
+ * "upd<i>.x", "upd<i>.ef", "conv0.msg.s", "conv0.msg.v"; internal layouts: v (N,3,V), ef (E,128) in the
+ * internal edge order.  fm_batch_query copies an int32 descriptor array ("e_src","e_dst","e_pair",
+ * "p_e0","p_e1","node_mol") to `dst`. */
+int fm_set_tap(fm_ctx* ctx, const char* name, void* dst);
+int fm_clear_taps(fm_ctx* ctx);
+int fm_batch_query(fm_ctx* ctx, void* stream, const char* name, int32_t* dst);
+
+/* per-kernel timing of the last fm_forward / fm_integrate when enabled (HIP events on `stream`):
+ * fm_profile_enable(ctx, 1); ... ; fm_profile_get(ctx, "edge_message", &total_ms, &launches) */
+int fm_profile_enable(fm_ctx* ctx, int on);
+int fm_profile_get(fm_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWMOL_HIP_H */

@@ -1,0 +1,178 @@
+// TEST TOOLING ONLY -- a host-side stand-in for <hip/hip_runtime.h>.
+//
+// It lets the *unmodified* HIP sources under flowmol_amd/csrc/ be compiled with the host clang++
+// (tests/emu/build_emu.sh puts this directory first on the include path) into
+// tests/emu/libflowmol_emu.so, where every workgroup is executed on the CPU: lanes are
+// coroutines, __syncthreads / MFMA / shuffles are rendezvous points, LDS is a heap buffer.
+// Purpose: debug index math, LDS layouts, MFMA fragment maps and weight packing in the build
+// container (which has no GPU) before spending GPU minutes.  The product never loads this
+// library: flowmol_amd/_lib.py only opens libflowmol_hip.so and fails loudly if it is missing.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define FM_HOST_EMULATION 1
+
+// ---------------------------------------------------------------- qualifiers
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+#define __shared__ static thread_local
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---------------------------------------------------------------- vector types
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+// ---------------------------------------------------------------- runtime (emu_rt.cpp)
+namespace emu {
+struct Lane;
+struct BlockCtx {
+    dim3 blockIdx, blockDim, gridDim;
+    unsigned char* lds;
+    size_t lds_bytes;
+};
+struct LaneView { dim3 tid; };
+Lane* cur();
+BlockCtx& blk();
+const dim3& tid();
+void syncthreads();
+float shfl_f(float v, int src_lane, int width);
+int shfl_i(int v, int src_lane, int width);
+void mfma16(float a, float b, float* c4);          // 16x16x4 f32
+void mfma32(float a, float b, float* c16);         // 32x32x2 f32
+unsigned long long ballot(int pred);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+int lane_id();
+}  // namespace emu
+
+#define threadIdx (emu::tid())
+#define blockIdx (emu::blk().blockIdx)
+#define blockDim (emu::blk().blockDim)
+#define gridDim (emu::blk().gridDim)
+#define warpSize 64
+
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emu::blk().lds);
+
+static inline void __syncthreads() { emu::syncthreads(); }
+
+static inline float __shfl(float v, int src, int width = 64) { return emu::shfl_f(v, src, width); }
+static inline int __shfl(int v, int src, int width = 64) { return emu::shfl_i(v, src, width); }
+static inline float __shfl_xor(float v, int mask, int width = 64) { return emu::shfl_f(v, emu::lane_id() ^ mask, width); }
+static inline int __shfl_xor(int v, int mask, int width = 64) { return emu::shfl_i(v, emu::lane_id() ^ mask, width); }
+static inline float __shfl_down(float v, unsigned d, int width = 64) {
+    int l = emu::lane_id();
+    int s = ((l % width) + (int)d < width) ? l + (int)d : l;
+    return emu::shfl_f(v, s, 64);
+}
+static inline int __shfl_down(int v, unsigned d, int width = 64) {
+    int l = emu::lane_id();
+    int s = ((l % width) + (int)d < width) ? l + (int)d : l;
+    return emu::shfl_i(v, s, 64);
+}
+static inline unsigned long long __ballot(int pred) { return emu::ballot(pred); }
+
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+static inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c, int, int, int) {
+    float t[4] = {c[0], c[1], c[2], c[3]};
+    emu::mfma16(a, b, t);
+    return emu_f32x4{t[0], t[1], t[2], t[3]};
+}
+static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, int, int) {
+    float t[16];
+    for (int i = 0; i < 16; ++i) t[i] = c[i];
+    emu::mfma32(a, b, t);
+    emu_f32x16 r;
+    for (int i = 0; i < 16; ++i) r[i] = t[i];
+    return r;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
+
+// ---------------------------------------------------------------- device math
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+// correctly-rounded, never-contracted f32 ops (the emulation is built with -ffp-contract=off)
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+
+// ---------------------------------------------------------------- atomics (blocks may run on several OS threads)
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline float atomicAdd(float* p, float v) {
+    uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), neu;
+    float f;
+    do {
+        memcpy(&f, &old, 4);
+        f += v;
+        memcpy(&neu, &f, 4);
+    } while (!__atomic_compare_exchange_n(ip, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&f, &old, 4);
+    return f;
+}
+
+// ---------------------------------------------------------------- host API subset
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+#define hipErrorOutOfMemory 2
+typedef void* hipStream_t;
+struct emu_event { double t; };
+typedef emu_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
+
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = n ? aligned_alloc(256, (n + 255) / 256 * 256) : nullptr; return (*p || !n) ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated hip error"; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "host-emulation");
+    strcpy(p->gcnArchName, "emu");
+    p->multiProcessorCount = 8;
+    return hipSuccess;
+}
+template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+double emu_now_ms();
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{0}; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = emu_now_ms(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
