@@ -71,6 +71,7 @@ _EXPORTS = {
     'fm_destroy': (C.c_int, [C.c_void_p]),
     'fm_workspace_bytes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     'fm_batch_bind': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    'fm_remove_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'fm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.c_void_p, C.POINTER(fm_dst), C.c_int, C.c_int,
                              C.POINTER(fm_dst)]),
     'fm_ctmc_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.POINTER(fm_dst), C.POINTER(fm_step_noise),

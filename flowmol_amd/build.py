@@ -1,0 +1,58 @@
+"""Build libflowmol_hip.so in-tree for gfx950 (MI355X) with hipcc.
+
+    python -m flowmol_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The library travels with the repo snapshot to the GPU box;
+it is git-ignored (source-only history).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+SRC = PKG / 'csrc'
+OUT = PKG / 'libflowmol_hip.so'
+STAMP = PKG / '.libflowmol_hip.stamp'
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', f'--offload-arch={ARCH}', '-Wno-pass-failed']
+
+
+def _sources():
+    return sorted(list(SRC.glob('*.cpp')) + list(SRC.glob('*.h')) + [PKG.parent / 'include' / 'flowmol_hip.h'])
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in _sources():
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    dig = _digest()
+    if not force and OUT.exists() and STAMP.exists() and STAMP.read_text().strip() == dig:
+        return OUT
+    if not Path(hipcc).exists():
+        if OUT.exists():
+            # e.g. the GPU box: the prebuilt library travelled with the snapshot
+            return OUT
+        raise RuntimeError('hipcc not found and no prebuilt libflowmol_hip.so present')
+    cmd = [hipcc, *FLAGS, '-x', 'hip', str(SRC / 'fm_engine.cpp'), '-o', str(OUT)]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    STAMP.write_text(dig)
+    return OUT
+
+
+if __name__ == '__main__':
+    p = build(force='--force' in sys.argv)
+    print('built', p, f'({p.stat().st_size // 1024} KiB)')

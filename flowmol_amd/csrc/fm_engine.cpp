@@ -700,6 +700,14 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     return FM_OK;
 }
 
+int fm_remove_com(fm_ctx* c, void* stream, float* x) {
+    if (!c || !x) return fail(c, FM_ERR_INVALID, "fm_remove_com: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_remove_com: no batch bound");
+    Launch L{c, (hipStream_t)stream};
+    L("remove_com", fm_k_remove_com, dim3(c->b.B), dim3(64), 0, x, (const int*)c->b.mol_node_off);
+    return L.rc;
+}
+
 int fm_forward(fm_ctx* c, void* stream, const fm_state* state, const float* temb, const fm_dst* prev, int bootstrap, int remove_com,
                const fm_dst* out) {
     if (!c || !state || !temb || !out) return fail(c, FM_ERR_INVALID, "fm_forward: null argument");

@@ -269,6 +269,13 @@ class Engine:
                                torch.full((self.N,), self.cfg.n_charges, dtype=torch.int32),
                                torch.full((self.U,), self.cfg.n_bond_types, dtype=torch.int32))
 
+    def remove_com(self, x: torch.Tensor) -> torch.Tensor:
+        """In-place per-molecule centring of an (N,3) tensor on the engine's device."""
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.shape == (self.N, 3)
+        with self._dev():
+            self._check(self.lib.fm_remove_com(self._ctx, self._stream(), _ptr(x)), 'fm_remove_com')
+        return x
+
     # ------------------------------------------------------------------ hot path
     def forward(self, state, t: float, prev=None, bootstrap=False, remove_com=True, out=None, taps: Optional[Dict[str, torch.Tensor]] = None):
         """One network evaluation -> dst dict of probabilities (EndpointVectorField.forward with
@@ -308,40 +315,10 @@ class Engine:
         """Run all steps of ``plan`` (CTMCVectorField.integrate).  ``noise_for_step(i, last)`` returns the
         StepNoise of step i; noise is produced ``chunk`` steps ahead and each chunk is one fm_integrate
         call (no host synchronisation in between).  Returns the final endpoint prediction dict."""
-        n_steps = len(plan.scalars)
-        tt = self.cfg.time_embedding_dim
-        temb_all = torch.stack([time_embedding_host(sc.t, tt) for sc in plan.scalars]).to(self.device).contiguous()
-        dst = [self.new_dst(), self.new_dst()]
-        dsts = [self._dst_struct(dst[0]), self._dst_struct(dst[1])]
-        st = self._state_struct(state)
-        final = C.c_int(0)
-        prev_idx = None
-        keep = []
-        for lo in range(0, n_steps, chunk):
-            hi = min(n_steps, lo + chunk)
-            k = hi - lo
-            scal = (fm_step_scalars * k)(*plan.scalars[lo:hi])
-            noises = [noise_for_step(i, bool(plan.scalars[i].last_step)) for i in range(lo, hi)]
-            nzs = (fm_step_noise * k)(*[nz.c_struct() for nz in noises])
-            sink = None
-            if traj is not None:
-                sink = fm_traj_sink()
-                for name in ('x', 'a', 'c', 'e', 'x1', 'a1', 'c1', 'e1'):
-                    tsr = traj.get(name)
-                    setattr(sink, name, _ptr(tsr[lo:]) if tsr is not None else None)
-            with self._dev():
-                rc = self.lib.fm_integrate(self._ctx, self._stream(), C.byref(st), k, scal, _ptr(temb_all[lo:]), nzs,
-                                           C.byref(dsts[prev_idx]) if prev_idx is not None else None,
-                                           C.byref(dsts[0]), C.byref(dsts[1]), C.byref(sink) if sink is not None else None,
-                                           C.byref(final))
-            self._check(rc, 'fm_integrate')
-            prev_idx = final.value
-            keep.append((noises, scal, nzs))
-            if len(keep) > 2:        # bound the noise kept alive: make sure older chunks have been consumed
-                self.synchronize()
-                keep = keep[-1:]
+        run = IntegrationRun(self, state, plan, noise_for_step, traj=traj)
+        run.run(0, len(plan.scalars), chunk=chunk)
         self.synchronize()
-        return dst[final.value]
+        return run.last_dst()
 
     # ------------------------------------------------------------------ profiling
     def profile(self, on: bool):
@@ -351,3 +328,54 @@ class Engine:
         ms, n = C.c_double(), C.c_int64()
         self._check(self.lib.fm_profile_get(self._ctx, kernel.encode(), C.byref(ms), C.byref(n)), 'fm_profile_get')
         return ms.value, n.value
+
+
+class IntegrationRun:
+    """A trajectory in progress: owns the two endpoint buffers and remembers which one holds the previous
+    step's prediction, so a trajectory can be advanced in several fm_integrate calls (bench.py times a
+    window of steps; Engine.integrate runs them all)."""
+
+    def __init__(self, eng: Engine, state, plan: StepPlan, noise_for_step, traj=None):
+        self.eng, self.state, self.plan, self.noise_for_step, self.traj = eng, state, plan, noise_for_step, traj
+        tt = eng.cfg.time_embedding_dim
+        self.temb_all = torch.stack([time_embedding_host(sc.t, tt) for sc in plan.scalars]).to(eng.device).contiguous()
+        self.dst = [eng.new_dst(), eng.new_dst()]
+        self._dsts = [eng._dst_struct(self.dst[0]), eng._dst_struct(self.dst[1])]
+        self._st = eng._state_struct(state)
+        self.prev_idx = None
+        self._keep = []
+
+    def reset(self, state):
+        self.state = state
+        self._st = self.eng._state_struct(state)
+        self.prev_idx = None
+
+    def last_dst(self):
+        return None if self.prev_idx is None else self.dst[self.prev_idx]
+
+    def run(self, lo: int, hi: int, chunk: int = 32):
+        eng = self.eng
+        final = C.c_int(0)
+        for a in range(lo, hi, chunk):
+            b = min(hi, a + chunk)
+            k = b - a
+            scal = (fm_step_scalars * k)(*self.plan.scalars[a:b])
+            noises = [self.noise_for_step(i, bool(self.plan.scalars[i].last_step)) for i in range(a, b)]
+            nzs = (fm_step_noise * k)(*[nz.c_struct() for nz in noises])
+            sink = None
+            if self.traj is not None:
+                sink = fm_traj_sink()
+                for name in ('x', 'a', 'c', 'e', 'x1', 'a1', 'c1', 'e1'):
+                    tsr = self.traj.get(name)
+                    setattr(sink, name, _ptr(tsr[a:]) if tsr is not None else None)
+            with eng._dev():
+                rc = eng.lib.fm_integrate(eng._ctx, eng._stream(), C.byref(self._st), k, scal, _ptr(self.temb_all[a:]), nzs,
+                                          C.byref(self._dsts[self.prev_idx]) if self.prev_idx is not None else None,
+                                          C.byref(self._dsts[0]), C.byref(self._dsts[1]),
+                                          C.byref(sink) if sink is not None else None, C.byref(final))
+            eng._check(rc, 'fm_integrate')
+            self.prev_idx = final.value
+            self._keep.append((noises, scal, nzs))
+            if len(self._keep) > 2:      # bound the noise kept alive: older chunks must have been consumed
+                eng.synchronize()
+                self._keep = self._keep[-1:]

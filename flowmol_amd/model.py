@@ -1,0 +1,279 @@
+"""``FlowMol``: the sampling-side drop-in for the reference's LightningModule
+(reference flowmol/models/flowmol.py: ``sample_random_sizes`` 473-486, ``sample`` 489-589,
+``sample_n_atoms`` 468-471, ``build_n_atoms_dist`` 461-466) backed by the HIP engine.
+
+    import flowmol_amd as flowmol
+    model = flowmol.load_pretrained('flowmol3').cuda().eval()
+    mols = model.sample_random_sizes(n_molecules=10, n_timesteps=250)
+
+Training, losses, optimizers and the chemistry metrics are out of scope.
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import torch
+
+from . import presets
+from .config import VFConfig, from_reference_hparams
+from .engine import Engine, StepNoise, make_step_plan
+from .molecule import SampledMolecule
+from .weights import synth_state_dict
+
+PKG = Path(__file__).resolve().parent
+
+
+def load_n_atoms_hist(name: str):
+    data = json.loads((PKG / 'data' / 'n_atoms_hist.json').read_text())
+    if name not in data:
+        raise KeyError(f'no size histogram named {name!r}; have {sorted(data)}')
+    return torch.tensor(data[name]['n_atoms'], dtype=torch.int64), torch.tensor(data[name]['counts'], dtype=torch.int64)
+
+
+class _Lenient(pickle.Unpickler):
+    """Unpickler for Lightning checkpoints without Lightning installed: unknown classes
+    (pytorch_lightning AttributeDict & co.) become plain dict / object stand-ins."""
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            if 'AttributeDict' in name or name.endswith('Dict'):
+                return dict
+            return type(name, (), {'__setstate__': lambda self, st: self.__dict__.update(st if isinstance(st, dict) else {})})
+
+
+class _LenientPickle:
+    Unpickler = _Lenient
+    __name__ = 'lenient_pickle'
+
+    @staticmethod
+    def load(f, **kw):
+        return _Lenient(f, **kw).load()
+
+
+def read_checkpoint(path):
+    """Lightning-free reader of ``<model_dir>/checkpoints/last.ckpt``: returns (hyper_parameters, state_dict)
+    (reference flowmol/__init__.py:54-55 -> FlowMol.load_from_checkpoint)."""
+    ck = torch.load(str(path), map_location='cpu', weights_only=False, pickle_module=_LenientPickle)
+    if 'state_dict' not in ck or 'hyper_parameters' not in ck:
+        raise ValueError(f'{path}: not a Lightning checkpoint (need state_dict and hyper_parameters)')
+    return dict(ck['hyper_parameters']), ck['state_dict']
+
+
+class FlowMol:
+    canonical_feat_order = ['x', 'a', 'c', 'e']
+
+    def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], prefix: str = 'vector_field.',
+                 n_atoms_hist: Optional[str] = None, _engine_lib=None):
+        self.cfg = cfg.validate()
+        self._sd = state_dict
+        self._prefix = prefix
+        self._lib = _engine_lib
+        self.atom_type_map = list(cfg.atom_type_map)
+        self.n_atom_types = cfg.n_atom_types
+        self.n_atom_charges = cfg.n_charges
+        self.n_bond_types = cfg.n_bond_types
+        self.fake_atoms = cfg.fake_atoms
+        self.explicit_aromaticity = cfg.explicit_aromaticity
+        self.default_n_timesteps = cfg.default_n_timesteps
+        self.parameterization = 'ctmc'
+        self.device = torch.device('cpu')
+        self._engine: Optional[Engine] = None
+        self.build_n_atoms_dist(n_atoms_hist or cfg.n_atoms_hist)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_preset(cls, name: str = 'flowmol3', seed: int = 0, **kw) -> "FlowMol":
+        """Architecture ``name`` with deterministic weights-by-name (no checkpoint ships with the reference)."""
+        cfg = presets.PRESETS[name]()
+        sd = {'vector_field.' + k: v for k, v in synth_state_dict(cfg, seed).items()}
+        return cls(cfg, sd, **kw)
+
+    @classmethod
+    def load_from_checkpoint(cls, ckpt_path, **kw) -> "FlowMol":
+        hp, sd = read_checkpoint(ckpt_path)
+        if hp.get('parameterization', 'ctmc') != 'ctmc':
+            raise NotImplementedError("only parameterization='ctmc' (FlowMol2/3) is implemented")
+        for mod in ('a', 'c', 'e'):
+            if hp.get('prior_config', {}).get(mod, {}).get('type', 'ctmc') != 'ctmc':
+                raise NotImplementedError('only ctmc masked priors are supported (as in the reference, flowmol.py:189-193)')
+        return cls(from_reference_hparams(hp), sd, **kw)
+
+    # nn.Module-ish conveniences of the documented usage (readme.md:44-49)
+    def to(self, device) -> "FlowMol":
+        device = torch.device(device)
+        if device != self.device or self._engine is None:
+            if self._engine is not None:
+                self._engine.close()
+                self._engine = None
+            self.device = device
+        return self
+
+    def cuda(self, device=None) -> "FlowMol":
+        return self.to('cuda:0' if device is None else (f'cuda:{device}' if isinstance(device, int) else device))
+
+    def eval(self) -> "FlowMol":
+        return self
+
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            if self.device.type != 'cuda' and self._lib is None:
+                raise RuntimeError('flowmol_amd runs on MI355X only: move the model to a GPU with .cuda() '
+                                   '(there is no CPU implementation of the sampling path)')
+            self._engine = Engine(self.cfg, self._sd, device=self.device, prefix=self._prefix, lib=self._lib)
+        return self._engine
+
+    # ------------------------------------------------------------------ sizes
+    def build_n_atoms_dist(self, n_atoms_hist):
+        """flowmol.py:461-466."""
+        if isinstance(n_atoms_hist, (str, Path)) and str(n_atoms_hist).endswith('.pt'):
+            n_atoms, counts = torch.load(str(n_atoms_hist))
+        else:
+            n_atoms, counts = load_n_atoms_hist(str(n_atoms_hist))
+        self.n_atoms_dist = torch.distributions.Categorical(probs=counts / counts.sum())
+        self.n_atoms_map = n_atoms
+
+    def sample_n_atoms(self, n_molecules: int, **kwargs):
+        """flowmol.py:468-471 (draws on the CPU generator like the reference)."""
+        return self.n_atoms_map[self.n_atoms_dist.sample((n_molecules,), **kwargs)]
+
+    # ------------------------------------------------------------------ sampling
+    def sample_random_sizes(self, n_molecules: int, device=None, stochasticity=None, high_confidence_threshold=None,
+                            xt_traj=False, ep_traj=False, **kwargs) -> List[SampledMolecule]:
+        atoms_per_molecule = self.sample_n_atoms(n_molecules)
+        return self.sample(atoms_per_molecule, device=device, stochasticity=stochasticity,
+                           high_confidence_threshold=high_confidence_threshold, xt_traj=xt_traj, ep_traj=ep_traj, **kwargs)
+
+    @torch.no_grad()
+    def sample(self, n_atoms: torch.Tensor, n_timesteps: int = None, device=None, stochasticity=None,
+               high_confidence_threshold=None, xt_traj=False, ep_traj=False, prior=None, return_tensors=False,
+               **kwargs):
+        """Sample molecules with the given numbers of atoms (flowmol.py:489-589).
+
+        RNG use mirrors the reference: ``randn(N,3)`` on the device for the position prior, then per step
+        and per modality (a, c, e) ``Exp(1)`` of shape (rows, K), ``rand(rows)``, ``rand(rows)`` (the last
+        one skipped on the final step)."""
+        if device is not None and torch.device(device) != self.device:
+            self.to(device)
+        eng = self.engine
+        dev = eng.device
+        n_timesteps = self.default_n_timesteps if n_timesteps is None else n_timesteps
+        for k in ('inv_temp_func', 'forward_weight_func'):
+            if kwargs.get(k) is not None:
+                raise NotImplementedError(f'{k} is not supported on the HIP path')
+        if kwargs.get('dfm_type', 'campbell') not in (None, 'campbell'):
+            raise NotImplementedError("only dfm_type='campbell' is implemented")
+        visualize = bool(xt_traj or ep_traj)
+        n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
+        eng.bind(n_atoms)
+        N, U = eng.N, eng.U
+        cfg = self.cfg
+        # ---- prior (flowmol.py:417-448 / 534-545)
+        if prior is None:
+            x0 = torch.randn(N, 3, device=dev)
+            eng.remove_com(x0)
+            state = eng.prior_state(x0)
+        else:
+            state = self._state_from_prior(prior)
+        eta = cfg.stochasticity if stochasticity is None else stochasticity
+        hc = cfg.high_confidence_threshold if high_confidence_threshold is None else high_confidence_threshold
+        temp = cfg.cat_temperature
+        plan = make_step_plan(n_timesteps, eta, hc, temp, tspan=kwargs.get('tspan'))
+        ctf = kwargs.get('cat_temp_func')
+        if ctf is not None:
+            for sc in plan.scalars:
+                sc.cat_temperature = float(ctf(torch.tensor(sc.t)))
+        n_steps = len(plan.scalars)
+        traj = None
+        if visualize:
+            i32 = dict(dtype=torch.int32, device=dev)
+            traj = {'x': torch.empty(n_steps, N, 3, device=dev), 'a': torch.empty(n_steps, N, **i32),
+                    'c': torch.empty(n_steps, N, **i32), 'e': torch.empty(n_steps, U, **i32),
+                    'x1': torch.empty(n_steps, N, 3, device=dev), 'a1': torch.empty(n_steps, N, **i32),
+                    'c1': torch.empty(n_steps, N, **i32), 'e1': torch.empty(n_steps, U, **i32)}
+            init = {k: state[f'{k}_t'].clone() for k in 'xace'}
+
+        def noise_for_step(i, last):
+            return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev)
+
+        eng.integrate(state, plan, noise_for_step, traj=traj)
+        out = {k: state[f'{k}_t'].cpu() for k in 'xace'}
+        if return_tensors:
+            return out, n_atoms
+        frames = None
+        if visualize:
+            frames = {k: torch.cat([init[k].unsqueeze(0), traj[k]]).cpu() for k in 'xace'}
+            frames.update({f'{k}_1_pred': traj[f'{k}1'].cpu() for k in 'xace'})
+        return self._package(out, n_atoms, frames, xt_traj, ep_traj)
+
+    # ------------------------------------------------------------------ helpers
+    def _state_from_prior(self, prior):
+        """Reference-format prior dict: x_0 (N,3), a_0/c_0 one-hot (N,*), e_0 one-hot (E,*) in reference edge order."""
+        eng = self.engine
+        a0 = prior['a_0']
+        if prior.get('fake_atoms', False) and not self.fake_atoms:
+            a0 = a0[:, 1:]
+        elif not prior.get('fake_atoms', False) and self.fake_atoms:
+            a0 = torch.cat([torch.zeros(a0.shape[0], 1, device=a0.device), a0], dim=-1)
+        e0 = prior['e_0']
+        n = eng.n_atoms
+        if e0.shape[0] == eng.E:      # directed edges, upper block first per molecule -> keep the upper halves
+            idx, off = [], 0
+            for k in n.tolist():
+                u = k * (k - 1) // 2
+                idx.append(torch.arange(off, off + u))
+                off += 2 * u
+            e0 = e0[torch.cat(idx)]
+        return eng.make_state(prior['x_0'], a0.argmax(-1), prior['c_0'].argmax(-1), e0.argmax(-1))
+
+    def _package(self, out, n_atoms, frames, xt_traj, ep_traj) -> List[SampledMolecule]:
+        mols = []
+        noff = poff = 0
+        for n in n_atoms.tolist():
+            u = n * (n - 1) // 2
+            tf = None
+            if frames is not None:
+                tf = {}
+                for k, v in frames.items():
+                    tf[k] = v[:, poff:poff + u] if k.startswith('e') else v[:, noff:noff + n]
+            mols.append(SampledMolecule(out['x'][noff:noff + n], out['a'][noff:noff + n], out['c'][noff:noff + n],
+                                        out['e'][poff:poff + u], self.atom_type_map, fake_atoms=self.fake_atoms,
+                                        ctmc_mol=True, explicit_aromaticity=self.explicit_aromaticity, traj_frames=tf,
+                                        build_xt_traj=xt_traj, build_ep_traj=ep_traj))
+            noff += n
+            poff += u
+        return mols
+
+
+# names accepted by the reference's load_pretrained (flowmol/__init__.py:5-28)
+pretrained_model_names = [
+    'flowmol3', 'fm3_nodistort', 'fm3_none', 'fm3_ahigh', 'fm3_alow', 'fm3_chigh', 'fm3_clow', 'fm3_distort_extreme',
+    'fm3_distort_highp', 'fm3_distort_hight', 'fm3_distort_lowp', 'fm3_distort_lowt', 'fm3_ehigh', 'fm3_elow',
+    'fm3_fa_highp', 'fm3_fa_highstd', 'fm3_fa_lowp', 'fm3_fa_lowstd', 'fm3_scprop_high', 'fm3_scprop_low',
+    'fm3_xhigh', 'fm3_xlow',
+]
+
+
+def load_pretrained(model_name: str = 'flowmol3') -> FlowMol:
+    """Load ``<models_dir>/<model_name>/checkpoints/last.ckpt`` (reference flowmol/__init__.py:30-56).
+
+    ``models_dir`` is ``$FLOWMOL_MODELS_DIR`` or ``flowmol_amd/trained_models``.  The reference downloads
+    missing models with wget; there is no network in this environment, so a missing directory is an error
+    that says where to put the files (``FlowMol.from_preset`` gives the same architecture with synthetic weights)."""
+    if model_name not in pretrained_model_names:
+        raise ValueError(f'Model {model_name} not found. Supported models: {pretrained_model_names}')
+    root = Path(os.environ.get('FLOWMOL_MODELS_DIR', PKG / 'trained_models'))
+    ckpt = root / model_name / 'checkpoints' / 'last.ckpt'
+    if not ckpt.exists():
+        raise FileNotFoundError(
+            f'{ckpt} not found. Download the model directory from https://bits.csb.pitt.edu/files/FlowMol/trained_models_v3.1/'
+            f'{model_name}/ into {root} (or set FLOWMOL_MODELS_DIR); this build has no network access and does not wget.')
+    kw = {}
+    if 'qm9' in model_name:
+        kw['n_atoms_hist'] = 'qm9'
+    return FlowMol.load_from_checkpoint(ckpt, **kw)

@@ -1,0 +1,148 @@
+"""``SampledMolecule``: the result object of ``FlowMol.sample*`` (drop-in for the fields of reference
+flowmol/analysis/molecule_builder.py:17-84,217-265 that do not need RDKit).
+
+The reference keeps float one-hots on a per-molecule DGL graph; here a molecule is a few index
+tensors, so trajectories cost bytes instead of megabytes.  ``rdkit_mol`` is
+built lazily and is ``None`` when RDKit is not installed (it is not, in this image).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+
+def pair_indices(n: int):
+    """(src, dst) of the unordered pairs in the reference's upper-edge order
+    (torch.triu_indices(n, n, 1), flowmol/data_processing/utils.py:4-17)."""
+    up = torch.triu_indices(n, n, offset=1)
+    return up[0], up[1]
+
+
+def extract_moldata(x, a_idx, c_idx, e_idx, atom_type_map: List[str], fake_atoms: bool, n_bond_types: int = 4,
+                    show_fake_atoms: bool = False):
+    """Tokens -> (positions, symbols, charges, bond_types, bond_src, bond_dst).
+
+    Semantics of reference extract_moldata_from_graph (molecule_builder.py:217-265): atoms whose type is
+    the fake-atom index (= len(atom_type_map), before the mask token) are removed and bonds re-indexed
+    (DGL remove_nodes); charge = index - 2; bond order 0 and the mask index mean "no bond"; only
+    upper-triangle bonds are kept."""
+    n = int(a_idx.shape[0])
+    amap = list(atom_type_map) + (['Sn'] if fake_atoms else []) + ['Se']      # molecule_builder.py:40-44
+    keep = torch.ones(n, dtype=torch.bool)
+    if fake_atoms and not show_fake_atoms:
+        keep = a_idx != len(atom_type_map)
+    new_id = torch.cumsum(keep.long(), 0) - 1
+    src, dst = pair_indices(n)
+    bt = e_idx.clone().long()
+    bt[bt == n_bond_types] = 0
+    ok = keep[src] & keep[dst] & (bt != 0)
+    symbols = [amap[int(i)] for i in a_idx[keep]]
+    return x[keep], symbols, c_idx[keep].long() - 2, bt[ok], new_id[src[ok]], new_id[dst[ok]]
+
+
+class SampledMolecule:
+    """One sampled molecule.  Fields follow the reference's SampledMolecule."""
+
+    def __init__(self, x_1: torch.Tensor, a_1: torch.Tensor, c_1: torch.Tensor, e_1: torch.Tensor,
+                 atom_type_map: List[str], fake_atoms: bool = False, ctmc_mol: bool = True,
+                 explicit_aromaticity: bool = False, traj_frames: Optional[Dict[str, torch.Tensor]] = None,
+                 build_xt_traj: bool = True, build_ep_traj: bool = True):
+        self.atom_type_map_in = list(atom_type_map)
+        self.fake_atoms = fake_atoms
+        self.ctmc_mol = ctmc_mol
+        self.explicit_aromaticity = explicit_aromaticity
+        self.n_bond_types = 5 if explicit_aromaticity else 4
+        # raw final state (tokens), kept like the reference keeps ``self.g``
+        self.x_1, self.a_1, self.c_1, self.e_1 = x_1, a_1.long(), c_1.long(), e_1.long()
+        (self.positions, self.atom_types, self.atom_charges, self.bond_types, self.bond_src_idxs,
+         self.bond_dst_idxs) = extract_moldata(x_1, self.a_1, self.c_1, self.e_1, atom_type_map, fake_atoms, self.n_bond_types)
+        self.atom_type_map = list(atom_type_map) + (['Sn'] if fake_atoms else []) + (['Se'] if ctmc_mol else [])
+        self.num_atom_types = len(self.atom_type_map)
+        self.num_atoms = int(x_1.shape[0])
+        if fake_atoms:
+            self.num_atoms -= int((self.a_1 == len(atom_type_map)).sum())
+        self.valencies = self.compute_valencies(arom_dependent=explicit_aromaticity)
+        self.traj_frames = traj_frames
+        self._rdkit_mol = False      # lazily built
+        self.build_xt_traj, self.build_ep_traj = build_xt_traj, build_ep_traj
+
+    def compute_valencies(self, arom_dependent: bool = False):
+        """molecule_builder.py:138-157."""
+        adj = torch.zeros((self.num_atoms, self.num_atoms)).float()
+        bt = self.bond_types.clone().float()
+        bt[bt == 4] = 1.5
+        adj[self.bond_src_idxs, self.bond_dst_idxs] = bt
+        adj[self.bond_dst_idxs, self.bond_src_idxs] = bt
+        val = torch.sum(adj, dim=-1)
+        if arom_dependent:
+            n_arom = (adj == 1.5).sum(dim=-1)
+            val = torch.stack([n_arom, (val - n_arom * 1.5).long()], dim=1)
+        return val
+
+    # ---------------------------------------------------------------- optional RDKit
+    @property
+    def rdkit_mol(self):
+        if self._rdkit_mol is False:
+            self._rdkit_mol = build_rdkit_mol(self.positions, self.atom_types, self.atom_charges, self.bond_src_idxs,
+                                              self.bond_dst_idxs, self.bond_types)
+        return self._rdkit_mol
+
+    def frame_moldata(self, frame_idx: int, ep_traj: bool = False):
+        """(positions, symbols, charges, bond_types, bond_src, bond_dst) of one trajectory frame, fake atoms
+        shown (molecule_builder.py:186-196).  Frames are token tensors: keys 'x','a','c','e' hold T frames
+        (frame 0 = prior) and 'x_1_pred','a_1_pred','c_1_pred','e_1_pred' hold T-1 frames."""
+        tf = self.traj_frames
+        sfx = '_1_pred' if ep_traj else ''
+        return extract_moldata(tf['x' + sfx][frame_idx], tf['a' + sfx][frame_idx].long(), tf['c' + sfx][frame_idx].long(),
+                               tf['e' + sfx][frame_idx].long(), self.atom_type_map_in, self.fake_atoms, self.n_bond_types,
+                               show_fake_atoms=True)
+
+    def to_sdf_block(self) -> str:
+        """V2000 mol block without RDKit (atoms, formal charges, bond orders)."""
+        return mol_block(self.positions, self.atom_types, self.atom_charges, self.bond_src_idxs, self.bond_dst_idxs, self.bond_types)
+
+
+def build_rdkit_mol(positions, atom_types, atom_charges, bond_src, bond_dst, bond_types):
+    try:
+        from rdkit import Chem
+        from rdkit.Geometry import Point3D
+    except Exception:
+        return None
+    bmap = [None, Chem.rdchem.BondType.SINGLE, Chem.rdchem.BondType.DOUBLE, Chem.rdchem.BondType.TRIPLE, Chem.rdchem.BondType.AROMATIC]
+    mol = Chem.RWMol()
+    for sym, ch in zip(atom_types, atom_charges):
+        at = Chem.Atom(sym)
+        if int(ch) != 0:
+            at.SetFormalCharge(int(ch))
+        mol.AddAtom(at)
+    for bt, s, d in zip(bond_types, bond_src, bond_dst):
+        mol.AddBond(int(s), int(d), bmap[int(bt)])
+    try:
+        mol = mol.GetMol()
+    except Exception:
+        return None
+    conf = Chem.Conformer(mol.GetNumAtoms())
+    for i in range(mol.GetNumAtoms()):
+        x, y, z = (float(v) for v in positions[i])
+        conf.SetAtomPosition(i, Point3D(x, y, z))
+    mol.AddConformer(conf)
+    return mol
+
+
+_CHG = {3: 1, 2: 2, 1: 3, -1: 5, -2: 6, -3: 7}
+
+
+def mol_block(positions, atom_types, atom_charges, bond_src, bond_dst, bond_types, name: str = 'flowmol_amd') -> str:
+    """MDL V2000 mol block (+ '$$$$' is the caller's job)."""
+    na, nb = len(atom_types), int(bond_types.shape[0])
+    lines = [name, '  flowmol_amd          3D', '', f'{na:3d}{nb:3d}  0  0  0  0  0  0  0  0999 V2000']
+    for i, sym in enumerate(atom_types):
+        x, y, z = (float(v) for v in positions[i])
+        chg = _CHG.get(int(atom_charges[i]), 0)
+        lines.append(f'{x:10.4f}{y:10.4f}{z:10.4f} {sym:<3s} 0{chg:3d}  0  0  0  0  0  0  0  0  0  0')
+    for k in range(nb):
+        bt = int(bond_types[k])
+        lines.append(f'{int(bond_src[k]) + 1:3d}{int(bond_dst[k]) + 1:3d}{bt:3d}  0')
+    lines.append('M  END')
+    return '\n'.join(lines) + '\n'

@@ -133,6 +133,10 @@ int fm_workspace_bytes(fm_ctx* ctx, const int32_t* n_atoms_host, int n_mols, siz
 /* bind a batch: builds the internal destination-sorted edge layout inside `workspace` */
 int fm_batch_bind(fm_ctx* ctx, void* stream, const int32_t* n_atoms_host, int n_mols, void* workspace, size_t bytes);
 
+/* x -= per-molecule mean, in place, for the bound batch: the centring step of the position prior
+ * (centered_normal_prior_batched_graph, flowmol/data_processing/priors.py:27-35) */
+int fm_remove_com(fm_ctx* ctx, void* stream, float* x);
+
 /* one network evaluation.  temb: device (time_embedding_dim) floats (raw t when dim == 1).
  * prev: previous endpoint for self-conditioning or NULL.  bootstrap != 0 reproduces the reference's
  * first-step behaviour (vector_field.py:269-282): an extra evaluation with remove_com=False whose

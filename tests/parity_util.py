@@ -1,0 +1,130 @@
+"""Shared helpers of the parity tests: run the engine (HIP on the GPU box, or the host emulation in
+tests/test_emu_parity.py) and the CPU oracle on the same seeded inputs and compare stage by stage."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+
+
+def rand_tokens(n, k, frac_masked, gen):
+    t = torch.randint(0, k, (n,), generator=gen)
+    t[torch.rand(n, generator=gen) < frac_masked] = k
+    return t
+
+
+def onehots(cfg, batch, a, c, eu):
+    m = batch.upper_edge_mask
+    e = torch.zeros(batch.E, cfg.n_bond_types + 1)
+    e[m] = F.one_hot(eu, cfg.n_bond_types + 1).float()
+    e[~m] = F.one_hot(eu, cfg.n_bond_types + 1).float()
+    return F.one_hot(a, cfg.n_atom_types + 1).float(), F.one_hot(c, cfg.n_charges + 1).float(), e
+
+
+def edge_perm(eng, batch):
+    """internal (destination-major) edge index -> reference edge index"""
+    e_src, e_dst = eng.query('e_src').cpu().long(), eng.query('e_dst').cpu().long()
+    N = batch.N
+    ref = torch.full((N * N,), -1, dtype=torch.int64)
+    ref[batch.src * N + batch.dst] = torch.arange(batch.E)
+    perm = ref[e_src * N + e_dst]
+    assert (perm >= 0).all()
+    return perm
+
+
+def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_masked=0.4, taps=True):
+    """Returns {stage: relative error (max abs diff / max abs ref)} for every tap and the outputs."""
+    dev = eng.device
+    batch = cpu_ref.build_batch(n_atoms)
+    eng.bind(n_atoms)
+    gen = torch.Generator().manual_seed(seed)
+    N, U, E = eng.N, eng.U, eng.E
+    a = rand_tokens(N, cfg.n_atom_types, frac_masked, gen)
+    c = rand_tokens(N, cfg.n_charges, frac_masked, gen)
+    eu = rand_tokens(U, cfg.n_bond_types, frac_masked, gen)
+    x = torch.randn(N, 3, generator=gen) * 1.5
+    prev = None
+    if with_prev and cfg.self_conditioning:
+        prev = {'x': x + 0.3 * torch.randn(N, 3, generator=gen),
+                'a': torch.softmax(torch.randn(N, cfg.n_atom_types, generator=gen), -1),
+                'c': torch.softmax(torch.randn(N, cfg.n_charges, generator=gen), -1),
+                'e': torch.softmax(torch.randn(U, cfg.n_bond_types, generator=gen), -1)}
+    a1h, c1h, e1h = onehots(cfg, batch, a, c, eu)
+    orc.taps = {}
+    with torch.no_grad():
+        ref = orc.forward(batch, x, a1h, c1h, e1h, torch.full((batch.B,), float(t_val)), prev=prev, apply_softmax=True, remove_com=True)
+    taps_o, orc.taps = orc.taps, None
+    state = eng.make_state(x, a, c, eu)
+    V = cfg.n_vec_channels
+    bufs = {}
+    if taps:
+        for i in range(cfg.n_convs):
+            bufs[f'conv{i}.s'] = torch.zeros(N, 256, device=dev)
+            bufs[f'conv{i}.v'] = torch.zeros(N, 3, V, device=dev)
+            bufs[f'conv{i}.agg.s'] = torch.zeros(N, 256, device=dev)
+            bufs[f'conv{i}.agg.v'] = torch.zeros(N, 3, V, device=dev)
+            if cfg.update_schedule()[i] >= 0:
+                bufs[f'upd{i}.x'] = torch.zeros(N, 3, device=dev)
+                bufs[f'upd{i}.ef'] = torch.zeros(E, 128, device=dev)
+        first = 'sc' if prev is not None else 'embed'
+        bufs[f'{first}.s'] = torch.zeros(N, 256, device=dev)
+        bufs[f'{first}.ef'] = torch.zeros(E, 128, device=dev)
+        bufs['conv0.msg.s'] = torch.zeros(E, 256, device=dev)
+        bufs['conv0.msg.v'] = torch.zeros(E, 3, V, device=dev)
+    prev_d = {k: v.to(dev).contiguous() for k, v in prev.items()} if prev is not None else None
+    bootstrap = (t_val == 0) and prev is None
+    out = eng.forward(state, t_val, prev=prev_d, bootstrap=bootstrap, remove_com=True, taps=bufs)
+    eng.synchronize()
+    perm = edge_perm(eng, batch) if taps else None
+    errs = {}
+
+    def rel(got, want):
+        got = got.detach().cpu()
+        if torch.isnan(got).any():
+            return float('nan')
+        return float((got - want).abs().max() / want.abs().max().clamp(min=1e-20))
+    for k, v in bufs.items():
+        if k.endswith('.msg.s'):
+            want = taps_o['conv0.msg2.s'][perm]
+        elif k.endswith('.msg.v'):
+            want = taps_o['conv0.msg2.v'][perm].transpose(1, 2)
+        elif k.endswith('.ef'):
+            want = taps_o[k][perm]
+        elif k.endswith('.v'):
+            want = taps_o[k].transpose(1, 2)
+        else:
+            want = taps_o[k]
+        errs[k] = rel(v, want)
+    for k in 'xace':
+        errs['out.' + k] = rel(out[k], ref[k])
+    return errs, out, ref
+
+
+def integrate_golden(eng, cfg, g, chunk=8, device=None):
+    """Free-running trajectory on the engine with the reference's recorded noise (golden fixture g)."""
+    from flowmol_amd.engine import StepNoise, make_step_plan
+    device = device or eng.device
+    eng.bind(g['n_atoms'])
+    T = int(g['T'])
+    tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    state = eng.prior_state(g['x_0'])
+    pos = [0]
+
+    def noise_for_step(i, last):
+        nz, pos[0] = StepNoise.from_tape(tape, pos[0], last, device)
+        return nz
+    traj = {'x': torch.zeros(T - 1, eng.N, 3, device=device), 'a': torch.zeros(T - 1, eng.N, dtype=torch.int32, device=device)}
+    eng.integrate(state, plan, noise_for_step, chunk=chunk, traj=traj)
+    assert pos[0] == len(tape)
+    res = {
+        'a_flips': int((state['a_t'].cpu().long() != g['a_1']).sum()),
+        'c_flips': int((state['c_t'].cpu().long() != g['c_1']).sum()),
+        'e_flips': int((state['e_t'].cpu().long() != g['e_1_upper']).sum()),
+        'x_rel': float((state['x_t'].cpu() - g['x_1']).abs().max() / g['x_1'].abs().max()),
+    }
+    n0 = int(g['n_atoms'][0])
+    res['traj0_x_rel'] = float((traj['x'][:, :n0].cpu() - g['traj0.x'][1:]).abs().max() / g['traj0.x'].abs().max())
+    res['traj0_a_flips'] = int((traj['a'][:, :n0].cpu().long() != g['traj0.a'][1:]).sum())
+    return res, state

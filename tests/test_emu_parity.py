@@ -1,0 +1,62 @@
+"""CPU-side parity of the HIP kernels through the host emulation (tests/emu): the SAME kernel and host
+sources compiled with the host clang++ and executed lane-by-lane on the CPU.  This debugs index math, LDS
+layouts, MFMA fragment maps and weight packing without a GPU; the real parity gate is tests/test_gpu_parity.py."""
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from flowmol_amd import _lib, presets, weights
+from oracle import cpu_ref
+from parity_util import forward_compare
+
+HERE = Path(__file__).resolve().parent
+EMU = HERE / 'emu' / 'libflowmol_emu.so'
+
+
+@pytest.fixture(scope='module')
+def emu_lib():
+    cxx = '/opt/rocm/lib/llvm/bin/clang++'
+    if not Path(cxx).exists() and not shutil.which('clang++'):
+        pytest.skip('no clang++ to build the host emulation')
+    srcs = [HERE / 'emu' / 'emu_rt.cpp', HERE / 'emu' / 'hip' / 'hip_runtime.h'] + sorted((HERE.parent / 'flowmol_amd' / 'csrc').glob('*'))
+    if not EMU.exists() or any(s.stat().st_mtime > EMU.stat().st_mtime for s in srcs):
+        subprocess.run([str(HERE / 'emu' / 'build_emu.sh')], check=True, capture_output=True)
+    return _lib.load(EMU)
+
+
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False)])
+def test_emulated_forward_matches_oracle(emu_lib, name, sizes, t, prev):
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+    orc = cpu_ref.OracleVF(cfg, sd)
+    errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev)
+    bad = {k: v for k, v in errs.items() if not v < 2e-5}
+    assert not bad, bad
+
+
+def test_emulated_sample_api_short_trajectory(emu_lib):
+    """The public API end to end on the emulation: prior, 3 steps incl. bootstrap, packaging."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu_lib)
+    torch.manual_seed(0)
+    mols = model.sample(torch.tensor([4, 3]), n_timesteps=3, device='cpu')
+    assert len(mols) == 2 and mols[0].positions.shape[1] == 3
+    assert all('Se' not in m.atom_types for m in mols)
+    # same seed on the oracle: identical RNG stream -> identical categorical outcome
+    cfg = model.cfg
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    batch = cpu_ref.build_batch(torch.tensor([4, 3]))
+    torch.manual_seed(0)
+    prior = orc.sample_prior(batch)
+    with torch.no_grad():
+        ref = orc.integrate(batch, prior, 3)
+    got_a = torch.cat([m.a_1 for m in mols])
+    assert torch.equal(got_a, ref['a_1'].argmax(-1))
+    got_x = torch.cat([m.x_1 for m in mols])
+    assert torch.allclose(got_x, ref['x_1'], atol=1e-5)

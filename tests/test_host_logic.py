@@ -1,0 +1,150 @@
+"""Host-side logic (no GPU): configs, step scalars, result extraction, checkpoint reader, sharding."""
+import math
+
+import pytest
+import torch
+
+from flowmol_amd import presets, weights
+from flowmol_amd.config import VFConfig, from_reference_hparams
+from flowmol_amd.engine import StepNoise, make_step_plan, time_embedding_host
+from flowmol_amd.model import FlowMol, load_pretrained, read_checkpoint
+from flowmol_amd.molecule import SampledMolecule, extract_moldata, mol_block
+from flowmol_amd.shard import pack_results, partition_lpt, unpack_results
+from oracle import cpu_ref
+
+
+def test_param_counts_match_survey_appendix_a():
+    assert weights.n_params(presets.flowmol3()) == 5854185
+    assert weights.n_params(presets.geom_ctmc()) == 4288922
+
+
+def test_update_schedule_quirk():
+    # convs_per_update=1: no update after conv 0, updater index = conv index (updater 0 dead) -- SURVEY Appendix C.2
+    assert presets.flowmol3().update_schedule() == [-1, 1, 2, 3, 4, 5]
+    assert presets.geom_ctmc().update_schedule() == [-1, 1, 2, 3, 4]
+    c = VFConfig(n_molecule_updates=2, convs_per_update=2, separate_mol_updaters=False)
+    assert c.update_schedule() == [-1, 0, -1, 0]
+
+
+def test_unsupported_configs_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        VFConfig(use_dst_feats=True).validate()
+    with pytest.raises(NotImplementedError):
+        VFConfig(n_hidden_scalars=64).validate()
+    with pytest.raises(NotImplementedError):
+        VFConfig(message_norm='mean').validate()
+
+
+@pytest.mark.parametrize('eta,hc,T', [(30.0, 0.9, 250), (10.0, 0.0, 20), (0.0, 0.9, 7)])
+def test_step_plan_matches_oracle_arithmetic(eta, hc, T):
+    plan = make_step_plan(T, eta, hc, 0.05)
+    t = torch.linspace(0, 1, T)
+    al, alp = cpu_ref.alpha_tables(t)
+    assert len(plan.scalars) == T - 1
+    for s_idx in (1, T // 2, T - 1):
+        sc = plan.scalars[s_idx - 1]
+        dt = t[s_idx] - t[s_idx - 1]
+        a_i, ap_i = al[s_idx - 1], alp[s_idx - 1]
+        assert sc.t == float(t[s_idx - 1]) and sc.dt == float(dt)
+        assert sc.x_coef == float(ap_i[0] / (1 - a_i[0]))
+        assert sc.unmask_prob[1] == float(torch.clamp(dt * (ap_i[1] + eta * a_i[1]) / (1 - a_i[1]), min=0, max=1))
+        assert sc.mask_prob[2] == float(torch.clamp(dt * eta, min=0, max=1))
+        assert bool(sc.last_step) == (s_idx == T - 1)
+    assert plan.scalars[-1].unmask_prob[0] == 1.0        # last step resolves every mask token (Appendix C.7)
+
+
+def test_time_embedding_host_matches_oracle():
+    for t in (0.0, 0.004016064, 0.5, 1.0):
+        a = time_embedding_host(t, 64)
+        b = cpu_ref.time_embedding(torch.tensor([t], dtype=torch.float32), 64)[0]
+        assert torch.equal(a, b)
+    assert torch.equal(time_embedding_host(0.25, 1), torch.tensor([0.25]))
+
+
+def test_step_noise_draw_order_matches_reference_rng_stream():
+    N, U, na, nc, ne = 7, 21, 11, 6, 4
+    torch.manual_seed(3)
+    nz = StepNoise.draw(N, U, na, nc, ne, False, 'cpu')
+    torch.manual_seed(3)
+    rec = cpu_ref.TorchNoise()
+    for tag, rows, k in (('a', N, na), ('c', N, nc), ('e', U, ne)):
+        assert torch.equal(getattr(nz, f'q_{tag}'), rec.exp_like(torch.empty(rows, k)))
+        assert torch.equal(getattr(nz, f'u1_{tag}'), rec.rand(rows, 'cpu'))
+        assert torch.equal(getattr(nz, f'u2_{tag}'), rec.rand(rows, 'cpu'))
+
+
+def test_extract_moldata_matches_oracle_restatement():
+    gen = torch.Generator().manual_seed(0)
+    n = 9
+    amap = presets.GEOM_ATOMS
+    a = torch.randint(0, 11, (n,), generator=gen)
+    a[2] = 10                      # a fake atom
+    c = torch.randint(0, 6, (n,), generator=gen)
+    u = n * (n - 1) // 2
+    e = torch.randint(0, 5, (u,), generator=gen)
+    x = torch.randn(n, 3, generator=gen)
+    got = extract_moldata(x, a, c, e, amap, True)
+    import torch.nn.functional as F
+    e1h = torch.cat([F.one_hot(e, 5), F.one_hot(e, 5)]).float()
+    want = cpu_ref.extract_moldata(x, F.one_hot(a, 12).float(), F.one_hot(c, 7).float(), e1h, n, amap, True)
+    assert torch.equal(got[0], want[0]) and got[1] == want[1] and torch.equal(got[2], want[2])
+    assert torch.equal(got[3], want[3]) and torch.equal(got[4], want[4]) and torch.equal(got[5], want[5])
+    m = SampledMolecule(x, a, c, e, amap, fake_atoms=True)
+    assert m.num_atoms == n - int((a == 10).sum()) == len(m.atom_types)
+    assert m.valencies.shape == (m.num_atoms,)
+    blk = mol_block(m.positions, m.atom_types, m.atom_charges, m.bond_src_idxs, m.bond_dst_idxs, m.bond_types)
+    assert blk.splitlines()[3].startswith(f'{m.num_atoms:3d}{m.bond_types.shape[0]:3d}') and blk.rstrip().endswith('M  END')
+    assert m.rdkit_mol is None or m.rdkit_mol.GetNumAtoms() == m.num_atoms
+
+
+def test_checkpoint_reader_roundtrip(tmp_path):
+    cfg = presets.flowmol3()
+    sd = {'vector_field.' + k: v for k, v in weights.synth_state_dict(cfg, 0).items()}
+    hp = {'atom_type_map': presets.GEOM_ATOMS, 'n_atoms_hist_file': 'data/geom_full_kekulized/train_data_n_atoms_histogram.pt',
+          'marginal_dists_file': 'x', 'n_atom_charges': 6, 'parameterization': 'ctmc', 'fake_atom_p': 0.3, 'default_n_timesteps': 250,
+          'prior_config': {k: {'type': 'ctmc'} for k in 'ace'},
+          'vector_field_config': dict(self_conditioning=True, stochasticity=30.0, high_confidence_threshold=0.9, n_vec_channels=32,
+                                      update_edge_w_distance=True, n_hidden_scalars=256, n_hidden_edge_feats=128, s_message_dim=None,
+                                      v_message_dim=None, n_expansion_gvps=3, attention=False, n_heads=32, n_recycles=1,
+                                      separate_mol_updaters=True, n_molecule_updates=6, convs_per_update=1, n_cp_feats=4, n_message_gvps=3,
+                                      n_update_gvps=3, message_norm='sum', rbf_dmax=10, rbf_dim=32, time_embedding_dim=64, a_token_dim=64,
+                                      c_token_dim=64, e_token_dim=64)}
+    d = tmp_path / 'flowmol3' / 'checkpoints'
+    d.mkdir(parents=True)
+    torch.save({'state_dict': sd, 'hyper_parameters': hp}, d / 'last.ckpt')
+    hp2, sd2 = read_checkpoint(d / 'last.ckpt')
+    cfg2 = from_reference_hparams(hp2)
+    assert cfg2.to_dict() == cfg.to_dict()
+    model = FlowMol.load_from_checkpoint(d / 'last.ckpt')
+    assert model.n_atom_types == 11 and model.default_n_timesteps == 250
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        model.sample(torch.tensor([3]))            # no silent CPU path
+    with pytest.raises(FileNotFoundError):
+        load_pretrained('flowmol3')
+    with pytest.raises(ValueError):
+        load_pretrained('not-a-model')
+
+
+def test_n_atoms_distribution():
+    m = FlowMol.from_preset('qm9')
+    torch.manual_seed(0)
+    n = m.sample_n_atoms(1000)
+    assert n.min() >= 3 and n.max() <= 29 and abs(float(n.float().mean()) - 18.0) < 0.5
+    g = FlowMol.from_preset('flowmol3')
+    n = g.sample_n_atoms(2000)
+    assert n.min() >= 3 and n.max() <= 181 and abs(float(n.float().mean()) - 46.9) < 1.5
+
+
+def test_lpt_partition_and_packing():
+    torch.manual_seed(0)
+    n = torch.randint(5, 90, (37,))
+    parts = partition_lpt(n, 8)
+    allidx = torch.cat(parts).sort().values
+    assert torch.equal(allidx, torch.arange(37))
+    cost = (n * (n - 1)).float()
+    loads = torch.tensor([float(cost[p].sum()) for p in parts])
+    assert loads.max() / loads.mean() < 1.25
+    N, U = 11, 20
+    x = torch.randn(N, 3); a = torch.randint(0, 12, (N,)); c = torch.randint(0, 7, (N,)); e = torch.randint(0, 5, (U,))
+    got = unpack_results(pack_results(x, a, c, e), N, U)
+    assert torch.equal(got['x'], x) and torch.equal(got['a'].long(), a) and torch.equal(got['e'].long(), e)
