@@ -51,11 +51,10 @@ def network_flops(n, V=32):
     return 4.8744e6 * n * (n - 1) + 6.50e6 * n
 
 
-def cpu_baseline(cfg, sd, n_atoms_each, B, steps, T):
-    """Time the CPU oracle (the op-for-op restatement of the reference's PyTorch path, oracle/cpu_ref.py)
-    on this box's host cores on a bounded sample of the same workload."""
+def _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, threads):
+    """Warm-up step (with the bootstrap evaluation) + `steps` timed integration steps of the CPU oracle."""
     from oracle import cpu_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     n_atoms = torch.full((B,), n_atoms_each, dtype=torch.int64)
     batch = cpu_ref.build_batch(n_atoms)
     orc = cpu_ref.OracleVF(cfg, sd)
@@ -68,17 +67,32 @@ def cpu_baseline(cfg, sd, n_atoms_each, B, steps, T):
     dst = None
     times = []
     with torch.no_grad():
-        for s_idx in range(1, steps + 2):            # first step (with bootstrap) is warm-up
+        for s_idx in range(1, steps + 2):
             t0 = time.perf_counter()
             new, dst = orc.step(batch, state, t[s_idx], t[s_idx - 1], alpha_t[s_idx - 1], alpha_tp[s_idx - 1], prev=dst,
                                 eta=cfg.stochasticity, hc_thresh=cfg.high_confidence_threshold, last_step=False, noise=noise)
             state = {k: new[k] for k in ('x_t', 'a_t', 'c_t', 'e_t')}
             times.append(time.perf_counter() - t0)
-    per_step = sum(times[1:]) / len(times[1:])
-    return {'value': B / (T * per_step), 'unit': 'molecules/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return sum(times[1:]) / len(times[1:])
+
+
+def cpu_baseline(cfg, sd, n_atoms_each, B, steps, T):
+    """Time the CPU oracle (the op-for-op restatement of the reference's PyTorch path, oracle/cpu_ref.py) on this
+    box's host cores on a bounded sample of the same workload.  The intra-op thread count is chosen by a short
+    probe (2 molecules, 1 step per candidate): torch with one thread per logical CPU of a many-core host
+    oversubscribes these small operators badly, which would make the baseline look worse than it is."""
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 128) if c <= ncpu} | ({ncpu} if ncpu < 8 else set()))
+    probe = {}
+    for c in cands:
+        probe[c] = _cpu_steps(cfg, sd, n_atoms_each, 2, 1, T, c)
+    best = min(probe, key=probe.get)
+    per_step = _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, best)
+    return {'value': B / (T * per_step), 'unit': 'molecules/s', 'cores': best, 'kind': 'port',
             'sample': f'{B} molecules x {n_atoms_each} atoms, {steps} timed integration steps after 1 warm-up step '
-                      f'({per_step * 1e3:.0f} ms/step), extrapolated linearly to {T} network evaluations per sample',
-            'ms_per_step': per_step * 1e3}
+                      f'({per_step * 1e3:.0f} ms/step) with {best} torch threads (best of {cands} in a 2-molecule probe; host has '
+                      f'{ncpu} logical CPUs), extrapolated linearly to {T} network evaluations per sample',
+            'ms_per_step': per_step * 1e3, 'thread_probe_ms_per_step': {str(k): v * 1e3 for k, v in probe.items()}}
 
 
 def main():
@@ -91,8 +105,8 @@ def main():
     ap.add_argument('--timesteps', type=int, default=250)
     ap.add_argument('--preset', default='flowmol3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-mols', type=int, default=16)
-    ap.add_argument('--cpu-steps', type=int, default=4)
+    ap.add_argument('--cpu-mols', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -31,6 +31,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float fm_silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float fm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Correctly rounded, never-contracted f32 operations for the few places whose results must equal the
+// reference's separately rounded torch ops bit for bit (Euler step, purity-sampling probabilities).
+// HIP's __fmul_rn & co. are plain operators that hipcc's default -ffp-contract=fast may fuse into FMAs.
+__device__ __forceinline__ float fm_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float fm_add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float fm_sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float fm_div_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 // Gaussian RBF, reference flowmol/utils/embedding.py:19-34: mu_k = k*Dmax/(R-1), sigma = Dmax/R
 __device__ __forceinline__ float fm_rbf(float d, int k, float mu_step, float inv_sigma) {
     float z = (d - (float)k * mu_step) * inv_sigma;

@@ -655,8 +655,8 @@ __global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, con
 __global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, const float* __restrict__ x1, float coef, float dt, int n3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n3) {
-        const float vf = __fmul_rn(coef, __fsub_rn(x1[i], x_t[i]));
-        x_t[i] = __fadd_rn(x_t[i], __fmul_rn(dt, vf));
+        const float vf = fm_mul_rn(coef, fm_sub_rn(x1[i], x_t[i]));
+        x_t[i] = fm_add_rn(x_t[i], fm_mul_rn(dt, vf));
     }
 }
 
@@ -687,14 +687,14 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_pass1(FmCtmcArgs a) {
     if (i >= a.rows) return;
     float lp[16];
     float mx = -INFINITY;
-    for (int k = 0; k < a.K; ++k) { lp[k] = __fdiv_rn(logf(a.p[(size_t)i * a.K + k]), a.inv_temp_div); mx = fmaxf(mx, lp[k]); }
+    for (int k = 0; k < a.K; ++k) { lp[k] = fm_div_rn(logf(a.p[(size_t)i * a.K + k]), a.inv_temp_div); mx = fmaxf(mx, lp[k]); }
     float sum = 0.f;
-    for (int k = 0; k < a.K; ++k) { lp[k] = expf(__fsub_rn(lp[k], mx)); sum = __fadd_rn(sum, lp[k]); }
+    for (int k = 0; k < a.K; ++k) { lp[k] = expf(fm_sub_rn(lp[k], mx)); sum = fm_add_rn(sum, lp[k]); }
     float purity = 0.f, psum = 0.f;
-    for (int k = 0; k < a.K; ++k) { lp[k] = __fdiv_rn(lp[k], sum); purity = fmaxf(purity, lp[k]); psum = __fadd_rn(psum, lp[k]); }
+    for (int k = 0; k < a.K; ++k) { lp[k] = fm_div_rn(lp[k], sum); purity = fmaxf(purity, lp[k]); psum = fm_add_rn(psum, lp[k]); }
     int best = 0; float bestv = -1.f;
     for (int k = 0; k < a.K; ++k) {
-        const float v = __fdiv_rn(__fdiv_rn(lp[k], psum), a.q[(size_t)i * a.K + k]);
+        const float v = fm_div_rn(fm_div_rn(lp[k], psum), a.q[(size_t)i * a.K + k]);
         if (v > bestv) { bestv = v; best = k; }
     }
     a.x1[i] = best;
@@ -719,11 +719,11 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_pass2(FmCtmcArgs a) {
             const int mol = a.row_mol[i];
             const float m = (float)a.cnt_m[mol], h = (float)a.cnt_h[mol];
             // ph = min(unmask_prob*m/h, 1) (inf when h == 0); pl = (unmask_prob*m - ph*h)/(m-h)
-            const float um = __fmul_rn(a.unmask_prob, m);
-            float ph = (a.cnt_h[mol] == 0) ? INFINITY : __fdiv_rn(um, h);
+            const float um = fm_mul_rn(a.unmask_prob, m);
+            float ph = (a.cnt_h[mol] == 0) ? INFINITY : fm_div_rn(um, h);
             ph = fminf(ph, 1.0f);
             if (a.hc_flag[i]) prob = ph;
-            else prob = __fdiv_rn(__fsub_rn(um, __fmul_rn(ph, h)), __fsub_rn(m, h));
+            else prob = fm_div_rn(fm_sub_rn(um, fm_mul_rn(ph, h)), fm_sub_rn(m, h));
         }
         will_unmask = a.u1[i] < prob;           // comparisons against NaN are false, as in torch
     } else {

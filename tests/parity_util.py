@@ -67,7 +67,8 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
             if cfg.update_schedule()[i] >= 0:
                 bufs[f'upd{i}.x'] = torch.zeros(N, 3, device=dev)
                 bufs[f'upd{i}.ef'] = torch.zeros(E, 128, device=dev)
-        first = 'sc' if prev is not None else 'embed'
+        bootstrap_ = (t_val == 0) and prev is None and cfg.self_conditioning
+        first = 'sc' if (prev is not None or bootstrap_) else 'embed'   # the bootstrap result feeds the SC layer
         bufs[f'{first}.s'] = torch.zeros(N, 256, device=dev)
         bufs[f'{first}.ef'] = torch.zeros(E, 128, device=dev)
         bufs['conv0.msg.s'] = torch.zeros(E, 256, device=dev)
