@@ -67,26 +67,47 @@ __device__ __forceinline__ float fm_norm3(float dx, float dy, float dz) {
 // wave-level GEMM: acc[MT][NT] += A(lds rows m0.., K) * Wp(cols of tiles nt0..nt0+NT-1)
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT>
+__device__ __forceinline__ void fm_frag_load(float2 (&a)[MT], float2 (&b)[NT], const float* ap, int lda,
+                                             const float2* __restrict__ wp, size_t wstep, int ks) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(ap + mt * 16 * lda + 8 * ks);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = wp[(size_t)ks * wstep + (size_t)nt * 64];
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void fm_frag_mma(f32x4 (&acc)[MT][NT], const float2 (&a)[MT], const float2 (&b)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+}
+
+// Software-pipelined over k-supersteps: the A (LDS) and B (L2) fragments of step ks+1 are requested
+// before the MFMAs of step ks are issued, so one wave covers its own load latency (only 2 waves share
+// a SIMD).  Two named register sets, manually unrolled by 2 (no runtime-indexed register arrays).
+template <int MT, int NT>
 __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* A, int lda, int K8,
                                              const float2* __restrict__ Wp, int ntiles, int nt0, int lane) {
     const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
     const float2* wp = Wp + (size_t)nt0 * 64 + lane;
     const size_t wstep = (size_t)ntiles * 64;
-#pragma unroll 2
-    for (int ks = 0; ks < K8; ++ks) {
-        float2 a[MT], b[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(ap + mt * 16 * lda + 8 * ks);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = wp[(size_t)ks * wstep + (size_t)nt * 64];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-            }
+    float2 a0[MT], b0[NT], a1[MT], b1[NT];
+    fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, 0);
+    int ks = 0;
+    for (; ks + 2 <= K8; ks += 2) {
+        fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 1);
+        fm_frag_mma<MT, NT>(acc, a0, b0);
+        if (ks + 2 < K8) fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, ks + 2);
+        fm_frag_mma<MT, NT>(acc, a1, b1);
     }
+    if (ks < K8) fm_frag_mma<MT, NT>(acc, a0, b0);
 }
 
 // block-level GEMM over an (mtiles x ntiles) grid of 16x16 output tiles: super-tiles of MT x NT tiles
