@@ -22,14 +22,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define FM_TM 64          // rows per workgroup tile
+#define FM_TM 64          // rows per workgroup tile of the non-GVP kernels (MLPs, edge update, projections)
 #define FM_THREADS 512    // 8 waves
 #define FM_WAVES 8
 #define FM_LDX 300        // scalar tile leading dim: >= 296, (300/4)=75 odd
 #define FM_LDG 33         // gate tile leading dim
 
-__device__ __forceinline__ float fm_silu(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float fm_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// SiLU / sigmoid on the hardware transcendental path: v_exp_f32 (2^x) and v_rcp_f32, ~1 ulp each.  Measured on
+// MI355X (profiles/r01b_ab.jsonl): -8 % on the edge-message kernel vs expf + IEEE division, with unchanged parity
+// (per-evaluation output error vs the CPU oracle 3-5e-7 either way).
+__device__ __forceinline__ float fm_exp_neg(float x) { return __builtin_amdgcn_exp2f(x * -1.44269504088896341f); }
+__device__ __forceinline__ float fm_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fm_exp_neg(x)); }
+__device__ __forceinline__ float fm_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fm_exp_neg(x)); }
 
 // Correctly rounded, never-contracted f32 operations for the few places whose results must equal the
 // reference's separately rounded torch ops bit for bit (Euler step, purity-sampling probabilities).
@@ -148,16 +152,18 @@ struct FmGvpW {
     const float* bg;     // (VOUT padded)
 };
 
-// LDS tile geometry shared by every GVP-based kernel
-template <int V>
+// LDS tile geometry shared by every GVP-based kernel; TM = rows (edges or nodes) per workgroup tile:
+// 64 -> 154 KB of LDS, one workgroup per CU; 32 -> 77 KB, two workgroups per CU whose MFMA and
+// VALU/LDS/gather phases overlap each other.
+template <int V, int TM>
 struct FmGvpTile {
     static constexpr int LDVI = V + 4;       // Vin  [3*TM][LDVI]   (36 | 20: /4 odd)
     static constexpr int LDVH = V + 20;      // Vh   [3*TM][LDVH]   (52 | 36: /4 odd)
     static constexpr int KU = V + 8;         // K of the Wu GEMM    (hidden h + 4 cp (+pad) <= V+8)
-    static constexpr int X_FLOATS = FM_TM * FM_LDX;
-    static constexpr int VIN_FLOATS = 3 * FM_TM * LDVI;
-    static constexpr int VH_FLOATS = 3 * FM_TM * LDVH;
-    static constexpr int G_FLOATS = FM_TM * FM_LDG;
+    static constexpr int X_FLOATS = TM * FM_LDX;
+    static constexpr int VIN_FLOATS = 3 * TM * LDVI;
+    static constexpr int VH_FLOATS = 3 * TM * LDVH;
+    static constexpr int G_FLOATS = TM * FM_LDG;
     static constexpr int TOTAL_FLOATS = X_FLOATS + VIN_FLOATS + VH_FLOATS + G_FLOATS;
 };
 
@@ -168,10 +174,11 @@ struct FmGvpTile {
 // State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
 // `addend`/`arows` (optional): per-row gather added before the SiLU (the hoisted W_s * s[src] term).
 // All 512 threads must call it (it contains barriers); it ends with a barrier.
-template <int V, int VOUT, bool FIRST, bool SIGMOID>
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             const float* __restrict__ addend, const int* arows) {
-    typedef FmGvpTile<V> T;
+    typedef FmGvpTile<V, TM> T;
+    constexpr int MT = TM / 16;                          // row tiles of the scalar GEMM
     constexpr int H = FIRST ? V + 1 : V;                 // hidden vector channels
     constexpr int SOFF = FIRST ? 160 : 256;              // where sh goes in X
     constexpr int K8S = (SOFF + V + 8) / 8;
@@ -181,98 +188,114 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 
     if (!FIRST) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
-        fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * FM_TM / 16, V / 8, w.Wv1, (V + 16) / 16,
+        fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * TM / 16, V / 8, w.Wv1, (V + 16) / 16,
                             [&](int row, int col, float v) { Vh[row * T::LDVH + col] = v; });
         __syncthreads();
     }
     // cross products cp_p = a_p x b_p, (a,b) = Vcp[0..3], Vcp[4..7]  (gvp.py:105-112); written at
     // columns H..H+3.  Each thread touches only its own columns, so no barrier is needed inside.
-    if (tid < FM_TM * 4) {
+    if (tid < TM * 4) {
         const int r = tid >> 2, p = tid & 3;
         float a[3], b[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            a[c] = Vh[(c * FM_TM + r) * T::LDVH + CPSRC + p];
-            b[c] = Vh[(c * FM_TM + r) * T::LDVH + CPSRC + 4 + p];
+            a[c] = Vh[(c * TM + r) * T::LDVH + CPSRC + p];
+            b[c] = Vh[(c * TM + r) * T::LDVH + CPSRC + 4 + p];
         }
         const float cx = a[1] * b[2] - a[2] * b[1];
         const float cy = a[2] * b[0] - a[0] * b[2];
         const float cz = a[0] * b[1] - a[1] * b[0];
         if (!FIRST) {   // the b-channels sit inside the K range of the Wu GEMM: clear them
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Vh[(c * FM_TM + r) * T::LDVH + V + 4 + p] = 0.f;
+            for (int c = 0; c < 3; ++c) Vh[(c * TM + r) * T::LDVH + V + 4 + p] = 0.f;
         }
-        Vh[(0 * FM_TM + r) * T::LDVH + H + p] = cx;
-        Vh[(1 * FM_TM + r) * T::LDVH + H + p] = cy;
-        Vh[(2 * FM_TM + r) * T::LDVH + H + p] = cz;
+        Vh[(0 * TM + r) * T::LDVH + H + p] = cx;
+        Vh[(1 * TM + r) * T::LDVH + H + p] = cy;
+        Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
     }
     __syncthreads();
     // sh = |Vh_full| per channel with the reference's clamp (gvp.py:116, _norm_no_nan) -> X[:, SOFF..]
-    for (int idx = tid; idx < FM_TM * (V + 8); idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * (V + 8); idx += FM_THREADS) {
         const int r = idx / (V + 8), c = idx % (V + 8);
         float val = 0.f;
         if (c < H + 4) {
-            const float vx = Vh[(0 * FM_TM + r) * T::LDVH + c];
-            const float vy = Vh[(1 * FM_TM + r) * T::LDVH + c];
-            const float vz = Vh[(2 * FM_TM + r) * T::LDVH + c];
+            const float vx = Vh[(0 * TM + r) * T::LDVH + c];
+            const float vy = Vh[(1 * TM + r) * T::LDVH + c];
+            const float vz = Vh[(2 * TM + r) * T::LDVH + c];
             val = fm_norm3(vx, vy, vz);
         }
         X[r * FM_LDX + SOFF + c] = val;
     }
     __syncthreads();
     // Vu = Vh_full * Wu -> Vin (the input vectors are dead by now)
-    fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * FM_TM / 16, T::KU / 8, w.Wu, VOP / 16,
+    fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * TM / 16, T::KU / 8, w.Wu, VOP / 16,
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
     // scalar linear: 64 x K -> 256, wave w owns column tiles 2w, 2w+1 for all 4 row tiles
     {
-        f32x4 acc[4][2];
+        f32x4 acc[MT][2];
+        // bias and (FIRST) the hoisted per-source term are requested BEFORE the GEMM so their L2 latency
+        // hides behind the MFMAs; they seed the accumulators' epilogue, not the MFMA chain
+        float pre[MT][2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        fm_wave_gemm<4, 2>(acc, X, FM_LDX, K8S, w.Ws, 16, 2 * wave, lane);
-        __syncthreads();                      // every wave has finished reading X (and Vh)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = (2 * wave + j) * 16 + (lane & 15);
                 const float bias = w.bs[col];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = i * 16 + 4 * (lane >> 4) + r;
-                    float v = acc[i][j][r] + bias;
+                    float v = bias;
                     if (addend != nullptr) {
-                        const int ar = arows[row];
+                        const int ar = arows[i * 16 + 4 * (lane >> 4) + r];
                         if (ar >= 0) v += addend[(size_t)ar * 256 + col];
                     }
-                    X[row * FM_LDX + col] = fm_silu(v);
+                    pre[i][j][r] = v;
+                }
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        fm_wave_gemm<MT, 2>(acc, X, FM_LDX, K8S, w.Ws, 16, 2 * wave, lane);
+        __syncthreads();                      // every wave has finished reading X (and Vh)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = (2 * wave + j) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + 4 * (lane >> 4) + r;
+                    X[row * FM_LDX + col] = fm_silu(acc[i][j][r] + pre[i][j][r]);
                 }
             }
         __syncthreads();
     }
     // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128)
-    fm_block_gemm<1, 1>(X, FM_LDX, FM_TM / 16, 256 / 8, w.Wg, VOP / 16, [&](int row, int col, float v) {
+    fm_block_gemm<1, 1>(X, FM_LDX, TM / 16, 256 / 8, w.Wg, VOP / 16, [&](int row, int col, float v) {
         v += w.bg[col];
         G[row * FM_LDG + col] = SIGMOID ? fm_sigmoid(v) : v;
     });
     __syncthreads();
-    for (int idx = tid; idx < 3 * FM_TM * VOUT; idx += FM_THREADS) {
+    for (int idx = tid; idx < 3 * TM * VOUT; idx += FM_THREADS) {
         const int row = idx / VOUT, u = idx % VOUT;
-        Vin[row * T::LDVI + u] *= G[(row % FM_TM) * FM_LDG + u];
+        Vin[row * T::LDVI + u] *= G[(row % TM) * FM_LDG + u];
     }
     __syncthreads();
 }
 
-// LayerNorm statistics of one LDS row handled by a group of 8 consecutive lanes (n = 256 or 128):
-// two-pass mean / biased variance like torch.nn.functional.layer_norm.
-__device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {
+// LayerNorm statistics of one LDS row handled by a group of LPR consecutive lanes (LPR = 8 or 16):
+// two-pass mean / biased variance like torch.nn.functional.layer_norm.  All lanes must call it.
+template <int LPR>
+__device__ __forceinline__ void fm_row_stats(const float* row, int n, int sub, float& mean, float& rstd) {
     float s = 0.f;
-    for (int c = sub; c < n; c += 8) s += row[c];
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    for (int c = sub; c < n; c += LPR) s += row[c];
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
     mean = s / (float)n;
     float q = 0.f;
-    for (int c = sub; c < n; c += 8) { const float d = row[c] - mean; q += d * d; }
-    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    for (int c = sub; c < n; c += LPR) { const float d = row[c] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
     rstd = 1.0f / sqrtf(q / (float)n + 1e-5f);
+}
+__device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {
+    fm_row_stats<8>(row, n, sub, mean, rstd);
 }

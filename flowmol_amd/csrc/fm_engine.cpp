@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -45,6 +46,7 @@ struct fm_ctx {
     fm_config cfg{};
     std::string err;
     int V = 32, na = 0, nc = 0, ne = 0;
+    int tm_edge = 32, tm_node = 32;        // rows per workgroup tile of the GVP kernels (FM_TILE_EDGE / FM_TILE_NODE override)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
     char* arena = nullptr; size_t arena_bytes = 0;
@@ -186,9 +188,9 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int vout, FmG
 
 template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
-size_t lds_gvp(int V, bool with_meta) {
-    size_t fl = (size_t)FM_TM * FM_LDX + 3 * FM_TM * (V + 4) + 3 * FM_TM * (V + 20) + FM_TM * FM_LDG;
-    return fl * 4 + (with_meta ? (size_t)FM_TM * 6 * 4 : 0);
+size_t lds_gvp(int V, int TM, bool with_meta) {
+    size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (V + 20) + TM * FM_LDG;
+    return fl * 4 + (with_meta ? (size_t)TM * 6 * 4 : 0);
 }
 size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 4 * FM_TM * 4; }
 size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }
@@ -242,7 +244,7 @@ void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int row
 }
 
 // ---------------------------------------------------------------------------------------- one network evaluation
-template <int V>
+template <int V, int TE, int TN>
 int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
              bool taps_on) {
     Launch L{c, st};
@@ -280,7 +282,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     L.copy(c->xw, state->x_t, (size_t)N * 3 * 4);
 
     const dim3 blk(FM_THREADS);
-    const dim3 gn(c->n_tiles_n), ge(c->n_tiles_e);
+    const dim3 gn((N + FM_TM - 1) / FM_TM), ge((E + FM_TM - 1) / FM_TM);     // 64-row kernels
+    const dim3 gnt((N + TN - 1) / TN), get((E + TE - 1) / TE);              // GVP kernels
     for (int i = 0; i < cf.n_convs; ++i) {
         const ConvW& cw = c->conv[i];
         FmProjArgs pa{};
@@ -294,7 +297,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         // per-edge message taps are written straight into the caller's buffers (both must be registered)
         const bool dbg = taps_on && i == 0 && c->taps.count("conv0.msg.s") && c->taps.count("conv0.msg.v");
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
-        L("edge_message", fm_k_edge_message<V>, ge, blk, lds_gvp(V, true), m);
+        L("edge_message", fm_k_edge_message<V, TE>, get, blk, lds_gvp(V, TE, true), m);
         FmNodeUpdArgs nu{};
         nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
         nu.g0 = cw.upd[0]; nu.g1 = cw.upd[1]; nu.g2 = cw.upd[2];
@@ -303,7 +306,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         const bool tagg = taps_on && (c->taps.count(ci + ".agg.s") || c->taps.count(ci + ".agg.v"));
         nu.agg_s = tagg ? c->Ps : nullptr;        // Ps / PV are dead until the next conv: reuse as tap scratch
         nu.agg_v = tagg ? c->PV : nullptr;
-        L("node_update", fm_k_node_update<V>, gn, blk, lds_gvp(V, false), nu);
+        nu.tile_e = TE;
+        L("node_update", fm_k_node_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), nu);
         if (tagg) { tap(ci + ".agg.s", c->Ps, (size_t)N * 256 * 4); tap(ci + ".agg.v", c->PV, (size_t)N * 3 * V * 4); }
         tap(ci + ".s", c->s, (size_t)N * 256 * 4);
         tap(ci + ".v", c->v, (size_t)N * 3 * V * 4);
@@ -312,7 +316,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             const UpdW& uw = c->upd[u];
             FmPosArgs pp{};
             pp.N = N; pp.s = c->s; pp.v = c->v; pp.x = c->xw; pp.g0 = uw.pos[0]; pp.g1 = uw.pos[1]; pp.g2 = uw.pos[2];
-            L("pos_update", fm_k_pos_update<V>, gn, blk, lds_gvp(V, false), pp);
+            L("pos_update", fm_k_pos_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), pp);
             FmProjArgs pa2{};
             pa2.N = N; pa2.s = c->s; pa2.v = c->v; pa2.Wasd = uw.Wasd; pa2.Asd = c->Asd;
             L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
@@ -338,6 +342,14 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     return L.rc;
 }
 
+int evaluate_dispatch(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out, bool taps_on) {
+#define FM_EVAL(V_, TE_, TN_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_) return evaluate<V_, TE_, TN_>(c, st, state, prev, remove_com, out, taps_on);
+    FM_EVAL(32, 32, 32) FM_EVAL(32, 32, 64) FM_EVAL(32, 64, 32) FM_EVAL(32, 64, 64)
+    FM_EVAL(16, 32, 32) FM_EVAL(16, 32, 64) FM_EVAL(16, 64, 32) FM_EVAL(16, 64, 64)
+#undef FM_EVAL
+    return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d", c->V, c->tm_edge, c->tm_node);
+}
+
 int embed_table(fm_ctx* c, hipStream_t st, const float* temb) {
     Launch L{c, st};
     const fm_config& cf = c->cfg;
@@ -356,14 +368,14 @@ int forward_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const float* 
     if (rc) return rc;
     const bool sc = c->cfg.self_conditioning != 0;
     if (sc && !prev && bootstrap) {
-        rc = (c->V == 32) ? evaluate<32>(c, st, state, nullptr, 0, &c->boot, false) : evaluate<16>(c, st, state, nullptr, 0, &c->boot, false);
+        rc = evaluate_dispatch(c, st, state, nullptr, 0, &c->boot, false);
         if (rc) return rc;
         if (c->taps.count("boot.x")) { Launch L{c, st}; L.tap("boot.x", c->boot.x, (size_t)c->b.N * 12); L.tap("boot.a", c->boot.a, (size_t)c->b.N * c->na * 4);
             L.tap("boot.c", c->boot.c, (size_t)c->b.N * c->nc * 4); L.tap("boot.e", c->boot.e, (size_t)c->b.U * c->ne * 4); if (L.rc) return L.rc; }
         prev = &c->boot;
     }
     if (!sc) prev = nullptr;
-    return (c->V == 32) ? evaluate<32>(c, st, state, prev, remove_com, out, true) : evaluate<16>(c, st, state, prev, remove_com, out, true);
+    return evaluate_dispatch(c, st, state, prev, remove_com, out, true);
 }
 
 int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* dst, const fm_step_noise* nz,
@@ -588,13 +600,17 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (e != hipSuccess) { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_HIP, "fm_create: weight upload failed: %s", hipGetErrorString(e)); }
     for (const Fix& f : B.fix) *f.slot = c->arena + f.off * sizeof(float);
     // ---- dynamic LDS opt-in (up to 160 KiB per workgroup on gfx950)
-    if (V == 32) {
-        set_lds(fm_k_edge_message<32>, lds_gvp(32, true)); set_lds(fm_k_node_update<32>, lds_gvp(32, false));
-        set_lds(fm_k_pos_update<32>, lds_gvp(32, false)); set_lds(fm_k_node_proj<32>, lds_proj(32));
-    } else {
-        set_lds(fm_k_edge_message<16>, lds_gvp(16, true)); set_lds(fm_k_node_update<16>, lds_gvp(16, false));
-        set_lds(fm_k_pos_update<16>, lds_gvp(16, false)); set_lds(fm_k_node_proj<16>, lds_proj(16));
+    if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge = atoi(e1);
+    if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node = atoi(e2);
+    if ((c->tm_edge != 32 && c->tm_edge != 64) || (c->tm_node != 32 && c->tm_node != 64)) {
+        (void)hipFree(c->arena); delete c;
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: FM_TILE_EDGE / FM_TILE_NODE must be 32 or 64");
     }
+#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_>, lds_gvp(V_, T_, false)); \
+    set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
+    FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 32) FM_SET(16, 64)
+#undef FM_SET
+    set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_edge_update, lds_edge_upd());
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
@@ -631,7 +647,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     if (E > 0x7fffffffLL / 4) return fail(c, FM_ERR_INVALID, "batch too large for int32 edge indexing (%lld edges)", E);
     const int V = c->V;
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
-    w.P = (nmax - 2) / FM_TM + 2;
+    w.P = (nmax - 2) / c->tm_edge + 2;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };

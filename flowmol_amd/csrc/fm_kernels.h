@@ -315,21 +315,21 @@ struct FmMsgArgs {
     float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
 };
 
-template <int V>
+template <int V, int TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
-    typedef FmGvpTile<V> T;
+    typedef FmGvpTile<V, TM> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
     float* Vin = X + T::X_FLOATS;
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = Vh + T::VH_FLOATS;
     int* m_src = reinterpret_cast<int*>(G + T::G_FLOATS);   // [64]
-    int* m_dst = m_src + FM_TM;                              // [64]
-    float* m_geo = reinterpret_cast<float*>(m_dst + FM_TM);  // [64][4]: xhat(3), dist
+    int* m_dst = m_src + TM;                              // [64]
+    float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [64][4]: xhat(3), dist
     const int tid = threadIdx.x;
-    const int e0 = blockIdx.x * FM_TM;
+    const int e0 = blockIdx.x * TM;
 
-    if (tid < FM_TM) {
+    if (tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1;
         float gx = 0.f, gy = 0.f, gz = 0.f, dist = 0.f;
@@ -345,11 +345,11 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
     }
     __syncthreads();
     // X[:, 0..31] = rbf(d), X[:, 32..159] = ef
-    for (int idx = tid; idx < FM_TM * 32; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
         const int r = idx >> 5, k = idx & 31;
         X[r * FM_LDX + k] = (m_src[r] >= 0) ? fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
     }
-    for (int idx = tid; idx < FM_TM * 32; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
         const int r = idx >> 5, c4 = idx & 31;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m_src[r] >= 0) val = reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4];
@@ -357,25 +357,25 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
         d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
     }
     // hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c] * w0[:]
-    for (int idx = tid; idx < 3 * FM_TM * (V + 16); idx += FM_THREADS) {
+    for (int idx = tid; idx < 3 * TM * (V + 16); idx += FM_THREADS) {
         const int row = idx / (V + 16), col = idx % (V + 16);
-        const int c = row / FM_TM, r = row % FM_TM;
+        const int c = row / TM, r = row % TM;
         float val = 0.f;
         if (m_src[r] >= 0) val = a.PV[((size_t)m_src[r] * 3 + c) * (V + 16) + col] + m_geo[4 * r + c] * a.w0[col];
         Vh[row * T::LDVH + col] = val;
     }
     __syncthreads();
-    fm_gvp_core<V, V, true, true>(X, Vin, Vh, G, a.g0, a.Ps, m_src);
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    fm_gvp_core<V, V, true, true, TM>(X, Vin, Vh, G, a.g0, a.Ps, m_src);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
 
     if (a.dbg_s) {
-        for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+        for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
             const int r = idx >> 8, c = idx & 255;
             if (m_src[r] >= 0) a.dbg_s[(size_t)(e0 + r) * 256 + c] = X[r * FM_LDX + c];
         }
-        for (int idx = tid; idx < 3 * FM_TM * V; idx += FM_THREADS) {
-            const int row = idx / V, u = idx % V, c = row / FM_TM, r = row % FM_TM;
+        for (int idx = tid; idx < 3 * TM * V; idx += FM_THREADS) {
+            const int row = idx / V, u = idx % V, c = row / TM, r = row % TM;
             if (m_src[r] >= 0) a.dbg_v[((size_t)(e0 + r) * 3 + c) * V + u] = Vin[row * T::LDVI + u];
         }
     }
@@ -385,13 +385,13 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
         const bool is_s = tid < 256;
         const int vc = (tid - 256) / V, vu = (tid - 256) % V;        // vector column -> (xyz, channel)
         float run = 0.f;
-        for (int r = 0; r < FM_TM; ++r) {
+        for (int r = 0; r < TM; ++r) {
             const int d = m_dst[r];
             if (d < 0) break;
-            run += is_s ? X[r * FM_LDX + tid] : Vin[(vc * FM_TM + r) * T::LDVI + vu];
-            const bool last = (r == FM_TM - 1) || (m_dst[r + 1] != d);
+            run += is_s ? X[r * FM_LDX + tid] : Vin[(vc * TM + r) * T::LDVI + vu];
+            const bool last = (r == TM - 1) || (m_dst[r + 1] != d);
             if (last) {
-                const int piece = (int)blockIdx.x - (a.b.node_first_edge[d] >> 6);
+                const int piece = (int)blockIdx.x - a.b.node_first_edge[d] / TM;
                 if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + tid] = run;
                 else a.part_v[(((size_t)d * a.b.P + piece) * 3 + vc) * V + vu] = run;
                 run = 0.f;
@@ -409,6 +409,7 @@ struct FmNodeUpdArgs {
     float* s; float* v;              // (N,256), (N,3,V) updated in place
     const float* part_s; const float* part_v;
     float inv_z;
+    int tile_e;                      // rows per tile of the edge-message kernel (defines the pieces)
     FmGvpW g0, g1, g2;
     const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
     float* agg_s; float* agg_v;      // optional debug taps of the aggregated messages, else null
@@ -416,49 +417,51 @@ struct FmNodeUpdArgs {
 
 // GVPLayerNorm of a tile held in X[:, 0..255] / Vin (gvp.py:169-184); result written to LDS in place and,
 // when out_s/out_v are given, to HBM.
-template <int V>
+template <int V, int TM>
 __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, const float* g, const float* b_,
                                                       int row0, int nrows, float* out_s, float* out_v) {
-    typedef FmGvpTile<V> T;
-    const int tid = threadIdx.x, r = tid >> 3, sub = tid & 7;
+    typedef FmGvpTile<V, TM> T;
+    constexpr int LPR = FM_THREADS / TM;          // lanes per row
+    const int tid = threadIdx.x, r = tid / LPR, sub = tid % LPR;
     float mean, rstd;
-    fm_row_stats8(X + r * FM_LDX, 256, sub, mean, rstd);
+    fm_row_stats<LPR>(X + r * FM_LDX, 256, sub, mean, rstd);
     // vector norm: vn = sqrt(mean_c max(|v_c|^2, 1e-8) + eps) + eps
     float q = 0.f;
-    for (int u = sub; u < V; u += 8) {
-        const float vx = Vin[(0 * FM_TM + r) * T::LDVI + u], vy = Vin[(1 * FM_TM + r) * T::LDVI + u], vz = Vin[(2 * FM_TM + r) * T::LDVI + u];
+    for (int u = sub; u < V; u += LPR) {
+        const float vx = Vin[(0 * TM + r) * T::LDVI + u], vy = Vin[(1 * TM + r) * T::LDVI + u], vz = Vin[(2 * TM + r) * T::LDVI + u];
         q += fmaxf(vx * vx + vy * vy + vz * vz, 1e-8f);
     }
-    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    #pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
     const float vn = sqrtf(q / (float)V + 1e-5f) + 1e-5f;
     const bool valid = row0 + r < nrows;
-    for (int c = sub; c < 256; c += 8) {
+    for (int c = sub; c < 256; c += LPR) {
         const float y = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
         X[r * FM_LDX + c] = y;
         if (out_s && valid) out_s[(size_t)(row0 + r) * 256 + c] = y;
     }
-    for (int u = sub; u < V; u += 8)
+    for (int u = sub; u < V; u += LPR)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float y = Vin[(c * FM_TM + r) * T::LDVI + u] / vn;
-            Vin[(c * FM_TM + r) * T::LDVI + u] = y;
+            const float y = Vin[(c * TM + r) * T::LDVI + u] / vn;
+            Vin[(c * TM + r) * T::LDVI + u] = y;
             if (out_v && valid) out_v[((size_t)(row0 + r) * 3 + c) * V + u] = y;
         }
     __syncthreads();
 }
 
-template <int V>
+template <int V, int TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) {
-    typedef FmGvpTile<V> T;
+    typedef FmGvpTile<V, TM> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
     float* Vin = X + T::X_FLOATS;
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = Vh + T::VH_FLOATS;
-    const int tid = threadIdx.x, row0 = blockIdx.x * FM_TM;
+    const int tid = threadIdx.x, row0 = blockIdx.x * TM;
     const int N = a.b.N;
     // s + sum(pieces)/z
-    for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
         const int r = idx >> 8, c = idx & 255, n = row0 + r;
         float val = 0.f;
         if (n < N) {
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
             float acc = 0.f;
             if (deg > 0) {
                 const int fe = a.b.node_first_edge[n];
-                const int np = ((fe + deg - 1) >> 6) - (fe >> 6) + 1;
+                const int np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
                 for (int p = 0; p < np; ++p) acc += a.part_s[((size_t)n * a.b.P + p) * 256 + c];
             }
             acc *= a.inv_z;
@@ -476,7 +479,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         }
         X[r * FM_LDX + c] = val;
     }
-    for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 3 * V; idx += FM_THREADS) {
         const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
         float val = 0.f;
         if (n < N) {
@@ -485,30 +488,30 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
             float acc = 0.f;
             if (deg > 0) {
                 const int fe = a.b.node_first_edge[n];
-                const int np = ((fe + deg - 1) >> 6) - (fe >> 6) + 1;
+                const int np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
                 for (int p = 0; p < np; ++p) acc += a.part_v[(((size_t)n * a.b.P + p) * 3 + c) * V + u];
             }
             acc *= a.inv_z;
             if (a.agg_v) a.agg_v[((size_t)n * 3 + c) * V + u] = acc;
             val = a.v[((size_t)n * 3 + c) * V + u] + acc;
         }
-        Vin[(c * FM_TM + r) * T::LDVI + u] = val;
+        Vin[(c * TM + r) * T::LDVI + u] = val;
     }
     __syncthreads();
-    fm_gvp_layernorm_tile<V>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v);     // s1, v1 -> HBM (needed for the residual)
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
-    for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v);     // s1, v1 -> HBM (needed for the residual)
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
         const int r = idx >> 8, c = idx & 255, n = row0 + r;
         if (n < N) X[r * FM_LDX + c] += a.s[(size_t)n * 256 + c];
     }
-    for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 3 * V; idx += FM_THREADS) {
         const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
-        if (n < N) Vin[(c * FM_TM + r) * T::LDVI + u] += a.v[((size_t)n * 3 + c) * V + u];
+        if (n < N) Vin[(c * TM + r) * T::LDVI + u] += a.v[((size_t)n * 3 + c) * V + u];
     }
     __syncthreads();
-    fm_gvp_layernorm_tile<V>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v);
+    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,30 +524,30 @@ struct FmPosArgs {
     FmGvpW g0, g1, g2;
 };
 
-template <int V>
+template <int V, int TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_pos_update(FmPosArgs a) {
-    typedef FmGvpTile<V> T;
+    typedef FmGvpTile<V, TM> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
     float* Vin = X + T::X_FLOATS;
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = Vh + T::VH_FLOATS;
-    const int tid = threadIdx.x, row0 = blockIdx.x * FM_TM;
-    for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
+    const int tid = threadIdx.x, row0 = blockIdx.x * TM;
+    for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
         const int r = idx >> 8, c = idx & 255, n = row0 + r;
         X[r * FM_LDX + c] = (n < a.N) ? a.s[(size_t)n * 256 + c] : 0.f;
     }
-    for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 3 * V; idx += FM_THREADS) {
         const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
-        Vin[(c * FM_TM + r) * T::LDVI + u] = (n < a.N) ? a.v[((size_t)n * 3 + c) * V + u] : 0.f;
+        Vin[(c * TM + r) * T::LDVI + u] = (n < a.N) ? a.v[((size_t)n * 3 + c) * V + u] : 0.f;
     }
     __syncthreads();
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
-    fm_gvp_core<V, 1, false, false>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
-    if (tid < FM_TM * 3) {
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
+    fm_gvp_core<V, 1, false, false, TM>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    if (tid < TM * 3) {
         const int r = tid / 3, c = tid % 3, n = row0 + r;
-        if (n < a.N) a.x[n * 3 + c] += Vin[(c * FM_TM + r) * T::LDVI];
+        if (n < a.N) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];
     }
 }
 
