@@ -21,6 +21,26 @@
 #include <hip/hip_runtime.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Profiling aid, compiled out unless -DFM_PHASE_TIMING: thread 0 of every workgroup accumulates the shader
+// cycles spent between consecutive FM_MARK(id) points into fm_tlog[id] (read back with fm_tlog_read, see
+// tools/phase_timing.py).  This is how profiles/r01c_phase_cycles_edge_message.json was produced.
+#ifdef FM_PHASE_TIMING
+__device__ unsigned long long fm_tlog[64];
+#define FM_MARK_DECL unsigned long long fm_tl_ = __builtin_readcyclecounter();
+#define FM_MARK_ARG , unsigned long long& fm_tl_, int fm_tb_
+#define FM_MARK_PASS(b) , fm_tl_, (b)
+#define FM_MARK(id) do { if (threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); \
+        atomicAdd(&fm_tlog[(id)], now_ - fm_tl_); fm_tl_ = now_; } } while (0)
+#define FM_MARKB(k) FM_MARK(fm_tb_ + (k))
+#else
+#define FM_MARK_DECL
+#define FM_MARK_ARG
+#define FM_MARK_PASS(b)
+#define FM_MARK(id) ((void)0)
+#define FM_MARKB(k) ((void)0)
+#endif
 
 #define FM_TM 64          // rows per workgroup tile of the non-GVP kernels (MLPs, edge update, projections)
 #define FM_THREADS 512    // 8 waves
@@ -58,7 +78,7 @@ __device__ __forceinline__ float fm_div_rn(float a, float b) {
 // Gaussian RBF, reference flowmol/utils/embedding.py:19-34: mu_k = k*Dmax/(R-1), sigma = Dmax/R
 __device__ __forceinline__ float fm_rbf(float d, int k, float mu_step, float inv_sigma) {
     float z = (d - (float)k * mu_step) * inv_sigma;
-    return expf(-(z * z));
+    return __builtin_amdgcn_exp2f(z * z * -1.44269504088896341f);
 }
 
 // distance with the reference's clamps: sqrt(max(|dx|^2,1e-8)) (+1e-8 added by the caller where the reference does)
@@ -73,8 +93,14 @@ __device__ __forceinline__ float fm_norm3(float dx, float dy, float dz) {
 template <int MT, int NT>
 __device__ __forceinline__ void fm_frag_load(float2 (&a)[MT], float2 (&b)[NT], const float* ap, int lda,
                                              const float2* __restrict__ wp, size_t wstep, int ks) {
+    // volatile LDS-address-space load: keeps each A fragment a single ds_read_b64 (conflict-free with (ld/4) odd, 256 B/clk).  Without it
+    // hipcc pairs them into ds_read2_b64, which is serviced in 16-lane groups over 32 banks at half the rate and
+    // 2-way conflicts on this layout (MI355X_MICROARCH.md LDS table; SQ_LDS_BANK_CONFLICT was 40 % of LDS cycles).
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float2*>(ap + mt * 16 * lda + 8 * ks);
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x2 t = *(const volatile __attribute__((address_space(3))) f32x2*)(ap + mt * 16 * lda + 8 * ks);
+        a[mt].x = t[0]; a[mt].y = t[1];
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b[nt] = wp[(size_t)ks * wstep + (size_t)nt * 64];
 }
@@ -103,15 +129,65 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
     const float2* wp = Wp + (size_t)nt0 * 64 + lane;
     const size_t wstep = (size_t)ntiles * 64;
     float2 a0[MT], b0[NT], a1[MT], b1[NT];
+    // sched_barrier(0) pins "request step k+1, then issue the MFMAs of step k": without it hipcc's scheduler sinks
+    // every load down to its first use (s_waitcnt vmcnt(0) right behind the global_load) and the pipelining is lost.
     fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, 0);
     int ks = 0;
     for (; ks + 2 <= K8; ks += 2) {
         fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 2 < K8) fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (ks < K8) fm_frag_mma<MT, NT>(acc, a0, b0);
+}
+
+// Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
+// are requested before the MFMAs of chunk c.  A 1x1 tile has only 2 MFMAs (64 cycles) per k-superstep, far less
+// than the L2 latency of its B fragment, so the one-step pipelining of fm_wave_gemm leaves it latency-bound
+// (profiles/r01c: the 256->V gate GEMM took 6-10k cycles for 2k cycles of MFMA work).  Two accumulators (even/odd
+// steps) break the 40-cycle dependent-accumulator chain; they are added at the end.
+template <int K8, int CH>
+__device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const float2* __restrict__ Wp, int ntiles, int nt, int lane) {
+    static_assert(K8 % CH == 0 && CH % 2 == 0, "K8 must be a multiple of the (even) chunk size");
+    constexpr int NCH = K8 / CH;
+    const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
+    const float2* wp = Wp + (size_t)nt * 64 + lane;
+    const size_t wstep = (size_t)ntiles * 64;
+    float2 a[2][CH], b[2][CH];
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        const f32x2 t = *(const volatile __attribute__((address_space(3))) f32x2*)(ap + 8 * q);
+        a[0][q].x = t[0]; a[0][q].y = t[1];
+        b[0][q] = wp[(size_t)q * wstep];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int ks = (c + 1) * CH + q;
+                const f32x2 t = *(const volatile __attribute__((address_space(3))) f32x2*)(ap + 8 * ks);
+                a[(c + 1) & 1][q].x = t[0]; a[(c + 1) & 1][q].y = t[1];
+                b[(c + 1) & 1][q] = wp[(size_t)ks * wstep];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CH; q += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q].x, b[c & 1][q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q + 1].x, b[c & 1][q + 1].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q].y, b[c & 1][q].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q + 1].y, b[c & 1][q + 1].y, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc0 + acc1;
 }
 
 // block-level GEMM over an (mtiles x ntiles) grid of 16x16 output tiles: super-tiles of MT x NT tiles
@@ -172,11 +248,11 @@ struct FmGvpTile {
 //           X[r][0..159]          = [rbf(32) | ef(128)]
 //   !FIRST: Vin[xyz*TM+r][0..V-1] = input vectors,  X[r][0..255] = input scalars
 // State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
-// `addend`/`arows` (optional): per-row gather added before the SiLU (the hoisted W_s * s[src] term).
+// `pre`: per-accumulator-element addend of the scalar linear (fm_gather_pre / fm_zero_pre); the bias is added here.
 // All 512 threads must call it (it contains barriers); it ends with a barrier.
 template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
-                                            const float* __restrict__ addend, const int* arows) {
+                                            float (&pre)[TM / 16][2][4] FM_MARK_ARG) {
     typedef FmGvpTile<V, TM> T;
     constexpr int MT = TM / 16;                          // row tiles of the scalar GEMM
     constexpr int H = FIRST ? V + 1 : V;                 // hidden vector channels
@@ -192,8 +268,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                             [&](int row, int col, float v) { Vh[row * T::LDVH + col] = v; });
         __syncthreads();
     }
-    // cross products cp_p = a_p x b_p, (a,b) = Vcp[0..3], Vcp[4..7]  (gvp.py:105-112); written at
-    // columns H..H+3.  Each thread touches only its own columns, so no barrier is needed inside.
+    FM_MARKB(0);
+    // One phase, no barrier inside: (a) threads < 4*TM form the cross products cp_p = a_p x b_p,
+    // (a,b) = Vcp[0..3], Vcp[4..7] (gvp.py:105-112), store them at columns H..H+3 of Vh (each thread touches
+    // only its own columns) and their norms into X; (b) all threads compute the norms sh of the H plain hidden
+    // channels (gvp.py:116, _norm_no_nan clamp) -> X[:, SOFF..SOFF+H) and clear the K padding of X.
     if (tid < TM * 4) {
         const int r = tid >> 2, p = tid & 3;
         float a[3], b[3];
@@ -212,49 +291,44 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(0 * TM + r) * T::LDVH + H + p] = cx;
         Vh[(1 * TM + r) * T::LDVH + H + p] = cy;
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
+        X[r * FM_LDX + SOFF + H + p] = fm_norm3(cx, cy, cz);
     }
-    __syncthreads();
-    // sh = |Vh_full| per channel with the reference's clamp (gvp.py:116, _norm_no_nan) -> X[:, SOFF..]
     for (int idx = tid; idx < TM * (V + 8); idx += FM_THREADS) {
         const int r = idx / (V + 8), c = idx % (V + 8);
-        float val = 0.f;
-        if (c < H + 4) {
+        if (c < H) {
             const float vx = Vh[(0 * TM + r) * T::LDVH + c];
             const float vy = Vh[(1 * TM + r) * T::LDVH + c];
             const float vz = Vh[(2 * TM + r) * T::LDVH + c];
-            val = fm_norm3(vx, vy, vz);
+            X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
+        } else if (c >= H + 4) {
+            X[r * FM_LDX + SOFF + c] = 0.f;
         }
-        X[r * FM_LDX + SOFF + c] = val;
     }
     __syncthreads();
+    FM_MARKB(1);
     // Vu = Vh_full * Wu -> Vin (the input vectors are dead by now)
     fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * TM / 16, T::KU / 8, w.Wu, VOP / 16,
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
     // scalar linear: 64 x K -> 256, wave w owns column tiles 2w, 2w+1 for all 4 row tiles
     {
         f32x4 acc[MT][2];
-        // bias and (FIRST) the hoisted per-source term are requested BEFORE the GEMM so their L2 latency
-        // hides behind the MFMAs; they seed the accumulators' epilogue, not the MFMA chain
-        float pre[MT][2][4];
+        // `pre` holds what is added to the linear output besides the MFMA result: the caller's per-element addend
+        // (the hoisted W_s*s[src] term of the first edge GVP, requested long before so its latency is hidden; zeros
+        // otherwise) plus the bias.
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = (2 * wave + j) * 16 + (lane & 15);
-                const float bias = w.bs[col];
+                const float bias = w.bs[(2 * wave + j) * 16 + (lane & 15)];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = bias;
-                    if (addend != nullptr) {
-                        const int ar = arows[i * 16 + 4 * (lane >> 4) + r];
-                        if (ar >= 0) v += addend[(size_t)ar * 256 + col];
-                    }
-                    pre[i][j][r] = v;
-                }
+                for (int r = 0; r < 4; ++r) pre[i][j][r] += bias;
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        FM_MARKB(2);
         fm_wave_gemm<MT, 2>(acc, X, FM_LDX, K8S, w.Ws, 16, 2 * wave, lane);
+        FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
+        FM_MARKB(4);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -268,17 +342,51 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
             }
         __syncthreads();
     }
-    // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128)
-    fm_block_gemm<1, 1>(X, FM_LDX, TM / 16, 256 / 8, w.Wg, VOP / 16, [&](int row, int col, float v) {
-        v += w.bg[col];
-        G[row * FM_LDG + col] = SIGMOID ? fm_sigmoid(v) : v;
-    });
+    FM_MARKB(5);
+    // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128): (TM/16) x (VOP/16) single-tile jobs, K = 256
+    for (int job = wave; job < (TM / 16) * (VOP / 16); job += FM_WAVES) {
+        const int m0 = job / (VOP / 16), n0 = job % (VOP / 16);
+        const f32x4 g = fm_wave_gemm_1x1<32, 8>(X + (size_t)m0 * 16 * FM_LDX, FM_LDX, w.Wg, VOP / 16, n0, lane);
+        const int col = n0 * 16 + (lane & 15);
+        const float bg = w.bg[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = g[r] + bg;
+            G[(m0 * 16 + 4 * (lane >> 4) + r) * FM_LDG + col] = SIGMOID ? fm_sigmoid(v) : v;
+        }
+    }
+    FM_MARKB(6);
     __syncthreads();
     for (int idx = tid; idx < 3 * TM * VOUT; idx += FM_THREADS) {
         const int row = idx / VOUT, u = idx % VOUT;
         Vin[row * T::LDVI + u] *= G[(row % TM) * FM_LDG + u];
     }
     __syncthreads();
+    FM_MARKB(7);
+}
+
+// per-element addend of the first edge GVP's scalar linear: Ps[src[row]][col] for this lane's accumulator elements
+template <int TM>
+__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][2][4], const float* __restrict__ addend, const int* rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < TM / 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ar = rows[i * 16 + 4 * (lane >> 4) + r];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                pre[i][j][r] = (ar >= 0) ? addend[(size_t)ar * 256 + (2 * wave + j) * 16 + (lane & 15)] : 0.f;
+        }
+}
+template <int TM>
+__device__ __forceinline__ void fm_zero_pre(float (&pre)[TM / 16][2][4]) {
+#pragma unroll
+    for (int i = 0; i < TM / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre[i][j][r] = 0.f;
 }
 
 // LayerNorm statistics of one LDS row handled by a group of LPR consecutive lanes (LPR = 8 or 16):

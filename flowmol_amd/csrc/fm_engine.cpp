@@ -46,7 +46,8 @@ struct fm_ctx {
     fm_config cfg{};
     std::string err;
     int V = 32, na = 0, nc = 0, ne = 0;
-    int tm_edge = 32, tm_node = 32;        // rows per workgroup tile of the GVP kernels (FM_TILE_EDGE / FM_TILE_NODE override)
+    int tm_edge = 32, tm_node = 32, tm_eupd = 32;
+    int prio_mode = 0, skew_blocks = 0, skew_steps = 1;   // edge-message de-phasing (FM_PRIO / FM_SKEW_BLOCKS / FM_SKEW_STEPS override)        // rows per workgroup tile of the GVP kernels (FM_TILE_EDGE / FM_TILE_NODE override)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
     char* arena = nullptr; size_t arena_bytes = 0;
@@ -194,7 +195,7 @@ size_t lds_gvp(int V, int TM, bool with_meta) {
 }
 size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 4 * FM_TM * 4; }
 size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }
-size_t lds_edge_upd() { return ((size_t)FM_TM * 164 + FM_TM * 132) * 4 + FM_TM * 3 * 4; }
+size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
 
 // ---------------------------------------------------------------------------------------- launch helper
 int kid_of(fm_ctx* c, const char* name) {
@@ -323,7 +324,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             FmEdgeUpdArgs eu{};
             eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
             eu.ln_g = uw.ln_g; eu.ln_b = uw.ln_b; eu.rbf_mu_step = c->rbf_mu_step; eu.rbf_inv_sigma = c->rbf_inv_sigma;
-            L("edge_update", fm_k_edge_update, ge, blk, lds_edge_upd(), eu);
+            if (c->tm_eupd == 32) L("edge_update", fm_k_edge_update<32>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
+            else L("edge_update", fm_k_edge_update<64>, dim3((E + 63) / 64), blk, lds_edge_upd(64), eu);
             const std::string ui = "upd" + std::to_string(i);
             tap(ui + ".x", c->xw, (size_t)N * 3 * 4);
             tap(ui + ".ef", c->ef, (size_t)E * 128 * 4);
@@ -602,6 +604,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     // ---- dynamic LDS opt-in (up to 160 KiB per workgroup on gfx950)
     if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge = atoi(e1);
     if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node = atoi(e2);
+    if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
     if ((c->tm_edge != 32 && c->tm_edge != 64) || (c->tm_node != 32 && c->tm_node != 64)) {
         (void)hipFree(c->arena); delete c;
         return fail(nullptr, FM_ERR_INVALID, "fm_create: FM_TILE_EDGE / FM_TILE_NODE must be 32 or 64");
@@ -611,7 +614,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
-    set_lds(fm_k_edge_update, lds_edge_upd());
+    set_lds(fm_k_edge_update<32>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64>, lds_edge_upd(64));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max);
@@ -798,6 +801,15 @@ int fm_batch_query(fm_ctx* c, void* stream, const char* name, int32_t* dst) {
     FM_HIP(c, hipMemcpyAsync(dst, src, cnt * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FM_OK;
 }
+
+#ifdef FM_PHASE_TIMING
+// dev-only (not part of the ABI header): read / reset the phase-cycle accumulators of a -DFM_PHASE_TIMING build
+int fm_tlog_read(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fm_tlog), 64 * 8);
+    if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fm_tlog), z, 64 * 8); }
+    return 0;
+}
+#endif
 
 int fm_profile_enable(fm_ctx* c, int on) {
     if (!c) return FM_ERR_INVALID;

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + r < a.N) val = reinterpret_cast<const float4*>(a.s)[(size_t)(row0 + r) * 64 + c4];
         float* d = X + r * LDS_ + 4 * c4;
-        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        *reinterpret_cast<float4*>(d) = val;        // one ds_write_b128 (16-B aligned: row pitch and column offset are multiples of 16 B)
     }
     if (a.PV) {
         for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
@@ -327,8 +327,18 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
     int* m_dst = m_src + TM;                              // [64]
     float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [64][4]: xhat(3), dist
     const int tid = threadIdx.x;
-    const int e0 = blockIdx.x * TM;
-
+    const int tile = blockIdx.x;
+    const int e0 = tile * TM;
+    FM_MARK_DECL
+    // (A) the edge-feature rows depend only on the tile index: request them before anything else (HBM latency)
+    constexpr int NEF = TM * 32 / FM_THREADS;
+    float4 efv[NEF];
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) {
+        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        efv[k] = (e0 + r < a.b.E) ? reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (B) endpoints and geometry of the tile's edges
     if (tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1;
@@ -344,19 +354,13 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
         m_geo[4 * tid] = gx; m_geo[4 * tid + 1] = gy; m_geo[4 * tid + 2] = gz; m_geo[4 * tid + 3] = dist;
     }
     __syncthreads();
-    // X[:, 0..31] = rbf(d), X[:, 32..159] = ef
-    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
-        const int r = idx >> 5, k = idx & 31;
-        X[r * FM_LDX + k] = (m_src[r] >= 0) ? fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
-    }
-    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
-        const int r = idx >> 5, c4 = idx & 31;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m_src[r] >= 0) val = reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4];
-        float* d = X + r * FM_LDX + 32 + 4 * c4;
-        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-    }
-    // hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c] * w0[:]
+    FM_MARK(0);
+    // (C) the hoisted per-source scalar term of GVP0 is only consumed after its scalar GEMM: request it now so that its
+    //     L2 latency overlaps the fill below and the first phases of the GVP (VMEM returns in order, so a request
+    //     placed right before the GEMM would stall the GEMM's first weight fragments behind it)
+    float pre[TM / 16][2][4];
+    fm_gather_pre<TM>(pre, a.Ps, m_src);
+    // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     for (int idx = tid; idx < 3 * TM * (V + 16); idx += FM_THREADS) {
         const int row = idx / (V + 16), col = idx % (V + 16);
         const int c = row / TM, r = row % TM;
@@ -364,10 +368,22 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
         if (m_src[r] >= 0) val = a.PV[((size_t)m_src[r] * 3 + c) * (V + 16) + col] + m_geo[4 * r + c] * a.w0[col];
         Vh[row * T::LDVH + col] = val;
     }
+    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
+        const int r = idx >> 5, k = idx & 31;
+        X[r * FM_LDX + k] = (m_src[r] >= 0) ? fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) {
+        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(X + r * FM_LDX + 32 + 4 * c4) = efv[k];   // ds_write_b128 (16-B aligned)
+    }
     __syncthreads();
-    fm_gvp_core<V, V, true, true, TM>(X, Vin, Vh, G, a.g0, a.Ps, m_src);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    FM_MARK(1);
+    fm_gvp_core<V, V, true, true, TM>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
+    fm_zero_pre<TM>(pre);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
+    fm_zero_pre<TM>(pre);
+    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
 
     if (a.dbg_s) {
         for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
@@ -379,25 +395,37 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
             if (m_src[r] >= 0) a.dbg_v[((size_t)(e0 + r) * 3 + c) * V + u] = Vin[row * T::LDVI + u];
         }
     }
-    // segmented sum over the rows of each destination (rows are dst-sorted)
+    FM_MARK(40);
+    // segmented sum over the rows of each destination (rows are dst-sorted).  One thread per output column; the
+    // destination ids and the column's TM values are first pulled into registers with independent LDS reads, the
+    // running sums are then register-only (the first version walked the rows with dependent LDS reads: 15k cycles).
     const int ncols = 256 + 3 * V;
     if (tid < ncols) {
         const bool is_s = tid < 256;
-        const int vc = (tid - 256) / V, vu = (tid - 256) % V;        // vector column -> (xyz, channel)
+        const int vc = is_s ? 0 : (tid - 256) / V, vu = is_s ? 0 : (tid - 256) % V;     // vector column -> (xyz, channel)
+        int dsts[TM];
+        float val[TM];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) dsts[r] = m_dst[r];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) val[r] = is_s ? X[r * FM_LDX + tid] : Vin[(vc * TM + r) * T::LDVI + vu];
         float run = 0.f;
+#pragma unroll
         for (int r = 0; r < TM; ++r) {
-            const int d = m_dst[r];
-            if (d < 0) break;
-            run += is_s ? X[r * FM_LDX + tid] : Vin[(vc * TM + r) * T::LDVI + vu];
-            const bool last = (r == TM - 1) || (m_dst[r + 1] != d);
-            if (last) {
-                const int piece = (int)blockIdx.x - a.b.node_first_edge[d] / TM;
-                if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + tid] = run;
-                else a.part_v[(((size_t)d * a.b.P + piece) * 3 + vc) * V + vu] = run;
-                run = 0.f;
+            const int d = dsts[r];
+            if (d >= 0) {
+                run += val[r];
+                const bool last = (r == TM - 1) || (dsts[r == TM - 1 ? r : r + 1] != d);
+                if (last) {
+                    const int piece = tile - a.b.node_first_edge[d] / TM;
+                    if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + tid] = run;
+                    else a.part_v[(((size_t)d * a.b.P + piece) * 3 + vc) * V + vu] = run;
+                    run = 0.f;
+                }
             }
         }
     }
+    FM_MARK(41);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,9 +527,16 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     }
     __syncthreads();
     fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v);     // s1, v1 -> HBM (needed for the residual)
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    {
+        FM_MARK_DECL
+        float pre[TM / 16][2][4];
+        fm_zero_pre<TM>(pre);
+        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM>(pre);
+        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM>(pre);
+        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
+    }
     for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
         const int r = idx >> 8, c = idx & 255, n = row0 + r;
         if (n < N) X[r * FM_LDX + c] += a.s[(size_t)n * 256 + c];
@@ -542,9 +577,16 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_pos_update(FmPosArgs a) {
         Vin[(c * TM + r) * T::LDVI + u] = (n < a.N) ? a.v[((size_t)n * 3 + c) * V + u] : 0.f;
     }
     __syncthreads();
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, nullptr, nullptr);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, nullptr, nullptr);
-    fm_gvp_core<V, 1, false, false, TM>(X, Vin, Vh, G, a.g2, nullptr, nullptr);
+    {
+        FM_MARK_DECL
+        float pre[TM / 16][2][4];
+        fm_zero_pre<TM>(pre);
+        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM>(pre);
+        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM>(pre);
+        fm_gvp_core<V, 1, false, false, TM>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
+    }
     if (tid < TM * 3) {
         const int r = tid / 3, c = tid % 3, n = row0 + r;
         if (n < a.N) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];
@@ -566,16 +608,17 @@ struct FmEdgeUpdArgs {
     float rbf_mu_step, rbf_inv_sigma;
 };
 
+template <int TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) {
     HIP_DYNAMIC_SHARED(float, lds)
-    constexpr int LDX = 164, LDH = 132;
-    float* X = lds;                       // [64][164]: ef(128) | rbf(32)
-    float* Hb = lds + FM_TM * LDX;        // [64][132]
-    int* m_src = reinterpret_cast<int*>(Hb + FM_TM * LDH);
-    int* m_dst = m_src + FM_TM;
-    float* m_d = reinterpret_cast<float*>(m_dst + FM_TM);
-    const int tid = threadIdx.x, e0 = blockIdx.x * FM_TM;
-    if (tid < FM_TM) {
+    constexpr int LDX = 164, LDH = 132, MT = TM / 16, LPR = FM_THREADS / TM;
+    float* X = lds;                       // [TM][164]: ef(128) | rbf(32)
+    float* Hb = lds + TM * LDX;           // [TM][132]
+    int* m_src = reinterpret_cast<int*>(Hb + TM * LDH);
+    int* m_dst = m_src + TM;
+    float* m_d = reinterpret_cast<float*>(m_dst + TM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * TM;
+    if (tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1; float dist = 0.f;
         if (e < a.b.E) {
@@ -585,33 +628,59 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
         m_src[tid] = s; m_dst[tid] = d; m_d[tid] = dist;
     }
     __syncthreads();
-    for (int idx = tid; idx < FM_TM * 32; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
         const int r = idx >> 5, c4 = idx & 31;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m_src[r] >= 0) val = reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4];
         float* d = X + r * LDX + 4 * c4;
-        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        *reinterpret_cast<float4*>(d) = val;        // one ds_write_b128 (row pitch 656 B and column offset are multiples of 16 B)
         X[r * LDX + 128 + c4] = (m_src[r] >= 0) ? fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
     }
+    // layer 1: wave w owns column tile w for all MT row tiles.  The hoisted node terms W1_src*s[src] + W1_dst*s[dst]
+    // (+ bias) are requested before the GEMM so their L2 latency hides behind the MFMAs.
+    const int col = wave * 16 + (lane & 15);
+    float pre[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i * 16 + 4 * (lane >> 4) + r;
+            const int e = e0 + row;
+            float v = a.b1[col];
+            if (e < a.b.E) v += a.Asd[(size_t)a.b.e_src[e] * 256 + col] + a.Asd[(size_t)a.b.e_dst[e] * 256 + 128 + col];
+            pre[i][r] = v;
+        }
     __syncthreads();
-    fm_block_gemm<4, 1>(X, LDX, 4, 160 / 8, a.W1, 8, [&](int row, int col, float v) {
-        v += a.b1[col];
-        const int s = m_src[row];
-        if (s >= 0) v += a.Asd[(size_t)s * 256 + col] + a.Asd[(size_t)m_dst[row] * 256 + 128 + col];
-        Hb[row * LDH + col] = fm_silu(v);
-    });
+    {
+        f32x4 acc[MT][1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fm_wave_gemm<MT, 1>(acc, X, LDX, 160 / 8, a.W1, 8, wave, lane);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Hb[(i * 16 + 4 * (lane >> 4) + r) * LDH + col] = fm_silu(acc[i][0][r] + pre[i][r]);
+    }
     __syncthreads();
-    fm_block_gemm<4, 1>(Hb, LDH, 4, 128 / 8, a.W2, 8, [&](int row, int col, float v) {
-        X[row * LDX + col] += fm_silu(v + a.b2[col]);      // own element only: ef + update
-    });
+    {
+        f32x4 acc[MT][1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        fm_wave_gemm<MT, 1>(acc, Hb, LDH, 128 / 8, a.W2, 8, wave, lane);
+        const float b2 = a.b2[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(i * 16 + 4 * (lane >> 4) + r) * LDX + col] += fm_silu(acc[i][0][r] + b2);   // own element: ef + update
+    }
     __syncthreads();
-    const int r = tid >> 3, sub = tid & 7;
+    const int r = tid / LPR, sub = tid % LPR;
     float mean, rstd;
-    fm_row_stats8(X + r * LDX, 128, sub, mean, rstd);
+    fm_row_stats<LPR>(X + r * LDX, 128, sub, mean, rstd);
     if (m_src[r] >= 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = (j * 8 + sub) * 4;
+        for (int j = 0; j < 32 / LPR; ++j) {
+            const int c = (j * LPR + sub) * 4;
             float4 o;
             o.x = (X[r * LDX + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
             o.y = (X[r * LDX + c + 1] - mean) * rstd * a.ln_g[c + 1] + a.ln_b[c + 1];

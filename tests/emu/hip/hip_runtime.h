@@ -110,6 +110,9 @@ static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, i
 // ---------------------------------------------------------------- device math
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }

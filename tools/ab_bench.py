@@ -17,6 +17,11 @@ B = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 47
 os.environ['FM_TILE_EDGE'] = te
 os.environ['FM_TILE_NODE'] = tn
+if len(sys.argv) > 6:
+    os.environ['FM_TILE_EUPD'] = sys.argv[6]
+for kv in sys.argv[7:]:
+    k_, v_ = kv.split('=')
+    os.environ[k_] = v_
 
 import torch                                            # noqa: E402
 from flowmol_amd import _lib, presets, weights          # noqa: E402
@@ -57,6 +62,6 @@ for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj
     ms, cnt = eng.profile_get(k)
     if cnt:
         kern[k] = round(ms * 1e3 / cnt, 1)
-print(json.dumps({'lib': Path(lib_path).name, 'tile_edge': int(te), 'tile_node': int(tn), 'mols': B, 'eval_ms': round(wall, 2),
+print(json.dumps({'lib': Path(lib_path).name, 'tile_edge': int(te), 'tile_node': int(tn), 'tile_eupd': os.environ.get('FM_TILE_EUPD', '32'), 'env': {k: v for k, v in os.environ.items() if k.startswith('FM_')}, 'mols': B, 'eval_ms': round(wall, 2),
                   'mol_per_s_at_250': round(B / (250 * wall / 1e3), 2), 'kernels_us': kern,
                   'parity_out_rel': {k: float(f'{v:.2e}') for k, v in errs.items()}}))
