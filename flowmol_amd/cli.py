@@ -1,0 +1,110 @@
+"""Sampling CLI: the MI355X counterpart of the reference's ``test.py`` (reference test.py:17-55,99-259).
+
+    python -m flowmol_amd.cli --model_dir <dir> | --checkpoint <ckpt> | --preset flowmol3
+        [--n_mols 100] [--n_atoms_per_mol N] [--n_timesteps 250] [--max_batch_size 128]
+        [--xt_traj] [--ep_traj] [--stochasticity eta] [--hc_thresh p] [--seed s] [--output_file out.sdf]
+
+Writes an SDF of the sampled molecules (V2000 blocks written without RDKit; RDKit's writer is used when RDKit
+is installed), or with --xt_traj / --ep_traj one ``<stem>_<i>_xt.sdf`` / ``<stem>_<i>_ep.sdf`` per molecule.
+``--metrics`` (RDKit / PoseBusters analysis) is outside the hot path and not implemented.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import time
+from pathlib import Path
+
+import torch
+
+from .model import FlowMol
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='FlowMol3 sampling on MI355X')
+    p.add_argument('--model_dir', type=Path, default=None, help='model directory holding checkpoints/last.ckpt')
+    p.add_argument('--checkpoint', type=Path, default=None, help='path to a Lightning checkpoint')
+    p.add_argument('--preset', type=str, default=None, help='architecture preset with synthetic weights (flowmol3, geom_ctmc, qm9)')
+    p.add_argument('--output_file', type=Path, default=None)
+    p.add_argument('--n_mols', type=int, default=100)
+    p.add_argument('--n_atoms_per_mol', type=int, default=None)
+    p.add_argument('--n_timesteps', type=int, default=250)
+    p.add_argument('--xt_traj', action='store_true')
+    p.add_argument('--ep_traj', action='store_true')
+    p.add_argument('--metrics', action='store_true')
+    p.add_argument('--max_batch_size', type=int, default=128)
+    p.add_argument('--stochasticity', type=float, default=None)
+    p.add_argument('--hc_thresh', type=float, default=None)
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--device', type=str, default='cuda:0')
+    args = p.parse_args(argv)
+    if sum(x is not None for x in (args.model_dir, args.checkpoint, args.preset)) != 1:
+        raise ValueError('specify exactly one of --model_dir, --checkpoint, --preset')
+    if args.hc_thresh is not None and not (0 <= args.hc_thresh <= 1):
+        raise ValueError('hc_thresh must be on the interval [0, 1]')
+    if args.metrics:
+        raise NotImplementedError('--metrics needs RDKit/PoseBusters and is outside the MI355X hot path (SURVEY.md §8)')
+    return args
+
+
+def load_model(args, engine_lib=None) -> FlowMol:
+    kw = {'_engine_lib': engine_lib} if engine_lib is not None else {}
+    if args.preset is not None:
+        return FlowMol.from_preset(args.preset, **kw)
+    ckpt = args.checkpoint if args.checkpoint is not None else args.model_dir / 'checkpoints' / 'last.ckpt'
+    return FlowMol.load_from_checkpoint(ckpt, **kw)
+
+
+def write_sdf(path: Path, blocks):
+    with open(path, 'w') as f:
+        for b in blocks:
+            f.write(b)
+            f.write('$$$$\n')
+
+
+def run(args, engine_lib=None):
+    if args.seed is not None:
+        torch.manual_seed(args.seed)        # the reference uses lightning's seed_everything (test.py:70-71)
+    model = load_model(args, engine_lib).to(args.device).eval()
+    molecules = []
+    n_batches = math.ceil(args.n_mols / args.max_batch_size)
+    start = time.time()
+    for _ in range(n_batches):
+        bs = min(args.n_mols - len(molecules), args.max_batch_size)
+        common = dict(device=args.device, n_timesteps=args.n_timesteps, xt_traj=args.xt_traj, ep_traj=args.ep_traj,
+                      stochasticity=args.stochasticity, high_confidence_threshold=args.hc_thresh)
+        if args.n_atoms_per_mol is None:
+            molecules.extend(model.sample_random_sizes(bs, **common))
+        else:
+            molecules.extend(model.sample(torch.full((bs,), args.n_atoms_per_mol, dtype=torch.long), **common))
+    sampling_time = time.time() - start
+    if args.output_file is not None:
+        out = args.output_file
+    else:
+        base = args.model_dir if args.model_dir is not None else Path('.')
+        out = base / 'samples' / 'sampled_mols.sdf'
+    out.parent.mkdir(parents=True, exist_ok=True)
+    if out.suffix != '.sdf':
+        raise ValueError('output file must be an sdf file')
+    if not (args.xt_traj or args.ep_traj):
+        print(f'Writing molecules to {out}')
+        write_sdf(out, [m.to_sdf_block() for m in molecules])
+    else:
+        print('Trajectories requested, writing a separate output file for each molecule trajectory')
+        for i, m in enumerate(molecules):
+            if args.xt_traj:
+                write_sdf(out.parent / f'{out.stem}_{i}_xt{out.suffix}', m.traj_mol_blocks(ep_traj=False))
+            if args.ep_traj:
+                write_sdf(out.parent / f'{out.stem}_{i}_ep{out.suffix}', m.traj_mol_blocks(ep_traj=True))
+        print(f'All molecules written to {out.parent}')
+    print(f'sampling_time: {sampling_time:.3f} s for {len(molecules)} molecules '
+          f'({len(molecules) / sampling_time:.2f} molecules/s at {args.n_timesteps} timesteps)')
+    return molecules, sampling_time
+
+
+def main(argv=None):
+    run(parse_args(argv))
+
+
+if __name__ == '__main__':
+    main()

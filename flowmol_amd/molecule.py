@@ -98,9 +98,37 @@ class SampledMolecule:
                                tf['e' + sfx][frame_idx].long(), self.atom_type_map_in, self.fake_atoms, self.n_bond_types,
                                show_fake_atoms=True)
 
+    def traj_mol_blocks(self, ep_traj: bool = False, align: bool = True) -> List[str]:
+        """One V2000 mol block per trajectory frame, fake atoms shown as Sn and masked atoms as Se, positions
+        rigidly aligned to the final frame (reference process_traj_frames, molecule_builder.py:156-214)."""
+        tf = self.traj_frames
+        key = 'x_1_pred' if ep_traj else 'x'
+        n_frames = int(tf[key].shape[0])
+        x_final = tf[key][-1]
+        blocks = []
+        for f in range(n_frames):
+            pos, sym, chg, bt, bs, bd = self.frame_moldata(f, ep_traj=ep_traj)
+            if align:
+                pos = rigid_alignment(pos, x_final)
+            blocks.append(mol_block(pos, sym, chg, bs, bd, bt, name=f'frame {f}'))
+        return blocks
+
     def to_sdf_block(self) -> str:
         """V2000 mol block without RDKit (atoms, formal charges, bond orders)."""
         return mol_block(self.positions, self.atom_types, self.atom_charges, self.bond_src_idxs, self.bond_dst_idxs, self.bond_types)
+
+
+def rigid_alignment(x_0: torch.Tensor, x_1: torch.Tensor) -> torch.Tensor:
+    """Kabsch alignment of x_0 onto x_1 (same algorithm as reference flowmol/data_processing/priors.py:128-169):
+    centre both, R from the SVD of the covariance, move x_0 into x_1's frame."""
+    assert x_0.shape == x_1.shape
+    m0 = x_0.mean(dim=0, keepdim=True)
+    m1 = x_1.mean(dim=0, keepdim=True)
+    a, b = x_0 - m0, x_1 - m1
+    U, S, V = torch.svd(a.T.mm(b))
+    R = V.mm(U.T)
+    t = m1 - R.mm(m0.T).T
+    return a.mm(R.T) + m0 + t
 
 
 def build_rdkit_mol(positions, atom_types, atom_charges, bond_src, bond_dst, bond_types):

@@ -148,3 +148,15 @@ def test_lpt_partition_and_packing():
     x = torch.randn(N, 3); a = torch.randint(0, 12, (N,)); c = torch.randint(0, 7, (N,)); e = torch.randint(0, 5, (U,))
     got = unpack_results(pack_results(x, a, c, e), N, U)
     assert torch.equal(got['x'], x) and torch.equal(got['a'].long(), a) and torch.equal(got['e'].long(), e)
+
+
+def test_rigid_alignment_recovers_rotation():
+    from flowmol_amd.molecule import rigid_alignment
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(12, 3, generator=g)
+    x = x - x.mean(0, keepdim=True)       # trajectory frames are COM-free; for x_0 with a non-zero mean the reference's
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))   # formula (priors.py:163-167) adds m0 - R m0 on top -- reproduced, not fixed
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    y = x @ q.T + torch.tensor([1.0, -2.0, 0.5])
+    assert torch.allclose(rigid_alignment(x, y), y, atol=1e-5)
