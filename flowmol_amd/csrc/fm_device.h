@@ -43,8 +43,7 @@ __device__ unsigned long long fm_tlog[64];
 #endif
 
 #define FM_TM 64          // rows per workgroup tile of the non-GVP kernels (MLPs, edge update, projections)
-#define FM_THREADS 512    // 8 waves
-#define FM_WAVES 8
+#define FM_THREADS 512    // threads per workgroup of the non-GVP kernels (8 waves)
 #define FM_LDX 300        // scalar tile leading dim: >= 296, (300/4)=75 odd
 #define FM_LDG 33         // gate tile leading dim
 
@@ -128,22 +127,30 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
     const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
     const float2* wp = Wp + (size_t)nt0 * 64 + lane;
     const size_t wstep = (size_t)ntiles * 64;
-    float2 a0[MT], b0[NT], a1[MT], b1[NT];
-    // sched_barrier(0) pins "request step k+1, then issue the MFMAs of step k": without it hipcc's scheduler sinks
-    // every load down to its first use (s_waitcnt vmcnt(0) right behind the global_load) and the pipelining is lost.
+    // Three register sets, prefetch distance 2: while the MFMAs of step k issue, the fragments of steps k+1 and k+2
+    // are in flight (measured on MI355X: a fully unrolled variant with distance 2/4/6 was 2/7/12 % slower).  sched_barrier(0) pins "request, then issue": without it hipcc's scheduler sinks every load down
+    // to its first use (s_waitcnt vmcnt(0) right behind the global_load) and the pipelining is lost.
+    float2 a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
     fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, 0);
+    if (K8 > 1) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, 1);
     int ks = 0;
-    for (; ks + 2 <= K8; ks += 2) {
-        fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 1);
+    for (; ks + 3 <= K8; ks += 3) {
+        if (ks + 2 < K8) fm_frag_load<MT, NT>(a2, b2, ap, lda, wp, wstep, ks + 2);
         __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < K8) fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, ks + 2);
+        if (ks + 3 < K8) fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, ks + 3);
         __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        if (ks + 4 < K8) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        fm_frag_mma<MT, NT>(acc, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // tail: K8 - ks in {0, 1, 2} steps are already loaded in (a0,b0), (a1,b1)
     if (ks < K8) fm_frag_mma<MT, NT>(acc, a0, b0);
+    if (ks + 1 < K8) fm_frag_mma<MT, NT>(acc, a1, b1);
 }
 
 // Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
@@ -198,7 +205,8 @@ __device__ __forceinline__ void fm_block_gemm(const float* X, int ldx, int mtile
                                               const float2* __restrict__ Wp, int ntiles, Epi epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sm = mtiles / MT, sn = ntiles / NT;
-    for (int st = wave; st < sm * sn; st += FM_WAVES) {
+    const int nwaves = (int)(blockDim.x >> 6);
+    for (int st = wave; st < sm * sn; st += nwaves) {
         const int m0 = (st / sn) * MT, n0 = (st % sn) * NT;
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -250,11 +258,13 @@ struct FmGvpTile {
 // State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
 // `pre`: per-accumulator-element addend of the scalar linear (fm_gather_pre / fm_zero_pre); the bias is added here.
 // All 512 threads must call it (it contains barriers); it ends with a barrier.
-template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM>
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
-                                            float (&pre)[TM / 16][2][4] FM_MARK_ARG) {
+                                            float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
     typedef FmGvpTile<V, TM> T;
     constexpr int MT = TM / 16;                          // row tiles of the scalar GEMM
+    constexpr int NW = NTH / 64;                         // waves per workgroup
+    constexpr int NTW = 16 / NW;                         // column tiles of the scalar GEMM per wave (16 tiles = 256 columns)
     constexpr int H = FIRST ? V + 1 : V;                 // hidden vector channels
     constexpr int SOFF = FIRST ? 160 : 256;              // where sh goes in X
     constexpr int K8S = (SOFF + V + 8) / 8;
@@ -273,6 +283,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // (a,b) = Vcp[0..3], Vcp[4..7] (gvp.py:105-112), store them at columns H..H+3 of Vh (each thread touches
     // only its own columns) and their norms into X; (b) all threads compute the norms sh of the H plain hidden
     // channels (gvp.py:116, _norm_no_nan clamp) -> X[:, SOFF..SOFF+H) and clear the K padding of X.
+    static_assert(TM * 4 <= NTH, "cross-product phase needs 4 threads per row");
     if (tid < TM * 4) {
         const int r = tid >> 2, p = tid & 3;
         float a[3], b[3];
@@ -293,7 +304,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
         X[r * FM_LDX + SOFF + H + p] = fm_norm3(cx, cy, cz);
     }
-    for (int idx = tid; idx < TM * (V + 8); idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * (V + 8); idx += NTH) {
         const int r = idx / (V + 8), c = idx % (V + 8);
         if (c < H) {
             const float vx = Vh[(0 * TM + r) * T::LDVH + c];
@@ -309,31 +320,31 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // Vu = Vh_full * Wu -> Vin (the input vectors are dead by now)
     fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * TM / 16, T::KU / 8, w.Wu, VOP / 16,
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
-    // scalar linear: 64 x K -> 256, wave w owns column tiles 2w, 2w+1 for all 4 row tiles
+    // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     {
-        f32x4 acc[MT][2];
+        f32x4 acc[MT][NTW];
         // `pre` holds what is added to the linear output besides the MFMA result: the caller's per-element addend
         // (the hoisted W_s*s[src] term of the first edge GVP, requested long before so its latency is hidden; zeros
         // otherwise) plus the bias.
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float bias = w.bs[(2 * wave + j) * 16 + (lane & 15)];
+            for (int j = 0; j < NTW; ++j) {
+                const float bias = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pre[i][j][r] += bias;
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         FM_MARKB(2);
-        fm_wave_gemm<MT, 2>(acc, X, FM_LDX, K8S, w.Ws, 16, 2 * wave, lane);
+        fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = (2 * wave + j) * 16 + (lane & 15);
+            for (int j = 0; j < NTW; ++j) {
+                const int col = (NTW * wave + j) * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = i * 16 + 4 * (lane >> 4) + r;
@@ -344,7 +355,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     }
     FM_MARKB(5);
     // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128): (TM/16) x (VOP/16) single-tile jobs, K = 256
-    for (int job = wave; job < (TM / 16) * (VOP / 16); job += FM_WAVES) {
+    for (int job = wave; job < (TM / 16) * (VOP / 16); job += NW) {
         const int m0 = job / (VOP / 16), n0 = job % (VOP / 16);
         const f32x4 g = fm_wave_gemm_1x1<32, 8>(X + (size_t)m0 * 16 * FM_LDX, FM_LDX, w.Wg, VOP / 16, n0, lane);
         const int col = n0 * 16 + (lane & 15);
@@ -357,7 +368,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     }
     FM_MARKB(6);
     __syncthreads();
-    for (int idx = tid; idx < 3 * TM * VOUT; idx += FM_THREADS) {
+    for (int idx = tid; idx < 3 * TM * VOUT; idx += NTH) {
         const int row = idx / VOUT, u = idx % VOUT;
         Vin[row * T::LDVI + u] *= G[(row % TM) * FM_LDG + u];
     }
@@ -366,8 +377,9 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 }
 
 // per-element addend of the first edge GVP's scalar linear: Ps[src[row]][col] for this lane's accumulator elements
-template <int TM>
-__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][2][4], const float* __restrict__ addend, const int* rows) {
+template <int TM, int NTH>
+__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, const int* rows) {
+    constexpr int NTW = 1024 / NTH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < TM / 16; ++i)
@@ -375,16 +387,16 @@ __device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][2][4], const
         for (int r = 0; r < 4; ++r) {
             const int ar = rows[i * 16 + 4 * (lane >> 4) + r];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                pre[i][j][r] = (ar >= 0) ? addend[(size_t)ar * 256 + (2 * wave + j) * 16 + (lane & 15)] : 0.f;
+            for (int j = 0; j < NTW; ++j)
+                pre[i][j][r] = (ar >= 0) ? addend[(size_t)ar * 256 + (NTW * wave + j) * 16 + (lane & 15)] : 0.f;
         }
 }
-template <int TM>
-__device__ __forceinline__ void fm_zero_pre(float (&pre)[TM / 16][2][4]) {
+template <int TM, int NTH>
+__device__ __forceinline__ void fm_zero_pre(float (&pre)[TM / 16][1024 / NTH][4]) {
 #pragma unroll
     for (int i = 0; i < TM / 16; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 1024 / NTH; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pre[i][j][r] = 0.f;
 }

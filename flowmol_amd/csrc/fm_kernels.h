@@ -315,8 +315,8 @@ struct FmMsgArgs {
     float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
 };
 
-template <int V, int TM>
-__global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
+template <int V, int TM, int NTH>
+__global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     typedef FmGvpTile<V, TM> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
@@ -331,11 +331,11 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
     const int e0 = tile * TM;
     FM_MARK_DECL
     // (A) the edge-feature rows depend only on the tile index: request them before anything else (HBM latency)
-    constexpr int NEF = TM * 32 / FM_THREADS;
+    constexpr int NEF = TM * 32 / NTH;
     float4 efv[NEF];
 #pragma unroll
     for (int k = 0; k < NEF; ++k) {
-        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        const int idx = tid + k * NTH, r = idx >> 5, c4 = idx & 31;
         efv[k] = (e0 + r < a.b.E) ? reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // (B) endpoints and geometry of the tile's edges
@@ -358,39 +358,55 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
     // (C) the hoisted per-source scalar term of GVP0 is only consumed after its scalar GEMM: request it now so that its
     //     L2 latency overlaps the fill below and the first phases of the GVP (VMEM returns in order, so a request
     //     placed right before the GEMM would stall the GEMM's first weight fragments behind it)
-    float pre[TM / 16][2][4];
-    fm_gather_pre<TM>(pre, a.Ps, m_src);
+    float pre[TM / 16][1024 / NTH][4];
+    fm_gather_pre<TM, NTH>(pre, a.Ps, m_src);
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
-    for (int idx = tid; idx < 3 * TM * (V + 16); idx += FM_THREADS) {
-        const int row = idx / (V + 16), col = idx % (V + 16);
-        const int c = row / TM, r = row % TM;
-        float val = 0.f;
-        if (m_src[r] >= 0) val = a.PV[((size_t)m_src[r] * 3 + c) * (V + 16) + col] + m_geo[4 * r + c] * a.w0[col];
-        Vh[row * T::LDVH + col] = val;
+    //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):
+    //     a branchy load-use-store loop serialises one L2 round trip per iteration (profiles/r01d: 37k cycles here).
+    {
+        constexpr int NV = 3 * TM * (V + 16) / NTH;
+        static_assert(3 * TM * (V + 16) % NTH == 0, "Vh fill must divide evenly");
+        float pv[NV], w0v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + k * NTH;
+            const int row = idx / (V + 16), col = idx % (V + 16);
+            const int c = row / TM, r = row % TM;
+            const int sidx = m_src[r];
+            pv[k] = a.PV[((size_t)(sidx < 0 ? 0 : sidx) * 3 + c) * (V + 16) + col];
+            w0v[k] = a.w0[col];
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + k * NTH;
+            const int row = idx / (V + 16), col = idx % (V + 16);
+            const int c = row / TM, r = row % TM;
+            Vh[row * T::LDVH + col] = (m_src[r] >= 0) ? pv[k] + m_geo[4 * r + c] * w0v[k] : 0.f;
+        }
     }
-    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
+    for (int idx = tid; idx < TM * 32; idx += NTH) {
         const int r = idx >> 5, k = idx & 31;
         X[r * FM_LDX + k] = (m_src[r] >= 0) ? fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NEF; ++k) {
-        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        const int idx = tid + k * NTH, r = idx >> 5, c4 = idx & 31;
         *reinterpret_cast<float4*>(X + r * FM_LDX + 32 + 4 * c4) = efv[k];   // ds_write_b128 (16-B aligned)
     }
     __syncthreads();
     FM_MARK(1);
-    fm_gvp_core<V, V, true, true, TM>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
-    fm_zero_pre<TM>(pre);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
-    fm_zero_pre<TM>(pre);
-    fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
+    fm_gvp_core<V, V, true, true, TM, NTH>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
+    fm_zero_pre<TM, NTH>(pre);
+    fm_gvp_core<V, V, false, true, TM, NTH>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
+    fm_zero_pre<TM, NTH>(pre);
+    fm_gvp_core<V, V, false, true, TM, NTH>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
 
     if (a.dbg_s) {
-        for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
+        for (int idx = tid; idx < TM * 256; idx += NTH) {
             const int r = idx >> 8, c = idx & 255;
             if (m_src[r] >= 0) a.dbg_s[(size_t)(e0 + r) * 256 + c] = X[r * FM_LDX + c];
         }
-        for (int idx = tid; idx < 3 * TM * V; idx += FM_THREADS) {
+        for (int idx = tid; idx < 3 * TM * V; idx += NTH) {
             const int row = idx / V, u = idx % V, c = row / TM, r = row % TM;
             if (m_src[r] >= 0) a.dbg_v[((size_t)(e0 + r) * 3 + c) * V + u] = Vin[row * T::LDVI + u];
         }
@@ -400,15 +416,15 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
     // destination ids and the column's TM values are first pulled into registers with independent LDS reads, the
     // running sums are then register-only (the first version walked the rows with dependent LDS reads: 15k cycles).
     const int ncols = 256 + 3 * V;
-    if (tid < ncols) {
-        const bool is_s = tid < 256;
-        const int vc = is_s ? 0 : (tid - 256) / V, vu = is_s ? 0 : (tid - 256) % V;     // vector column -> (xyz, channel)
+    for (int colx = tid; colx < ncols; colx += NTH) {
+        const bool is_s = colx < 256;
+        const int vc = is_s ? 0 : (colx - 256) / V, vu = is_s ? 0 : (colx - 256) % V;     // vector column -> (xyz, channel)
         int dsts[TM];
         float val[TM];
 #pragma unroll
         for (int r = 0; r < TM; ++r) dsts[r] = m_dst[r];
 #pragma unroll
-        for (int r = 0; r < TM; ++r) val[r] = is_s ? X[r * FM_LDX + tid] : Vin[(vc * TM + r) * T::LDVI + vu];
+        for (int r = 0; r < TM; ++r) val[r] = is_s ? X[r * FM_LDX + colx] : Vin[(vc * TM + r) * T::LDVI + vu];
         float run = 0.f;
 #pragma unroll
         for (int r = 0; r < TM; ++r) {
@@ -418,7 +434,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_message(FmMsgArgs a) {
                 const bool last = (r == TM - 1) || (dsts[r == TM - 1 ? r : r + 1] != d);
                 if (last) {
                     const int piece = tile - a.b.node_first_edge[d] / TM;
-                    if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + tid] = run;
+                    if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + colx] = run;
                     else a.part_v[(((size_t)d * a.b.P + piece) * 3 + vc) * V + vu] = run;
                     run = 0.f;
                 }
@@ -530,12 +546,12 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_zero_pre<TM>(pre);
-        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM>(pre);
-        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM>(pre);
-        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM, FM_THREADS>(pre);
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM, FM_THREADS>(pre);
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM, FM_THREADS>(pre);
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
     }
     for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
         const int r = idx >> 8, c = idx & 255, n = row0 + r;
@@ -580,12 +596,12 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_pos_update(FmPosArgs a) {
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_zero_pre<TM>(pre);
-        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM>(pre);
-        fm_gvp_core<V, V, false, true, TM>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM>(pre);
-        fm_gvp_core<V, 1, false, false, TM>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM, FM_THREADS>(pre);
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM, FM_THREADS>(pre);
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_zero_pre<TM, FM_THREADS>(pre);
+        fm_gvp_core<V, 1, false, false, TM, FM_THREADS>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
     }
     if (tid < TM * 3) {
         const int r = tid / 3, c = tid % 3, n = row0 + r;

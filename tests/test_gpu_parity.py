@@ -187,3 +187,48 @@ def test_full_size_properties():
     assert torch.allclose(o2['x'][:n], o1['x'][5 * n:6 * n], rtol=0, atol=1e-5)
     U = n * (n - 1) // 2
     assert torch.allclose(o2['e'][U:], o1['e'][3 * U:4 * U], rtol=0, atol=1e-5)
+
+
+def test_c5_mixed_sizes_trajectory_matches_oracle():
+    """BASELINE config C5 shape (geom_full_kekulized model, mixed 5-60 atoms, trajectory dump) at reduced T:
+    free-running trajectory with recorded noise vs the oracle, every frame."""
+    from flowmol_amd.engine import StepNoise, make_step_plan
+    cfg, sd, eng, orc = engine_for('geom_ctmc')
+    g = torch.Generator().manual_seed(0)
+    n_atoms = torch.randint(5, 61, (8,), generator=g)
+    batch = cpu_ref.build_batch(n_atoms)
+    torch.manual_seed(3)
+    prior = orc.sample_prior(batch)
+    T = 12
+    rec = cpu_ref.RecordingNoise()
+    with torch.no_grad():
+        ref, frames = orc.integrate(batch, prior, T, noise=rec, visualize=True)
+    eng.bind(n_atoms)
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    state = eng.prior_state(prior['x_0'])
+    pos = [0]
+
+    def noise_for_step(i, last):
+        nz, pos[0] = StepNoise.from_tape(rec.tape, pos[0], last, 'cuda:0')
+        return nz
+    traj = {'x': torch.zeros(T - 1, eng.N, 3, device='cuda:0'), 'a': torch.zeros(T - 1, eng.N, dtype=torch.int32, device='cuda:0'),
+            'e': torch.zeros(T - 1, eng.U, dtype=torch.int32, device='cuda:0'), 'x1': torch.zeros(T - 1, eng.N, 3, device='cuda:0')}
+    eng.integrate(state, plan, noise_for_step, chunk=5, traj=traj)
+    m = batch.upper_edge_mask
+    ref_x = torch.stack(frames['x'][1:])
+    ref_a = torch.stack([f.argmax(-1) for f in frames['a'][1:]])
+    ref_e = torch.stack([f[m].argmax(-1) for f in frames['e'][1:]])
+    ref_x1 = torch.stack(frames['x_1_pred'])
+    res = {'a_flips': int((traj['a'].cpu().long() != ref_a).sum()), 'e_flips': int((traj['e'].cpu().long() != ref_e).sum()),
+           'x_rel': float((traj['x'].cpu() - ref_x).abs().max() / ref_x.abs().max()),
+           'x1_rel': float((traj['x1'].cpu() - ref_x1).abs().max() / ref_x1.abs().max())}
+    _report('c5_traj', res)
+    assert res['a_flips'] == 0 and res['e_flips'] == 0 and res['x_rel'] < 1e-4 and res['x1_rel'] < 1e-4, res
+
+
+def test_cli_on_gpu(tmp_path):
+    from flowmol_amd import cli
+    args = cli.parse_args(['--preset', 'qm9', '--n_mols', '5', '--n_timesteps', '8', '--max_batch_size', '3', '--seed', '1',
+                           '--output_file', str(tmp_path / 'out.sdf')])
+    mols, t = cli.run(args)
+    assert len(mols) == 5 and (tmp_path / 'out.sdf').read_text().count('$$$$') == 5
