@@ -26,7 +26,24 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Profiling aid, compiled out unless -DFM_PHASE_TIMING: thread 0 of every workgroup accumulates the shader
 // cycles spent between consecutive FM_MARK(id) points into fm_tlog[id] (read back with fm_tlog_read, see
 // tools/phase_timing.py).  This is how profiles/r01c_phase_cycles_edge_message.json was produced.
-#ifdef FM_PHASE_TIMING
+#ifdef FM_TRACE
+// dev-only (-DFM_TRACE): absolute timestamps of selected marks per workgroup (first 16384 workgroups of launches with
+// more than 20000 workgroups, i.e. fm_k_edge_message) plus the hardware id, to see how the phases of workgroups that
+// share a CU line up (tools/trace_phases.py; profiles/r01e_trace_coresident.txt)
+__device__ unsigned long long fm_trace[16384 * 16];
+__device__ __forceinline__ int fm_trace_slot(int id) {
+    return id == 0 ? 0 : id == 1 ? 1 : id == 12 ? 2 : id == 13 ? 3 : id == 22 ? 4 : id == 23 ? 5 : id == 32 ? 6 : id == 33 ? 7 : id == 41 ? 8 : -1;
+}
+#define FM_MARK_DECL if (threadIdx.x == 0 && blockIdx.x < 16384 && gridDim.x > 20000) { \
+        fm_trace[blockIdx.x * 16 + 10] = __builtin_readcyclecounter(); \
+        fm_trace[blockIdx.x * 16 + 9] = ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11))) | \
+                                        ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32); }
+#define FM_MARK_ARG , int fm_tb_
+#define FM_MARK_PASS(b) , (b)
+#define FM_MARK(id) do { if (threadIdx.x == 0 && blockIdx.x < 16384 && gridDim.x > 20000) { const int sl_ = fm_trace_slot(id); \
+        if (sl_ >= 0) fm_trace[blockIdx.x * 16 + sl_] = __builtin_readcyclecounter(); } } while (0)
+#define FM_MARKB(k) FM_MARK(fm_tb_ + (k))
+#elif defined(FM_PHASE_TIMING)
 __device__ unsigned long long fm_tlog[64];
 #define FM_MARK_DECL unsigned long long fm_tl_ = __builtin_readcyclecounter();
 #define FM_MARK_ARG , unsigned long long& fm_tl_, int fm_tb_

@@ -803,6 +803,9 @@ int fm_batch_query(fm_ctx* c, void* stream, const char* name, int32_t* dst) {
     return FM_OK;
 }
 
+#ifdef FM_TRACE
+int fm_trace_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fm_trace), 16384 * 16 * 8); return 0; }
+#endif
 #ifdef FM_PHASE_TIMING
 // dev-only (not part of the ABI header): read / reset the phase-cycle accumulators of a -DFM_PHASE_TIMING build
 int fm_tlog_read(unsigned long long* out, int reset) {
