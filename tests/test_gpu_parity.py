@@ -52,7 +52,10 @@ def test_native_library_is_the_hip_build():
 @pytest.mark.parametrize('name,sizes,t,prev', [
     ('flowmol3', [5, 9, 12, 3, 2], 0.5, True),
     ('flowmol3', [5, 9, 12, 3, 2], 0.0, False),        # bootstrap: two evaluations
-    ('flowmol3', [70, 2, 47, 130], 0.3, True),         # destinations spanning several 64-edge tiles
+    ('flowmol3', [70, 2, 47, 130], 0.3, True),         # destinations spanning several edge tiles
+    ('flowmol3', [181, 2], 0.6, True),                 # largest GEOM molecule (7 pieces per destination) next to the smallest
+    ('flowmol3', [47], 0.2, True),                     # single-molecule batch
+    ('geom_ctmc', [2, 2, 2], 0.9, False),
     ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False),
     ('qm9', [18] * 8, 0.7, True),
 ])
