@@ -106,9 +106,26 @@ __device__ __forceinline__ float fm_norm3(float dx, float dy, float dz) {
 // ---------------------------------------------------------------------------------------------
 // wave-level GEMM: acc[MT][NT] += A(lds rows m0.., K) * Wp(cols of tiles nt0..nt0+NT-1)
 // ---------------------------------------------------------------------------------------------
+// Packed-weight fragment load through a buffer descriptor (raw_buffer_load_b64): the wave-uniform part of the address
+// (tile / k-superstep) travels in the SGPR soffset, the per-lane part is the constant VGPR voffset = lane*8, so the
+// unrolled GEMM loops contain no VALU address arithmetic at all.  That matters on gfx950: VALU instructions take issue
+// slots from the matrix pipe (tools/ubench/mfma_share.cpp: 4 VALU per 8 MFMAs cost 8 %, 16 cost 23 %, even with 4
+// waves per SIMD), and 64-bit flat addresses cost 2 VALU per load.
+__device__ __forceinline__ float2 fm_wload(const float2* __restrict__ base /*wave-uniform*/, int byte_off /*wave-uniform*/, int lane) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(base), (short)0, 0x7fffffff, 0x00020000);
+    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, byte_off, 0);
+    static_assert(sizeof(r) == 8, "raw_buffer_load_b64 must return two dwords");
+    const unsigned r0 = r[0], r1 = r[1];   // copy out first: __builtin_bit_cast on a vector-element lvalue reads element 0 (clang 19/ROCm 7.2)
+    float2 out;
+    out.x = __builtin_bit_cast(float, r0);
+    out.y = __builtin_bit_cast(float, r1);
+    return out;
+}
+
+// `wp` is the wave-uniform base of the wave's first column tile.
 template <int MT, int NT>
 __device__ __forceinline__ void fm_frag_load(float2 (&a)[MT], float2 (&b)[NT], const float* ap, int lda,
-                                             const float2* __restrict__ wp, size_t wstep, int ks) {
+                                             const float2* __restrict__ wp, size_t wstep, int ks, int lane) {
     // volatile LDS-address-space load: keeps each A fragment a single ds_read_b64 (conflict-free with (ld/4) odd, 256 B/clk).  Without it
     // hipcc pairs them into ds_read2_b64, which is serviced in 16-lane groups over 32 banks at half the rate and
     // 2-way conflicts on this layout (MI355X_MICROARCH.md LDS table; SQ_LDS_BANK_CONFLICT was 40 % of LDS cycles).
@@ -118,7 +135,7 @@ __device__ __forceinline__ void fm_frag_load(float2 (&a)[MT], float2 (&b)[NT], c
         a[mt].x = t[0]; a[mt].y = t[1];
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = wp[(size_t)ks * wstep + (size_t)nt * 64];
+    for (int nt = 0; nt < NT; ++nt) b[nt] = fm_wload(wp, (int)(((size_t)ks * wstep + (size_t)nt * 64) * sizeof(float2)), lane);
 }
 
 template <int MT, int NT>
@@ -142,25 +159,25 @@ template <int MT, int NT>
 __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* A, int lda, int K8,
                                              const float2* __restrict__ Wp, int ntiles, int nt0, int lane) {
     const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
-    const float2* wp = Wp + (size_t)nt0 * 64 + lane;
+    const float2* wp = Wp + (size_t)nt0 * 64;          // wave-uniform
     const size_t wstep = (size_t)ntiles * 64;
     // Three register sets, prefetch distance 2: while the MFMAs of step k issue, the fragments of steps k+1 and k+2
     // are in flight (measured on MI355X: a fully unrolled variant with distance 2/4/6 was 2/7/12 % slower).  sched_barrier(0) pins "request, then issue": without it hipcc's scheduler sinks every load down
     // to its first use (s_waitcnt vmcnt(0) right behind the global_load) and the pipelining is lost.
     float2 a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
-    fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, 0);
-    if (K8 > 1) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, 1);
+    fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, 0, lane);
+    if (K8 > 1) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, 1, lane);
     int ks = 0;
     for (; ks + 3 <= K8; ks += 3) {
-        if (ks + 2 < K8) fm_frag_load<MT, NT>(a2, b2, ap, lda, wp, wstep, ks + 2);
+        if (ks + 2 < K8) fm_frag_load<MT, NT>(a2, b2, ap, lda, wp, wstep, ks + 2, lane);
         __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 3 < K8) fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, ks + 3);
+        if (ks + 3 < K8) fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, ks + 3, lane);
         __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 4 < K8) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 4);
+        if (ks + 4 < K8) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 4, lane);
         __builtin_amdgcn_sched_barrier(0);
         fm_frag_mma<MT, NT>(acc, a2, b2);
         __builtin_amdgcn_sched_barrier(0);
@@ -180,7 +197,7 @@ __device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const
     static_assert(K8 % CH == 0 && CH % 2 == 0, "K8 must be a multiple of the (even) chunk size");
     constexpr int NCH = K8 / CH;
     const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
-    const float2* wp = Wp + (size_t)nt * 64 + lane;
+    const float2* wp = Wp + (size_t)nt * 64;            // wave-uniform
     const size_t wstep = (size_t)ntiles * 64;
     float2 a[2][CH], b[2][CH];
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -188,7 +205,7 @@ __device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const
     for (int q = 0; q < CH; ++q) {
         const f32x2 t = *(const volatile __attribute__((address_space(3))) f32x2*)(ap + 8 * q);
         a[0][q].x = t[0]; a[0][q].y = t[1];
-        b[0][q] = wp[(size_t)q * wstep];
+        b[0][q] = fm_wload(wp, (int)((size_t)q * wstep * sizeof(float2)), lane);
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -198,7 +215,7 @@ __device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const
                 const int ks = (c + 1) * CH + q;
                 const f32x2 t = *(const volatile __attribute__((address_space(3))) f32x2*)(ap + 8 * ks);
                 a[(c + 1) & 1][q].x = t[0]; a[(c + 1) & 1][q].y = t[1];
-                b[(c + 1) & 1][q] = wp[(size_t)ks * wstep];
+                b[(c + 1) & 1][q] = fm_wload(wp, (int)((size_t)ks * wstep * sizeof(float2)), lane);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -220,7 +237,7 @@ __device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const
 template <int MT, int NT, class Epi>
 __device__ __forceinline__ void fm_block_gemm(const float* X, int ldx, int mtiles, int K8,
                                               const float2* __restrict__ Wp, int ntiles, Epi epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: weight addresses become scalar
     const int sm = mtiles / MT, sn = ntiles / NT;
     const int nwaves = (int)(blockDim.x >> 6);
     for (int st = wave; st < sm * sn; st += nwaves) {
@@ -287,7 +304,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int K8S = (SOFF + V + 8) / 8;
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
     constexpr int CPSRC = FIRST ? V + 8 : V;             // where the 8 Vcp channels sit in Vh
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     if (!FIRST) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
@@ -397,7 +414,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 template <int TM, int NTH>
 __device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, const int* rows) {
     constexpr int NTW = 1024 / NTH;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: weight addresses become scalar
 #pragma unroll
     for (int i = 0; i < TM / 16; ++i)
 #pragma unroll

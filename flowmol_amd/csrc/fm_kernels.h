@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     int* m_src = reinterpret_cast<int*>(Hb + TM * LDH);
     int* m_dst = m_src + TM;
     float* m_d = reinterpret_cast<float*>(m_dst + TM);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, e0 = blockIdx.x * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), e0 = blockIdx.x * TM;
     if (tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1; float dist = 0.f;

@@ -110,7 +110,19 @@ static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, i
 // ---------------------------------------------------------------- device math
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+// buffer-descriptor loads: the descriptor is just the base pointer on the host
+struct emu_rsrc { const char* base; };
+static inline emu_rsrc emu_make_rsrc(void* p, short, int, int) { return emu_rsrc{static_cast<const char*>(p)}; }
+typedef unsigned emu_u32x2 __attribute__((ext_vector_type(2)));
+static inline emu_u32x2 emu_raw_buffer_load_b64(emu_rsrc r, int voff, int soff, int) {
+    emu_u32x2 v;
+    memcpy(&v, r.base + voff + soff, 8);
+    return v;
+}
+#define __builtin_amdgcn_make_buffer_rsrc emu_make_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b64 emu_raw_buffer_load_b64
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* value is wave-uniform by contract */
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
