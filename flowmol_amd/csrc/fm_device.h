@@ -111,15 +111,43 @@ __device__ __forceinline__ float fm_norm3(float dx, float dy, float dz) {
 // unrolled GEMM loops contain no VALU address arithmetic at all.  That matters on gfx950: VALU instructions take issue
 // slots from the matrix pipe (tools/ubench/mfma_share.cpp: 4 VALU per 8 MFMAs cost 8 %, 16 cost 23 %, even with 4
 // waves per SIMD), and 64-bit flat addresses cost 2 VALU per load.
-__device__ __forceinline__ float2 fm_wload(const float2* __restrict__ base /*wave-uniform*/, int byte_off /*wave-uniform*/, int lane) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(base), (short)0, 0x7fffffff, 0x00020000);
-    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, byte_off, 0);
+//
+// fm_buf(base, bytes) builds the descriptor (4 SGPRs) from a WAVE-UNIFORM base; the typed accessors take
+// (voffset: per-lane bytes, soffset: wave-uniform bytes).  Raw-buffer range checking is part of the contract:
+// an access with voffset (+ size) beyond `bytes` reads 0 / is dropped, which replaces compare+select pairs for
+// ragged tiles and invalid rows (callers pass FM_BUF_OOB as voffset for "no row").
+#define FM_BUF_OOB ((int)0x80000000)
+__device__ __forceinline__ auto fm_buf(const void* base, unsigned bytes = 0x7fffffffu) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+template <class R>
+__device__ __forceinline__ float fm_buf_f32(R rs, int voff, int soff) {
+    const unsigned r = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+    return __builtin_bit_cast(float, r);
+}
+template <class R>
+__device__ __forceinline__ float2 fm_buf_f32x2(R rs, int voff, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
     static_assert(sizeof(r) == 8, "raw_buffer_load_b64 must return two dwords");
     const unsigned r0 = r[0], r1 = r[1];   // copy out first: __builtin_bit_cast on a vector-element lvalue reads element 0 (clang 19/ROCm 7.2)
     float2 out;
     out.x = __builtin_bit_cast(float, r0);
     out.y = __builtin_bit_cast(float, r1);
     return out;
+}
+template <class R>
+__device__ __forceinline__ float4 fm_buf_f32x4(R rs, int voff, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    static_assert(sizeof(r) == 16, "raw_buffer_load_b128 must return four dwords");
+    const unsigned r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    return make_float4(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1), __builtin_bit_cast(float, r2), __builtin_bit_cast(float, r3));
+}
+template <class R>
+__device__ __forceinline__ void fm_buf_store_f32(R rs, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
+__device__ __forceinline__ float2 fm_wload(const float2* __restrict__ base /*wave-uniform*/, int byte_off /*wave-uniform*/, int lane) {
+    return fm_buf_f32x2(fm_buf(base), lane * 8, byte_off);
 }
 
 // `wp` is the wave-uniform base of the wave's first column tile.
@@ -290,7 +318,7 @@ struct FmGvpTile {
 //           X[r][0..159]          = [rbf(32) | ef(128)]
 //   !FIRST: Vin[xyz*TM+r][0..V-1] = input vectors,  X[r][0..255] = input scalars
 // State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
-// `pre`: per-accumulator-element addend of the scalar linear (fm_gather_pre / fm_zero_pre); the bias is added here.
+// `pre`: per-accumulator-element addend of the scalar linear, used by FIRST only (fm_gather_pre); the bias is added here.
 // All 512 threads must call it (it contains barriers); it ends with a barrier.
 template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
@@ -356,35 +384,30 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     {
+        // The accumulators start at bias (+ `pre` for the FIRST GVP of an edge tile: the hoisted W_s*s[src] term, requested
+        // long before so its latency is hidden) instead of zero: no separate add in the epilogue (VALU instructions cost
+        // matrix-pipe issue slots).
         f32x4 acc[MT][NTW];
-        // `pre` holds what is added to the linear output besides the MFMA result: the caller's per-element addend
-        // (the hoisted W_s*s[src] term of the first edge GVP, requested long before so its latency is hidden; zeros
-        // otherwise) plus the bias.
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NTW; ++j) {
+            const float bias = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const float bias = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre[i][j][r] += bias;
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = FIRST ? pre[i][j][r] + bias : bias;
+        }
         FM_MARKB(2);
         fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
+        float* xo = X + (4 * (lane >> 4)) * FM_LDX + NTW * wave * 16 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int col = (NTW * wave + j) * 16 + (lane & 15);
+            for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i * 16 + 4 * (lane >> 4) + r;
-                    X[row * FM_LDX + col] = fm_silu(acc[i][j][r] + pre[i][j][r]);
-                }
-            }
+                for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * FM_LDX + j * 16] = fm_silu(acc[i][j][r]);
         __syncthreads();
     }
     FM_MARKB(5);
@@ -410,29 +433,22 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     FM_MARKB(7);
 }
 
-// per-element addend of the first edge GVP's scalar linear: Ps[src[row]][col] for this lane's accumulator elements
+// per-element addend of the first edge GVP's scalar linear: addend[rows[row]][col] for this lane's accumulator elements
+// (rows[] < 0: no row -> 0, via the buffer range check).  `addend` is (nrows, 256) fp32.
 template <int TM, int NTH>
-__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, const int* rows) {
+__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, int nrows, const int* rows) {
     constexpr int NTW = 1024 / NTH;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index in an SGPR: weight addresses become scalar
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rs = fm_buf(addend, (unsigned)nrows * 1024u);
 #pragma unroll
     for (int i = 0; i < TM / 16; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ar = rows[i * 16 + 4 * (lane >> 4) + r];
+            const int voff = ar >= 0 ? ar * 1024 + (lane & 15) * 4 : FM_BUF_OOB;
 #pragma unroll
-            for (int j = 0; j < NTW; ++j)
-                pre[i][j][r] = (ar >= 0) ? addend[(size_t)ar * 256 + (NTW * wave + j) * 16 + (lane & 15)] : 0.f;
+            for (int j = 0; j < NTW; ++j) pre[i][j][r] = fm_buf_f32(rs, voff, (NTW * wave + j) * 64);
         }
-}
-template <int TM, int NTH>
-__device__ __forceinline__ void fm_zero_pre(float (&pre)[TM / 16][1024 / NTH][4]) {
-#pragma unroll
-    for (int i = 0; i < TM / 16; ++i)
-#pragma unroll
-        for (int j = 0; j < 1024 / NTH; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pre[i][j][r] = 0.f;
 }
 
 // LayerNorm statistics of one LDS row handled by a group of LPR consecutive lanes (LPR = 8 or 16):

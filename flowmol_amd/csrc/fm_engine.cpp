@@ -298,7 +298,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         // per-edge message taps are written straight into the caller's buffers (both must be registered)
         const bool dbg = taps_on && i == 0 && c->taps.count("conv0.msg.s") && c->taps.count("conv0.msg.v");
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
-        L("edge_message", fm_k_edge_message<V, TE, (TE == 16 ? 256 : 512)>, get, dim3(TE == 16 ? 256 : 512), lds_gvp(V, TE, true), m);
+        L("edge_message", fm_k_edge_message<V, TE, 512>, get, dim3(512), lds_gvp(V, TE, true), m);
         FmNodeUpdArgs nu{};
         nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
         nu.g0 = cw.upd[0]; nu.g1 = cw.upd[1]; nu.g2 = cw.upd[2];
@@ -346,8 +346,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
 
 int evaluate_dispatch(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out, bool taps_on) {
 #define FM_EVAL(V_, TE_, TN_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_) return evaluate<V_, TE_, TN_>(c, st, state, prev, remove_com, out, taps_on);
-    FM_EVAL(32, 16, 32) FM_EVAL(32, 32, 32) FM_EVAL(32, 32, 64) FM_EVAL(32, 64, 32) FM_EVAL(32, 64, 64)
-    FM_EVAL(16, 16, 32) FM_EVAL(16, 32, 32) FM_EVAL(16, 32, 64) FM_EVAL(16, 64, 32) FM_EVAL(16, 64, 64)
+    FM_EVAL(32, 32, 32) FM_EVAL(32, 32, 64) FM_EVAL(32, 64, 32) FM_EVAL(32, 64, 64)
+    FM_EVAL(16, 32, 32) FM_EVAL(16, 32, 64) FM_EVAL(16, 64, 32) FM_EVAL(16, 64, 64)
 #undef FM_EVAL
     return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d", c->V, c->tm_edge, c->tm_node);
 }
@@ -605,7 +605,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge = atoi(e1);
     if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node = atoi(e2);
     if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
-    if ((c->tm_edge != 16 && c->tm_edge != 32 && c->tm_edge != 64) || (c->tm_node != 32 && c->tm_node != 64) || (c->tm_edge == 16 && c->tm_node != 32)) {
+    if ((c->tm_edge != 32 && c->tm_edge != 64) || (c->tm_node != 32 && c->tm_node != 64)) {
         (void)hipFree(c->arena); delete c;
         return fail(nullptr, FM_ERR_INVALID, "fm_create: FM_TILE_EDGE / FM_TILE_NODE must be 32 or 64");
     }
@@ -613,7 +613,6 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
     FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
-    set_lds(fm_k_edge_message<32, 16, 256>, lds_gvp(32, 16, true)); set_lds(fm_k_edge_message<16, 16, 256>, lds_gvp(16, 16, true));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_edge_update<32>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64>, lds_edge_upd(64));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);

@@ -333,10 +333,11 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // (A) the edge-feature rows depend only on the tile index: request them before anything else (HBM latency)
     constexpr int NEF = TM * 32 / NTH;
     float4 efv[NEF];
+    {
+        const int left = a.b.E - e0;                         // rows of this tile that exist (ragged last tile: the range check zero-fills)
+        const auto rs = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
 #pragma unroll
-    for (int k = 0; k < NEF; ++k) {
-        const int idx = tid + k * NTH, r = idx >> 5, c4 = idx & 31;
-        efv[k] = (e0 + r < a.b.E) ? reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs, tid * 16 + k * NTH * 16, 0);
     }
     // (B) endpoints and geometry of the tile's edges
     if (tid < TM) {
@@ -359,29 +360,29 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     //     L2 latency overlaps the fill below and the first phases of the GVP (VMEM returns in order, so a request
     //     placed right before the GEMM would stall the GEMM's first weight fragments behind it)
     float pre[TM / 16][1024 / NTH][4];
-    fm_gather_pre<TM, NTH>(pre, a.Ps, m_src);
+    fm_gather_pre<TM, NTH>(pre, a.Ps, a.b.N, m_src);
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):
     //     a branchy load-use-store loop serialises one L2 round trip per iteration (profiles/r01d: 37k cycles here).
     {
-        constexpr int NV = 3 * TM * (V + 16) / NTH;
-        static_assert(3 * TM * (V + 16) % NTH == 0, "Vh fill must divide evenly");
-        float pv[NV], w0v[NV];
+        // thread -> (row chunk q, column j of a 16-wide block); chunk = (xyz c, block cb, row r).  With TM*16 == NTH the
+        // chunk's (c, cb) is the unrolled loop index and r = q, so every address is one VGPR + an immediate.
+        constexpr int CB = (V + 16) / 16, NCH = 3 * CB * TM, QN = NTH / 16, NP = NCH / QN;
+        static_assert(NCH % QN == 0, "Vh fill must divide evenly");
+        const int q = tid >> 4, j = tid & 15;
+        const auto rs = fm_buf(a.PV, (unsigned)a.b.N * (unsigned)(3 * (V + 16) * 4));
+        float pv[NP], w0v[NP];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int idx = tid + k * NTH;
-            const int row = idx / (V + 16), col = idx % (V + 16);
-            const int c = row / TM, r = row % TM;
+        for (int p_ = 0; p_ < NP; ++p_) {
+            const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
             const int sidx = m_src[r];
-            pv[k] = a.PV[((size_t)(sidx < 0 ? 0 : sidx) * 3 + c) * (V + 16) + col];
-            w0v[k] = a.w0[col];
+            pv[p_] = fm_buf_f32(rs, sidx >= 0 ? sidx * (3 * (V + 16) * 4) + j * 4 : FM_BUF_OOB, (c * (V + 16) + cb * 16) * 4);
+            w0v[p_] = a.w0[cb * 16 + j];
         }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int idx = tid + k * NTH;
-            const int row = idx / (V + 16), col = idx % (V + 16);
-            const int c = row / TM, r = row % TM;
-            Vh[row * T::LDVH + col] = (m_src[r] >= 0) ? pv[k] + m_geo[4 * r + c] * w0v[k] : 0.f;
+        for (int p_ = 0; p_ < NP; ++p_) {
+            const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
+            Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = (m_src[r] >= 0) ? pv[p_] + m_geo[4 * r + c] * w0v[p_] : 0.f;
         }
     }
     for (int idx = tid; idx < TM * 32; idx += NTH) {
@@ -396,9 +397,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     __syncthreads();
     FM_MARK(1);
     fm_gvp_core<V, V, true, true, TM, NTH>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
-    fm_zero_pre<TM, NTH>(pre);
     fm_gvp_core<V, V, false, true, TM, NTH>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
-    fm_zero_pre<TM, NTH>(pre);
     fm_gvp_core<V, V, false, true, TM, NTH>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
 
     if (a.dbg_s) {
@@ -415,29 +414,37 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // segmented sum over the rows of each destination (rows are dst-sorted).  One thread per output column; the
     // destination ids and the column's TM values are first pulled into registers with independent LDS reads, the
     // running sums are then register-only (the first version walked the rows with dependent LDS reads: 15k cycles).
-    const int ncols = 256 + 3 * V;
-    for (int colx = tid; colx < ncols; colx += NTH) {
-        const bool is_s = colx < 256;
-        const int vc = is_s ? 0 : (colx - 256) / V, vu = is_s ? 0 : (colx - 256) % V;     // vector column -> (xyz, channel)
-        int dsts[TM];
-        float val[TM];
+    // The destination ids are wave-uniform (scalar loads, scalar compares/branches); a wave holds either scalar or
+    // vector columns, so the only per-lane work is the LDS reads, the adds and the (rare) stores.
+    static_assert(NTH == 512 && 3 * V <= 128, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
+    {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int* __restrict__ edst = a.b.e_dst;
+        const int* __restrict__ nfe = a.b.node_first_edge;
+        const bool is_s = wave < 4;                                       // columns 0..255: scalars
+        const int cv = tid - 256;                                         // vector column = xyz*V + channel
+        if (is_s || cv < 3 * V) {
+            const float* vp = is_s ? X + tid : Vin + (cv / V) * TM * T::LDVI + (cv % V);
+            const int vstride = is_s ? FM_LDX : T::LDVI;
+            float val[TM];
 #pragma unroll
-        for (int r = 0; r < TM; ++r) dsts[r] = m_dst[r];
+            for (int r = 0; r < TM; ++r) val[r] = vp[r * vstride];
+            float run = 0.f;
+            int d = e0 < a.b.E ? edst[e0] : -1;
 #pragma unroll
-        for (int r = 0; r < TM; ++r) val[r] = is_s ? X[r * FM_LDX + colx] : Vin[(vc * TM + r) * T::LDVI + vu];
-        float run = 0.f;
-#pragma unroll
-        for (int r = 0; r < TM; ++r) {
-            const int d = dsts[r];
-            if (d >= 0) {
-                run += val[r];
-                const bool last = (r == TM - 1) || (dsts[r == TM - 1 ? r : r + 1] != d);
-                if (last) {
-                    const int piece = tile - a.b.node_first_edge[d] / TM;
-                    if (is_s) a.part_s[((size_t)d * a.b.P + piece) * 256 + colx] = run;
-                    else a.part_v[(((size_t)d * a.b.P + piece) * 3 + vc) * V + vu] = run;
-                    run = 0.f;
+            for (int r = 0; r < TM; ++r) {
+                const int dn = (r + 1 < TM && e0 + r + 1 < a.b.E) ? edst[e0 + r + 1] : -1;    // next row's destination (uniform)
+                if (d >= 0) {
+                    run += val[r];
+                    if (dn != d) {
+                        const int piece = tile - nfe[d] / TM;
+                        const size_t slot = (size_t)d * a.b.P + piece;
+                        if (is_s) fm_buf_store_f32(fm_buf(a.part_s + slot * 256, 1024u), tid * 4, 0, run);
+                        else fm_buf_store_f32(fm_buf(a.part_v + slot * 3 * V, 3 * V * 4u), cv * 4, 0, run);
+                        run = 0.f;
+                    }
                 }
+                d = dn;
             }
         }
     }
@@ -546,11 +553,8 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_zero_pre<TM, FM_THREADS>(pre);
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM, FM_THREADS>(pre);
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM, FM_THREADS>(pre);
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
     }
     for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
@@ -596,11 +600,8 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_pos_update(FmPosArgs a) {
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_zero_pre<TM, FM_THREADS>(pre);
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM, FM_THREADS>(pre);
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_zero_pre<TM, FM_THREADS>(pre);
         fm_gvp_core<V, 1, false, false, TM, FM_THREADS>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
     }
     if (tid < TM * 3) {

@@ -110,17 +110,36 @@ static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, i
 // ---------------------------------------------------------------- device math
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-// buffer-descriptor loads: the descriptor is just the base pointer on the host
-struct emu_rsrc { const char* base; };
-static inline emu_rsrc emu_make_rsrc(void* p, short, int, int) { return emu_rsrc{static_cast<const char*>(p)}; }
+// buffer-descriptor accesses: base pointer + byte count; raw-buffer range checking like the hardware's
+// (an access whose voffset+imm range leaves [0, num_records) reads 0 / is dropped; soffset is not range-checked)
+struct emu_rsrc { char* base; unsigned num_records; };
+static inline emu_rsrc emu_make_rsrc(void* p, short, int n, int) { return emu_rsrc{static_cast<char*>(p), (unsigned)n}; }
 typedef unsigned emu_u32x2 __attribute__((ext_vector_type(2)));
-static inline emu_u32x2 emu_raw_buffer_load_b64(emu_rsrc r, int voff, int soff, int) {
-    emu_u32x2 v;
-    memcpy(&v, r.base + voff + soff, 8);
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
+static inline bool emu_buf_ok(const emu_rsrc& r, int voff, unsigned bytes) { return (unsigned long long)(unsigned)voff + bytes <= r.num_records; }
+static inline unsigned emu_raw_buffer_load_b32(emu_rsrc r, int voff, int soff, int) {
+    unsigned v = 0;
+    if (emu_buf_ok(r, voff, 4)) memcpy(&v, r.base + (unsigned)voff + (unsigned)soff, 4);
     return v;
 }
+static inline emu_u32x2 emu_raw_buffer_load_b64(emu_rsrc r, int voff, int soff, int) {
+    emu_u32x2 v = {0u, 0u};
+    if (emu_buf_ok(r, voff, 8)) memcpy(&v, r.base + (unsigned)voff + (unsigned)soff, 8);
+    return v;
+}
+static inline emu_u32x4 emu_raw_buffer_load_b128(emu_rsrc r, int voff, int soff, int) {
+    emu_u32x4 v = {0u, 0u, 0u, 0u};
+    if (emu_buf_ok(r, voff, 16)) memcpy(&v, r.base + (unsigned)voff + (unsigned)soff, 16);
+    return v;
+}
+static inline void emu_raw_buffer_store_b32(unsigned d, emu_rsrc r, int voff, int soff, int) {
+    if (emu_buf_ok(r, voff, 4)) memcpy(r.base + (unsigned)voff + (unsigned)soff, &d, 4);
+}
 #define __builtin_amdgcn_make_buffer_rsrc emu_make_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b32 emu_raw_buffer_load_b32
 #define __builtin_amdgcn_raw_buffer_load_b64 emu_raw_buffer_load_b64
+#define __builtin_amdgcn_raw_buffer_load_b128 emu_raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_store_b32 emu_raw_buffer_store_b32
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* value is wave-uniform by contract */
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
