@@ -190,7 +190,7 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
     const float2* wp = Wp + (size_t)nt0 * 64;          // wave-uniform
     const size_t wstep = (size_t)ntiles * 64;
     // Three register sets, prefetch distance 2: while the MFMAs of step k issue, the fragments of steps k+1 and k+2
-    // are in flight (measured on MI355X: a fully unrolled variant with distance 2/4/6 was 2/7/12 % slower).  sched_barrier(0) pins "request, then issue": without it hipcc's scheduler sinks every load down
+    // are in flight (measured on MI355X: a fully unrolled variant with distance 2/4/6 was 2/7/12 % slower; distance 3 with four sets and buffer loads: no change).  sched_barrier(0) pins "request, then issue": without it hipcc's scheduler sinks every load down
     // to its first use (s_waitcnt vmcnt(0) right behind the global_load) and the pipelining is lost.
     float2 a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
     fm_frag_load<MT, NT>(a0, b0, ap, lda, wp, wstep, 0, lane);
@@ -222,12 +222,12 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
 // steps) break the 40-cycle dependent-accumulator chain; they are added at the end.
 template <int K8, int CH>
 __device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const float2* __restrict__ Wp, int ntiles, int nt, int lane) {
-    static_assert(K8 % CH == 0 && CH % 2 == 0, "K8 must be a multiple of the (even) chunk size");
+    static_assert(K8 % CH == 0, "K8 must be a multiple of the chunk size");
     constexpr int NCH = K8 / CH;
     const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
     const float2* wp = Wp + (size_t)nt * 64;            // wave-uniform
     const size_t wstep = (size_t)ntiles * 64;
-    float2 a[2][CH], b[2][CH];
+    float2 a[NCH > 1 ? 2 : 1][CH], b[NCH > 1 ? 2 : 1][CH];
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
@@ -248,11 +248,15 @@ __device__ __forceinline__ f32x4 fm_wave_gemm_1x1(const float* A, int lda, const
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < CH; q += 2) {
+        for (int q = 0; q + 1 < CH; q += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q].x, b[c & 1][q].x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q + 1].x, b[c & 1][q + 1].x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q].y, b[c & 1][q].y, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][q + 1].y, b[c & 1][q + 1].y, acc1, 0, 0, 0);
+        }
+        if (CH & 1) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][CH - 1].x, b[c & 1][CH - 1].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][CH - 1].y, b[c & 1][CH - 1].y, acc1, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -333,6 +337,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
     constexpr int CPSRC = FIRST ? V + 8 : V;             // where the 8 Vcp channels sit in Vh
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // biases of this lane's accumulator columns, requested first: their L2 latency hides behind the vector phases
+    float bias_s[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bias_s[j] = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
+    const float bias_g = w.bg[(wave % (VOP / 16)) * 16 + (lane & 15)];   // gate job `wave` has column tile wave % (VOP/16)
 
     if (!FIRST) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
@@ -390,7 +399,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         f32x4 acc[MT][NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-            const float bias = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
+            const float bias = bias_s[j];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -416,7 +425,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         const int m0 = job / (VOP / 16), n0 = job % (VOP / 16);
         const f32x4 g = fm_wave_gemm_1x1<32, 8>(X + (size_t)m0 * 16 * FM_LDX, FM_LDX, w.Wg, VOP / 16, n0, lane);
         const int col = n0 * 16 + (lane & 15);
-        const float bg = w.bg[col];
+        const float bg = (job == wave) ? bias_g : w.bg[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = g[r] + bg;

@@ -325,7 +325,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     float* G = Vh + T::VH_FLOATS;
     int* m_src = reinterpret_cast<int*>(G + T::G_FLOATS);   // [64]
     int* m_dst = m_src + TM;                              // [64]
-    float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [64][4]: xhat(3), dist
+    float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [TM][4]: xhat(3), dist
+    int* m_piece = reinterpret_cast<int*>(m_geo + 4 * TM); // [TM] which partial-sum slot of its destination the row adds to
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
     const int e0 = tile * TM;
@@ -342,16 +343,17 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // (B) endpoints and geometry of the tile's edges
     if (tid < TM) {
         const int e = e0 + tid;
-        int s = -1, d = -1;
+        int s = -1, d = -1, piece = 0;
         float gx = 0.f, gy = 0.f, gz = 0.f, dist = 0.f;
         if (e < a.b.E) {
             s = a.b.e_src[e]; d = a.b.e_dst[e];
+            piece = tile - a.b.node_first_edge[d] / TM;
             // x_diff = x[src] - x[dst]; d = sqrt(max(|.|^2,1e-8)) + 1e-8; xhat = x_diff / d  (vector_field.py:381-383)
             const float dx = a.x[s * 3] - a.x[d * 3], dy = a.x[s * 3 + 1] - a.x[d * 3 + 1], dz = a.x[s * 3 + 2] - a.x[d * 3 + 2];
             dist = fm_norm3(dx, dy, dz) + 1e-8f;
             gx = dx / dist; gy = dy / dist; gz = dz / dist;
         }
-        m_src[tid] = s; m_dst[tid] = d;
+        m_src[tid] = s; m_dst[tid] = d; m_piece[tid] = piece;
         m_geo[4 * tid] = gx; m_geo[4 * tid + 1] = gy; m_geo[4 * tid + 2] = gz; m_geo[4 * tid + 3] = dist;
     }
     __syncthreads();
@@ -414,13 +416,17 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // segmented sum over the rows of each destination (rows are dst-sorted).  One thread per output column; the
     // destination ids and the column's TM values are first pulled into registers with independent LDS reads, the
     // running sums are then register-only (the first version walked the rows with dependent LDS reads: 15k cycles).
-    // The destination ids are wave-uniform (scalar loads, scalar compares/branches); a wave holds either scalar or
-    // vector columns, so the only per-lane work is the LDS reads, the adds and the (rare) stores.
-    static_assert(NTH == 512 && 3 * V <= 128, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
+    // The destination ids are made wave-uniform (one LDS read per lane, then v_readlane with constant lane ids), so
+    // the segment logic runs on scalar compares/branches; a wave holds either scalar or vector columns, so the only
+    // per-lane work is the LDS reads, the adds and the (rare) stores.
+    static_assert(NTH == 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
     {
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int* __restrict__ edst = a.b.e_dst;
-        const int* __restrict__ nfe = a.b.node_first_edge;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int myd = m_dst[lane % TM], mypc = m_piece[lane % TM];
+        int dd[TM + 1], pc[TM];
+#pragma unroll
+        for (int r = 0; r < TM; ++r) { dd[r] = __builtin_amdgcn_readlane(myd, r); pc[r] = __builtin_amdgcn_readlane(mypc, r); }
+        dd[TM] = -1;
         const bool is_s = wave < 4;                                       // columns 0..255: scalars
         const int cv = tid - 256;                                         // vector column = xyz*V + channel
         if (is_s || cv < 3 * V) {
@@ -430,21 +436,18 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
 #pragma unroll
             for (int r = 0; r < TM; ++r) val[r] = vp[r * vstride];
             float run = 0.f;
-            int d = e0 < a.b.E ? edst[e0] : -1;
 #pragma unroll
             for (int r = 0; r < TM; ++r) {
-                const int dn = (r + 1 < TM && e0 + r + 1 < a.b.E) ? edst[e0 + r + 1] : -1;    // next row's destination (uniform)
+                const int d = dd[r];
                 if (d >= 0) {
                     run += val[r];
-                    if (dn != d) {
-                        const int piece = tile - nfe[d] / TM;
-                        const size_t slot = (size_t)d * a.b.P + piece;
+                    if (dd[r + 1] != d) {
+                        const size_t slot = (size_t)d * a.b.P + pc[r];
                         if (is_s) fm_buf_store_f32(fm_buf(a.part_s + slot * 256, 1024u), tid * 4, 0, run);
                         else fm_buf_store_f32(fm_buf(a.part_v + slot * 3 * V, 3 * V * 4u), cv * 4, 0, run);
                         run = 0.f;
                     }
                 }
-                d = dn;
             }
         }
     }

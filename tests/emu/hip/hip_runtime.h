@@ -141,6 +141,7 @@ static inline void emu_raw_buffer_store_b32(unsigned d, emu_rsrc r, int voff, in
 #define __builtin_amdgcn_raw_buffer_load_b128 emu_raw_buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_store_b32 emu_raw_buffer_store_b32
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l))   /* must be called by the whole wave */
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* value is wave-uniform by contract */
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
