@@ -146,6 +146,14 @@ template <class R>
 __device__ __forceinline__ void fm_buf_store_f32(R rs, int voff, int soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
 }
+template <class R>
+__device__ __forceinline__ void fm_buf_store_f32x4(R rs, int voff, int soff, float4 v) {
+    typedef unsigned fm_u32x4 __attribute__((ext_vector_type(4)));
+    fm_u32x4 d;
+    d[0] = __builtin_bit_cast(unsigned, v.x); d[1] = __builtin_bit_cast(unsigned, v.y);
+    d[2] = __builtin_bit_cast(unsigned, v.z); d[3] = __builtin_bit_cast(unsigned, v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
+}
 __device__ __forceinline__ float2 fm_wload(const float2* __restrict__ base /*wave-uniform*/, int byte_off /*wave-uniform*/, int lane) {
     return fm_buf_f32x2(fm_buf(base), lane * 8, byte_off);
 }

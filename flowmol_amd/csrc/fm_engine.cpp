@@ -193,7 +193,7 @@ size_t lds_gvp(int V, int TM, bool with_meta) {
     size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (V + 20) + TM * FM_LDG;
     return fl * 4 + (with_meta ? (size_t)TM * 7 * 4 : 0);
 }
-size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 4 * FM_TM * 4; }
+size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 5 * FM_TM * 4; }
 size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }
 size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
 
@@ -268,7 +268,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         e.e_src = b.e_src; e.e_dst = b.e_dst; e.e_pair = b.e_pair; e.tok_e = state->e_t;
         e.prev_e = prev->e; e.prev_x = prev->x; e.x_t = state->x_t; e.T1 = c->T1; e.ef_tab = c->ef_tab;
         e.out = c->ef;
-        launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, E);
+        e.p_e0 = b.p_e0; e.p_e1 = b.p_e1;
+        launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U);   // one row per unordered pair, written to both directed edges
         tap("sc.s", c->s, (size_t)N * 256 * 4);
         tap("sc.ef", c->ef, (size_t)E * 128 * 4);
     } else {
@@ -648,6 +649,8 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
         N += n; E += (long long)n * (n - 1); nmax = n > nmax ? n : nmax;
     }
     if (E > 0x7fffffffLL / 4) return fail(c, FM_ERR_INVALID, "batch too large for int32 edge indexing (%lld edges)", E);
+    // per-node tables (Ps, Asd: 1 KiB rows) are gathered through buffer descriptors with 31-bit byte offsets
+    if (N > 0x7fffffffLL / 1024) return fail(c, FM_ERR_INVALID, "batch too large: %lld nodes (limit %lld per bind; split the batch)", N, 0x7fffffffLL / 1024);
     const int V = c->V;
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
     w.P = (nmax - 2) / c->tm_edge + 2;

@@ -134,36 +134,56 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
             X[r * a.ldx + c] = (row0 + r < a.rows) ? a.in[(size_t)(row0 + r) * 256 + c] : 0.f;
         }
     } else if (MODE == FM_MLP_EDGE_HEAD) {
-        for (int idx = tid; idx < FM_TM * 128; idx += FM_THREADS) {
-            const int r = idx >> 7, c = idx & 127;
-            const int p = row0 + r;
-            float v = 0.f;
-            if (p < a.rows) v = a.ef[(size_t)a.p_e0[p] * 128 + c] + a.ef[(size_t)a.p_e1[p] * 128 + c];
-            X[r * a.ldx + c] = v;
-        }
-    } else {   // FM_MLP_SC_EDGE: per directed edge
-        float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64][2]: d(x_t), d(x1_prev)
-        int* pr = meta + 3 * FM_TM;                              // [64] pair id
+        int* pr = meta + 3 * FM_TM;                              // [64] second edge of the pair
         if (tid < FM_TM) {
-            const int e = row0 + tid;
-            int tok = -1, pair = 0;
+            const int p = row0 + tid;
+            meta[tid] = (p < a.rows) ? a.p_e0[p] : -1;
+            pr[tid] = (p < a.rows) ? a.p_e1[p] : -1;
+        }
+        __syncthreads();
+        // x = ef[e0] + ef[e1]: 16-byte loads, all of a thread's requests issued before the first use
+        constexpr int NQ = FM_TM * 32 / FM_THREADS;
+        float4 u0[NQ], u1[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+            const int ea = meta[r], eb = pr[r];
+            u0[k] = reinterpret_cast<const float4*>(a.ef)[(size_t)(ea < 0 ? 0 : ea) * 32 + c4];
+            u1[k] = reinterpret_cast<const float4*>(a.ef)[(size_t)(eb < 0 ? 0 : eb) * 32 + c4];
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+            const bool ok = meta[r] >= 0;
+            float4 v;
+            v.x = ok ? u0[k].x + u1[k].x : 0.f; v.y = ok ? u0[k].y + u1[k].y : 0.f;
+            v.z = ok ? u0[k].z + u1[k].z : 0.f; v.w = ok ? u0[k].w + u1[k].w : 0.f;
+            *reinterpret_cast<float4*>(X + r * a.ldx + 4 * c4) = v;
+        }
+    } else {   // FM_MLP_SC_EDGE: per unordered pair (input, token and output are the same for both directions)
+        float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64][2]: d(x_t), d(x1_prev)
+        int* pr = meta + 3 * FM_TM;                              // [64] second edge of the pair
+        if (tid < FM_TM) {
+            const int p = row0 + tid;
+            int tok = -1, ea = -1, eb = -1;
             float dt_ = 0.f, d1_ = 0.f;
-            if (e < a.rows) {
-                const int i = a.e_src[e], j = a.e_dst[e];
-                pair = a.e_pair[e];
-                tok = a.tok_e[pair];
+            if (p < a.rows) {
+                ea = a.p_e0[p]; eb = a.p_e1[p];
+                const int i = a.e_src[ea], j = a.e_dst[ea];
+                tok = a.tok_e[p];
                 dt_ = fm_norm3(a.x_t[i * 3] - a.x_t[j * 3], a.x_t[i * 3 + 1] - a.x_t[j * 3 + 1], a.x_t[i * 3 + 2] - a.x_t[j * 3 + 2]) + 1e-8f;
                 d1_ = fm_norm3(a.prev_x[i * 3] - a.prev_x[j * 3], a.prev_x[i * 3 + 1] - a.prev_x[j * 3 + 1],
                                a.prev_x[i * 3 + 2] - a.prev_x[j * 3 + 2]) + 1e-8f;
             }
-            meta[tid] = tok; pr[tid] = pair; dd[2 * tid] = dt_; dd[2 * tid + 1] = d1_;
+            meta[tid] = tok; pr[tid] = eb; dd[2 * tid] = dt_; dd[2 * tid + 1] = d1_;
+            meta[4 * FM_TM + tid] = ea;       // [64] first edge of the pair
         }
         __syncthreads();
         for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
             const int r = idx / a.K1p, c = idx % a.K1p;
             float v = 0.f;
             if (meta[r] >= 0) {
-                if (c < a.ne) v = a.prev_e[(size_t)pr[r] * a.ne + c];
+                if (c < a.ne) v = a.prev_e[(size_t)(row0 + r) * a.ne + c];
                 else if (c < a.ne + 32)
                     v = fm_rbf(dd[2 * r + 1], c - a.ne, a.rbf_mu_step, a.rbf_inv_sigma) -
                         fm_rbf(dd[2 * r], c - a.ne, a.rbf_mu_step, a.rbf_inv_sigma);
@@ -181,11 +201,14 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
     });
     __syncthreads();
     // ---------------- layer 2 -> X[:, 0..O)
-    fm_block_gemm<4, 1>(Hb, a.ldh, FM_TM / 16, a.H / 8, a.W2, a.O / 16, [&](int row, int col, float v) {
+    auto epi2 = [&](int row, int col, float v) {
         v += a.b2[col];
         if (MODE == FM_MLP_TABLE || MODE == FM_MLP_SC_NODE || MODE == FM_MLP_SC_EDGE) v = fm_silu(v);
         X[row * a.ldx + col] = v;
-    });
+    };
+    // the heads have 1-2 output column tiles: single-tile jobs keep 4-8 waves busy instead of 1-2
+    if (MODE == FM_MLP_NODE_HEAD || MODE == FM_MLP_EDGE_HEAD) fm_block_gemm<1, 1>(Hb, a.ldh, FM_TM / 16, a.H / 8, a.W2, a.O / 16, epi2);
+    else fm_block_gemm<4, 1>(Hb, a.ldh, FM_TM / 16, a.H / 8, a.W2, a.O / 16, epi2);
     __syncthreads();
 
     // ---------------- epilogue
@@ -202,9 +225,18 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
             for (int c = sub; c < 256; c += 8)
                 a.out[(size_t)grow * 256 + c] = a.s_tab[(size_t)meta[r] * 256 + c] + X[r * a.ldx + c];
     } else if (MODE == FM_MLP_SC_EDGE) {
-        if (grow < a.rows)
-            for (int c = sub; c < 128; c += 8)
-                a.out[(size_t)grow * 128 + c] = a.ef_tab[meta[r] * 128 + c] + X[r * a.ldx + c];
+        if (grow < a.rows) {
+            const int ea = meta[4 * FM_TM + r], eb = meta[3 * FM_TM + r], tok = meta[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (j * 8 + sub) * 4;
+                const float4 t = *reinterpret_cast<const float4*>(a.ef_tab + tok * 128 + c);
+                const float4 x = *reinterpret_cast<const float4*>(X + r * a.ldx + c);
+                const float4 o = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
+                *reinterpret_cast<float4*>(a.out + (size_t)ea * 128 + c) = o;
+                *reinterpret_cast<float4*>(a.out + (size_t)eb * 128 + c) = o;
+            }
+        }
     } else {
         // softmax heads (vector_field.py:336-344,364-367): one lane per (row, head)
         if (sub == 0 && grow < a.rows) {
@@ -638,6 +670,14 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     int* m_dst = m_src + TM;
     float* m_d = reinterpret_cast<float*>(m_dst + TM);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), e0 = blockIdx.x * TM;
+    // the tile's ef rows depend only on the tile index: request them first.  Tile-relative descriptor; its range check
+    // zero-fills the rows of a ragged last tile on load and drops them on the final store.
+    const int left = a.b.E - e0;
+    const auto rs_ef = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
+    constexpr int NEF = TM * 32 / FM_THREADS;
+    float4 efv[NEF];
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs_ef, tid * 16 + k * FM_THREADS * 16, 0);
     if (tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1; float dist = 0.f;
@@ -648,66 +688,71 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
         m_src[tid] = s; m_dst[tid] = d; m_d[tid] = dist;
     }
     __syncthreads();
-    for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
-        const int r = idx >> 5, c4 = idx & 31;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m_src[r] >= 0) val = reinterpret_cast<const float4*>(a.ef)[(size_t)(e0 + r) * 32 + c4];
-        float* d = X + r * LDX + 4 * c4;
-        *reinterpret_cast<float4*>(d) = val;        // one ds_write_b128 (row pitch 656 B and column offset are multiples of 16 B)
+    // layer 1: wave w owns column tile w for all MT row tiles.  The hoisted node terms W1_src*s[src] + W1_dst*s[dst]
+    // (+ bias) are requested before the GEMM so their L2 latency hides behind the fill and the MFMAs; rows without an
+    // edge read 0 through the range check.
+    const int col = wave * 16 + (lane & 15);
+    float pre_s[MT][4], pre_d[MT][4];
+    const float b1 = a.b1[col], b2 = a.b2[col];
+    {
+        const auto rs = fm_buf(a.Asd, (unsigned)a.b.N * 1024u);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + 4 * (lane >> 4) + r;
+                const int sidx = m_src[row], didx = m_dst[row];
+                pre_s[i][r] = fm_buf_f32(rs, sidx >= 0 ? sidx * 1024 + (lane & 15) * 4 : FM_BUF_OOB, wave * 64);
+                pre_d[i][r] = fm_buf_f32(rs, sidx >= 0 ? didx * 1024 + (lane & 15) * 4 : FM_BUF_OOB, 512 + wave * 64);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) {
+        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = efv[k];       // one ds_write_b128 (row pitch 656 B and column offset are multiples of 16 B)
         X[r * LDX + 128 + c4] = (m_src[r] >= 0) ? fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
     }
-    // layer 1: wave w owns column tile w for all MT row tiles.  The hoisted node terms W1_src*s[src] + W1_dst*s[dst]
-    // (+ bias) are requested before the GEMM so their L2 latency hides behind the MFMAs.
-    const int col = wave * 16 + (lane & 15);
-    float pre[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = i * 16 + 4 * (lane >> 4) + r;
-            const int e = e0 + row;
-            float v = a.b1[col];
-            if (e < a.b.E) v += a.Asd[(size_t)a.b.e_src[e] * 256 + col] + a.Asd[(size_t)a.b.e_dst[e] * 256 + 128 + col];
-            pre[i][r] = v;
-        }
     __syncthreads();
+    float* ho = Hb + (4 * (lane >> 4)) * LDH + col;
+    float* xo = X + (4 * (lane >> 4)) * LDX + col;
     {
         f32x4 acc[MT][1];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][0][r] = (pre_s[i][r] + pre_d[i][r]) + b1;
         fm_wave_gemm<MT, 1>(acc, X, LDX, 160 / 8, a.W1, 8, wave, lane);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Hb[(i * 16 + 4 * (lane >> 4) + r) * LDH + col] = fm_silu(acc[i][0][r] + pre[i][r]);
+            for (int r = 0; r < 4; ++r) ho[(i * 16 + r) * LDH] = fm_silu(acc[i][0][r]);
     }
     __syncthreads();
     {
         f32x4 acc[MT][1];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{b2, b2, b2, b2};
         fm_wave_gemm<MT, 1>(acc, Hb, LDH, 128 / 8, a.W2, 8, wave, lane);
-        const float b2 = a.b2[col];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[(i * 16 + 4 * (lane >> 4) + r) * LDX + col] += fm_silu(acc[i][0][r] + b2);   // own element: ef + update
+            for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * LDX] += fm_silu(acc[i][0][r]);   // own element: ef + update
     }
     __syncthreads();
     const int r = tid / LPR, sub = tid % LPR;
     float mean, rstd;
     fm_row_stats<LPR>(X + r * LDX, 128, sub, mean, rstd);
-    if (m_src[r] >= 0) {
 #pragma unroll
-        for (int j = 0; j < 32 / LPR; ++j) {
-            const int c = (j * LPR + sub) * 4;
-            float4 o;
-            o.x = (X[r * LDX + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
-            o.y = (X[r * LDX + c + 1] - mean) * rstd * a.ln_g[c + 1] + a.ln_b[c + 1];
-            o.z = (X[r * LDX + c + 2] - mean) * rstd * a.ln_g[c + 2] + a.ln_b[c + 2];
-            o.w = (X[r * LDX + c + 3] - mean) * rstd * a.ln_g[c + 3] + a.ln_b[c + 3];
-            reinterpret_cast<float4*>(a.ef)[(size_t)(e0 + r) * 32 + (c >> 2)] = o;
-        }
+    for (int j = 0; j < 32 / LPR; ++j) {
+        const int c = (j * LPR + sub) * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(X + r * LDX + c);
+        const float4 g = reinterpret_cast<const float4*>(a.ln_g)[c >> 2], bb = reinterpret_cast<const float4*>(a.ln_b)[c >> 2];
+        float4 o;
+        o.x = (xv.x - mean) * rstd * g.x + bb.x;
+        o.y = (xv.y - mean) * rstd * g.y + bb.y;
+        o.z = (xv.z - mean) * rstd * g.z + bb.z;
+        o.w = (xv.w - mean) * rstd * g.w + bb.w;
+        fm_buf_store_f32x4(rs_ef, r * 512 + c * 4, 0, o);
     }
 }
 
