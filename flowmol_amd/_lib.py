@@ -11,7 +11,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FM_ABI_VERSION = 1
+FM_ABI_VERSION = 2
+FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
 FM_MAX_CONVS = 16
 
 LIB_NAME = 'libflowmol_hip.so'
@@ -48,7 +49,8 @@ class fm_step_noise(C.Structure):
 class fm_step_scalars(C.Structure):
     _fields_ = [('t', C.c_float), ('dt', C.c_float), ('x_coef', C.c_float), ('unmask_prob', C.c_float * 3),
                 ('mask_prob', C.c_float * 3), ('hc_thresh', C.c_float), ('cat_temperature', C.c_float),
-                ('last_step', C.c_int32)]
+                ('last_step', C.c_int32), ('x_scale', C.c_float), ('dfm_type', C.c_int32), ('gat_cf', C.c_float * 3),
+                ('gat_cb', C.c_float * 3), ('gat_fw', C.c_float), ('gat_bw', C.c_float)]
 
 
 class fm_sampled(C.Structure):

@@ -47,8 +47,15 @@ class VFConfig:
     # ---- CTMC integrator defaults (ctmc_vector_field.py:23-34)
     stochasticity: float = 30.0
     high_confidence_threshold: float = 0.9
-    cat_temperature: float = 0.05
-    dfm_type: str = 'campbell'
+    cat_temperature: float = 0.05                       # constant schedule value (cat_temperature_schedule given as a number)
+    cat_temperature_schedule: Union[float, str] = 0.05  # number, or 'decay': max*(1-t)^a (ctmc_vector_field.py:71-82)
+    cat_temp_decay_max: float = 0.8
+    cat_temp_decay_a: float = 2
+    dfm_type: str = 'campbell'                          # 'campbell' | 'gat' (ctmc_vector_field.py:357,373)
+    forward_weight_schedule: Union[float, str] = 'beta' # 'gat' only: number, or 'beta': 1 + max*t^a*(1-t)^b (:84-95)
+    fw_beta_a: float = 0.25
+    fw_beta_b: float = 0.25
+    fw_beta_max: float = 10.0
     # ---- sampling defaults (flowmol.py:46)
     default_n_timesteps: int = 250
     # name of the size histogram shipped in flowmol_amd/data/n_atoms_hist.json
@@ -118,8 +125,12 @@ class VFConfig:
             raise NotImplementedError("n_recycles>1 is never enabled by a shipped config")
         if not self.update_edge_w_distance:
             raise NotImplementedError("update_edge_w_distance=False is never enabled by a shipped config")
-        if self.dfm_type != 'campbell':
-            raise NotImplementedError("only dfm_type='campbell' is implemented")
+        if self.dfm_type not in ('campbell', 'gat'):
+            raise ValueError(f"Invalid dfm_type: {self.dfm_type}")           # ctmc_vector_field.py:62-63
+        if not isinstance(self.cat_temperature_schedule, (int, float)) and self.cat_temperature_schedule != 'decay':
+            raise ValueError(f"Invalid cat_temperature_schedule: {self.cat_temperature_schedule}")
+        if not isinstance(self.forward_weight_schedule, (int, float)) and self.forward_weight_schedule != 'beta':
+            raise ValueError(f"Invalid forward_weight_schedule: {self.forward_weight_schedule}")
         tok = (self.a_token_dim > 0, self.c_token_dim > 0, self.e_token_dim > 0)
         if len(set(tok)) != 1:
             raise NotImplementedError("token dims must be all zero or all non-zero")
@@ -156,9 +167,12 @@ def from_reference_hparams(hp: dict) -> VFConfig:
     for k, dflt in ref_defaults.items():
         setattr(cfg, k, vf.get(k, dflt))
     ct = vf.get('cat_temperature_schedule', 0.05)
-    if not isinstance(ct, (int, float)):
-        raise NotImplementedError("only a constant categorical temperature is implemented")
-    cfg.cat_temperature = float(ct)
+    cfg.cat_temperature_schedule = ct
+    if isinstance(ct, (int, float)):
+        cfg.cat_temperature = float(ct)
+    for k, dflt in (('cat_temp_decay_max', 0.8), ('cat_temp_decay_a', 2), ('forward_weight_schedule', 'beta'),
+                    ('fw_beta_a', 0.25), ('fw_beta_b', 0.25), ('fw_beta_max', 10.0)):
+        setattr(cfg, k, vf.get(k, dflt))
     for unsupported in ('attention', 'dropout', 's_message_dim', 'v_message_dim'):
         v = vf.get(unsupported)
         if v not in (None, False, 0, 0.0):

@@ -47,6 +47,7 @@ struct fm_ctx {
     std::string err;
     int V = 32, na = 0, nc = 0, ne = 0;
     int tm_edge = 32, tm_node = 32, tm_eupd = 32;
+    int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
     int prio_mode = 0, skew_blocks = 0, skew_steps = 1;   // edge-message de-phasing (FM_PRIO / FM_SKEW_BLOCKS / FM_SKEW_STEPS override)        // rows per workgroup tile of the GVP kernels (FM_TILE_EDGE / FM_TILE_NODE override)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
@@ -299,7 +300,9 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         // per-edge message taps are written straight into the caller's buffers (both must be registered)
         const bool dbg = taps_on && i == 0 && c->taps.count("conv0.msg.s") && c->taps.count("conv0.msg.v");
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
-        L("edge_message", fm_k_edge_message<V, TE, 512>, get, dim3(512), lds_gvp(V, TE, true), m);
+        dim3 gmsg = get;
+        if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
+        L("edge_message", fm_k_edge_message<V, TE, 512>, gmsg, dim3(512), lds_gvp(V, TE, true), m);
         FmNodeUpdArgs nu{};
         nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
         nu.g0 = cw.upd[0]; nu.g1 = cw.upd[1]; nu.g2 = cw.upd[2];
@@ -385,13 +388,24 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
               const fm_step_scalars* sc, const fm_sampled* smp) {
     Launch L{c, st};
     const FmBatch& b = c->b;
-    L("x_step", fm_k_x_step, dim3((b.N * 3 + 255) / 256), dim3(256), 0, state->x_t, (const float*)dst->x, sc->x_coef, sc->dt, b.N * 3);
+    L("x_step", fm_k_x_step, dim3((b.N * 3 + 255) / 256), dim3(256), 0, state->x_t, (const float*)dst->x, sc->x_coef, sc->dt, sc->x_scale, b.N * 3);
     struct Mod { int rows, K; const float* p; const int* mol; int* xt; int* x1; const float *q, *u1, *u2; };
     Mod mods[3] = {
         {b.N, c->na, dst->a, b.node_mol, state->a_t, (smp && smp->a1) ? smp->a1 : c->sa1, nz->q_a, nz->u1_a, nz->u2_a},
         {b.N, c->nc, dst->c, b.node_mol, state->c_t, (smp && smp->c1) ? smp->c1 : c->sc1, nz->q_c, nz->u1_c, nz->u2_c},
         {b.U, c->ne, dst->e, b.pair_mol, state->e_t, (smp && smp->e1) ? smp->e1 : c->se1, nz->q_e, nz->u1_e, nz->u2_e},
     };
+    if (sc->dfm_type == FM_DFM_GAT) {
+        for (int m = 0; m < 3; ++m) {
+            if (mods[m].rows == 0) continue;
+            FmGatArgs a{};
+            a.rows = mods[m].rows; a.K = mods[m].K; a.p = mods[m].p; a.xt = mods[m].xt; a.x1 = mods[m].x1; a.q = mods[m].q;
+            a.temp = sc->cat_temperature; a.cf = sc->gat_cf[m]; a.cb = sc->gat_cb[m]; a.fw = sc->gat_fw; a.bw = sc->gat_bw; a.dt = sc->dt;
+            L("ctmc_gat", fm_k_ctmc_gat, dim3((a.rows + 255) / 256), dim3(256), 0, a);
+        }
+        return L.rc;
+    }
+    if (sc->dfm_type != FM_DFM_CAMPBELL) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: unknown dfm_type %d", sc->dfm_type);
     L.zero(c->cnt, (size_t)6 * b.B * 4);
     for (int m = 0; m < 3; ++m) {
         if (mods[m].rows == 0) continue;
@@ -605,6 +619,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     // ---- dynamic LDS opt-in (up to 160 KiB per workgroup on gfx950)
     if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge = atoi(e1);
     if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node = atoi(e2);
+    if (const char* e4 = getenv("FM_XCD_SWIZZLE")) c->xcd_swizzle = atoi(e4);
     if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
     if ((c->tm_edge != 32 && c->tm_edge != 64) || (c->tm_node != 32 && c->tm_node != 64)) {
         (void)hipFree(c->arena); delete c;

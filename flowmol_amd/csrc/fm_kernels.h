@@ -345,6 +345,7 @@ struct FmMsgArgs {
     float* part_v;            // (N, P, 3, V)
     float rbf_mu_step, rbf_inv_sigma;
     float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
+    int xcd_chunk;            // > 0: workgroup b handles tile (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk); 0: tile = b
 };
 
 template <int V, int TM, int NTH>
@@ -360,8 +361,12 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [TM][4]: xhat(3), dist
     int* m_piece = reinterpret_cast<int*>(m_geo + 4 * TM); // [TM] which partial-sum slot of its destination the row adds to
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  With the chunked mapping every XCD walks
+    // one contiguous range of tiles, so a molecule's Ps / PV rows (shared by its ~n^2/TM consecutive tiles) are filled
+    // into one L2 instead of all eight.
+    const int tile = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int e0 = tile * TM;
+    if (e0 >= a.b.E) return;          // padding workgroups of the chunked grid (uniform exit, before any barrier)
     FM_MARK_DECL
     // (A) the edge-feature rows depend only on the tile index: request them before anything else (HBM latency)
     constexpr int NEF = TM * 32 / NTH;
@@ -789,11 +794,12 @@ __global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, con
 }
 
 // Euler step for positions (ctmc_vector_field.py:331-334): x_t += dt * (coef * (x1 - x_t)), coef = alpha'/(1-alpha)
-__global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, const float* __restrict__ x1, float coef, float dt, int n3) {
+//   scale = inv_temp_func(t_i), 1 by default (multiplying by 1.0f is exact)
+__global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, const float* __restrict__ x1, float coef, float dt, float scale, int n3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n3) {
         const float vf = fm_mul_rn(coef, fm_sub_rn(x1[i], x_t[i]));
-        x_t[i] = fm_add_rn(x_t[i], fm_mul_rn(dt, vf));
+        x_t[i] = fm_add_rn(x_t[i], fm_mul_rn(fm_mul_rn(dt, vf), scale));
     }
 }
 
@@ -870,4 +876,51 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_pass2(FmCtmcArgs a) {
     if (!a.last_step) { if ((a.u2[i] < a.mask_prob) && !masked) nt = a.K; }
     if (will_unmask) nt = a.x1[i];
     a.xt[i] = nt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dfm_type 'gat' (ctmc_vector_field.py:373-388, 463-510): one draw from the transition distribution
+//   p_step = clamp(delta_xt + dt*(fw*u_f - bw*u_b), 1e-9, 1) over K+1 classes (mask = class K),
+//   u_f = cf*([p~, 0] - delta_xt), u_b = cb*(delta_xt - delta_mask); x_{t+dt} = argmax((p_step/sum)/q).
+// x1 receives argmax(p~) (the reference records the tempered probabilities as the "endpoint" frame).
+// ------------------------------------------------------------------------------------------------
+struct FmGatArgs {
+    int rows, K;
+    const float* p;                 // (rows,K) endpoint probabilities (un-tempered softmax)
+    int* xt;                        // (rows) tokens, updated in place
+    int* x1;                        // (rows) argmax of the tempered endpoint distribution
+    const float* q;                 // (rows,K+1) Exp(1) noise
+    float temp, cf, cb, fw, bw, dt;
+};
+
+__global__ void __launch_bounds__(256) fm_k_ctmc_gat(FmGatArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.rows) return;
+    float lp[17];
+    float mx = -INFINITY;
+    for (int k = 0; k < a.K; ++k) { lp[k] = fm_div_rn(logf(a.p[(size_t)i * a.K + k]), a.temp); mx = fmaxf(mx, lp[k]); }
+    float sum = 0.f;
+    for (int k = 0; k < a.K; ++k) { lp[k] = expf(fm_sub_rn(lp[k], mx)); sum = fm_add_rn(sum, lp[k]); }
+    int amax = 0; float amaxv = -1.f;
+    for (int k = 0; k < a.K; ++k) { lp[k] = fm_div_rn(lp[k], sum); if (lp[k] > amaxv) { amaxv = lp[k]; amax = k; } }
+    lp[a.K] = 0.f;
+    const int tok = a.xt[i];
+    float psum = 0.f;
+    for (int k = 0; k <= a.K; ++k) {
+        const float dx = (k == tok) ? 1.f : 0.f, dm = (k == a.K) ? 1.f : 0.f;
+        const float uf = fm_mul_rn(a.cf, fm_sub_rn(lp[k], dx));
+        const float ub = fm_mul_rn(a.cb, fm_sub_rn(dx, dm));
+        const float pv = fm_sub_rn(fm_mul_rn(a.fw, uf), fm_mul_rn(a.bw, ub));
+        float ps = fm_add_rn(dx, fm_mul_rn(a.dt, pv));
+        ps = fminf(fmaxf(ps, 1.0e-9f), 1.0f);
+        lp[k] = ps;
+        psum = fm_add_rn(psum, ps);
+    }
+    int best = 0; float bestv = -1.f;
+    for (int k = 0; k <= a.K; ++k) {
+        const float v = fm_div_rn(fm_div_rn(lp[k], psum), a.q[(size_t)i * (a.K + 1) + k]);
+        if (v > bestv) { bestv = v; best = k; }
+    }
+    a.xt[i] = best;
+    a.x1[i] = amax;
 }

@@ -10,12 +10,12 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 
 from . import _lib
-from ._lib import (FlowMolHipError, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
+from ._lib import (FM_DFM_CAMPBELL, FM_DFM_GAT, FlowMolHipError, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
                    fm_tensor_desc, fm_traj_sink)
 from .config import VFConfig
 from .weights import check_state_dict, state_dict_shapes
@@ -50,11 +50,40 @@ class StepPlan:
     scalars: List[fm_step_scalars]
 
 
-def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperature: float,
-                   tspan: Optional[torch.Tensor] = None) -> StepPlan:
+def cat_temp_schedule(cfg: VFConfig) -> Callable:
+    """CTMCVectorField.build_cat_temp_schedule (ctmc_vector_field.py:71-82) for the configured schedule."""
+    sched = cfg.cat_temperature_schedule
+    if sched == 'decay':
+        mx, a = cfg.cat_temp_decay_max, cfg.cat_temp_decay_a
+        return lambda t: mx * torch.pow(1 - t, a)
+    val = cfg.cat_temperature if isinstance(sched, str) else sched
+    return lambda t: val
+
+
+def forward_weight_schedule(cfg: VFConfig) -> Callable:
+    """CTMCVectorField.build_fw_schedule (ctmc_vector_field.py:84-95)."""
+    sched = cfg.forward_weight_schedule
+    if sched == 'beta':
+        a, b, mx = cfg.fw_beta_a, cfg.fw_beta_b, cfg.fw_beta_max
+        return lambda t: 1 + mx * torch.pow(t, a) * torch.pow(1 - t, b)
+    return lambda t: sched
+
+
+def _f32(v) -> float:
+    """A Python number or 0-dim tensor as the float32 value a torch op on float32 tensors would use."""
+    return float(v.to(torch.float32)) if torch.is_tensor(v) else float(torch.tensor(v, dtype=torch.float32))
+
+
+def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperature,
+                   tspan: Optional[torch.Tensor] = None, dfm_type: str = 'campbell', forward_weight_func: Optional[Callable] = None,
+                   inv_temp_func: Optional[Callable] = None) -> StepPlan:
+    """Per-step scalars of CTMCVectorField.integrate/step (ctmc_vector_field.py:169-178, 287-340), computed with the
+    reference's own float32 tensor arithmetic.  ``cat_temperature`` is a number or a callable of the 0-dim tensor t_i."""
     t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32)
     alpha = t          # linear schedule: alpha_t = t, alpha_t' = 1 for x, a, c, e (interpolant_scheduler.py:148-153)
     one = torch.ones(())
+    if dfm_type not in ('campbell', 'gat'):
+        raise ValueError(f"Invalid dfm_type: {dfm_type}")
     out = []
     for s_idx in range(1, t.shape[0]):
         s_i, t_i = t[s_idx], t[s_idx - 1]
@@ -70,8 +99,17 @@ def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperatu
             sc.unmask_prob[k] = float(unmask)
             sc.mask_prob[k] = float(mask)
         sc.hc_thresh = float(torch.tensor(hc_thresh, dtype=torch.float32))
-        sc.cat_temperature = float(torch.tensor(cat_temperature, dtype=torch.float32))
+        sc.cat_temperature = _f32(cat_temperature(t_i) if callable(cat_temperature) else cat_temperature)
         sc.last_step = 1 if s_idx == t.shape[0] - 1 else 0
+        sc.x_scale = 1.0 if inv_temp_func is None else _f32(inv_temp_func(t_i))
+        sc.dfm_type = FM_DFM_GAT if dfm_type == 'gat' else FM_DFM_CAMPBELL
+        if dfm_type == 'gat':
+            fw = 1.0 if forward_weight_func is None else forward_weight_func(t_i)
+            bw = fw - 1                                     # python or tensor arithmetic, as in gat_step
+            for k in range(3):
+                sc.gat_cf[k] = float(one / (1 - a_i))
+                sc.gat_cb[k] = float(one / (a_i + 1e-8))
+            sc.gat_fw, sc.gat_bw = _f32(fw), _f32(bw)
         out.append(sc)
     return StepPlan(t, out)
 
@@ -86,10 +124,14 @@ class StepNoise:
             setattr(self, k, kw.get(k))
 
     @staticmethod
-    def draw(N: int, U: int, na: int, nc: int, ne: int, last_step: bool, device, generator=None) -> "StepNoise":
+    def draw(N: int, U: int, na: int, nc: int, ne: int, last_step: bool, device, generator=None, dfm_type: str = 'campbell') -> "StepNoise":
         """Draw with torch's generator on ``device`` exactly as the reference's ops would
-        (torch.multinomial's Exp(1) draw, then the two torch.rand calls)."""
+        (torch.multinomial's Exp(1) draw, then the two torch.rand calls; 'gat': one Exp(1) draw over K+1 classes)."""
         out = {}
+        if dfm_type == 'gat':
+            for tag, rows, k in (('a', N, na), ('c', N, nc), ('e', U, ne)):
+                out[f'q_{tag}'] = torch.empty(rows, k + 1, device=device, dtype=torch.float32).exponential_(1, generator=generator)
+            return StepNoise(**out)
         for tag, rows, k in (('a', N, na), ('c', N, nc), ('e', U, ne)):
             out[f'q_{tag}'] = torch.empty(rows, k, device=device, dtype=torch.float32).exponential_(1, generator=generator)
             out[f'u1_{tag}'] = torch.rand(rows, device=device, generator=generator)
@@ -97,8 +139,12 @@ class StepNoise:
         return StepNoise(**out)
 
     @staticmethod
-    def from_tape(tape: Sequence[torch.Tensor], pos: int, last_step: bool, device) -> "tuple[StepNoise, int]":
+    def from_tape(tape: Sequence[torch.Tensor], pos: int, last_step: bool, device, dfm_type: str = 'campbell') -> "tuple[StepNoise, int]":
         out = {}
+        if dfm_type == 'gat':
+            for tag in 'ace':
+                out[f'q_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1
+            return StepNoise(**out), pos
         for tag in 'ace':
             out[f'q_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1
             out[f'u1_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1

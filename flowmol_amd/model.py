@@ -20,7 +20,7 @@ import torch
 
 from . import presets
 from .config import VFConfig, from_reference_hparams
-from .engine import Engine, StepNoise, make_step_plan
+from .engine import Engine, StepNoise, cat_temp_schedule, forward_weight_schedule, make_step_plan
 from .molecule import SampledMolecule
 from .weights import synth_state_dict
 
@@ -163,11 +163,13 @@ class FlowMol:
         eng = self.engine
         dev = eng.device
         n_timesteps = self.default_n_timesteps if n_timesteps is None else n_timesteps
-        for k in ('inv_temp_func', 'forward_weight_func'):
-            if kwargs.get(k) is not None:
-                raise NotImplementedError(f'{k} is not supported on the HIP path')
-        if kwargs.get('dfm_type', 'campbell') not in (None, 'campbell'):
-            raise NotImplementedError("only dfm_type='campbell' is implemented")
+        # integrator variants of CTMCVectorField.integrate/step (ctmc_vector_field.py:145-156,287-315): all optional
+        dfm_type = kwargs.get('dfm_type') or self.cfg.dfm_type
+        if dfm_type not in ('campbell', 'gat'):
+            raise ValueError(f"Invalid dfm_type: {dfm_type}")
+        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func'}
+        if unknown:
+            raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         visualize = bool(xt_traj or ep_traj)
         n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
         eng.bind(n_atoms)
@@ -182,12 +184,10 @@ class FlowMol:
             state = self._state_from_prior(prior)
         eta = cfg.stochasticity if stochasticity is None else stochasticity
         hc = cfg.high_confidence_threshold if high_confidence_threshold is None else high_confidence_threshold
-        temp = cfg.cat_temperature
-        plan = make_step_plan(n_timesteps, eta, hc, temp, tspan=kwargs.get('tspan'))
-        ctf = kwargs.get('cat_temp_func')
-        if ctf is not None:
-            for sc in plan.scalars:
-                sc.cat_temperature = float(ctf(torch.tensor(sc.t)))
+        ctf = kwargs.get('cat_temp_func') or cat_temp_schedule(cfg)
+        fwf = kwargs.get('forward_weight_func') or forward_weight_schedule(cfg)
+        plan = make_step_plan(n_timesteps, eta, hc, ctf, tspan=kwargs.get('tspan'), dfm_type=dfm_type,
+                              forward_weight_func=fwf, inv_temp_func=kwargs.get('inv_temp_func'))
         n_steps = len(plan.scalars)
         traj = None
         if visualize:
@@ -199,7 +199,7 @@ class FlowMol:
             init = {k: state[f'{k}_t'].clone() for k in 'xace'}
 
         def noise_for_step(i, last):
-            return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev)
+            return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, dfm_type=dfm_type)
 
         eng.integrate(state, plan, noise_for_step, traj=traj)
         out = {k: state[f'{k}_t'].cpu() for k in 'xace'}

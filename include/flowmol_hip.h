@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 1
+#define FM_ABI_VERSION 2
 #define FM_MAX_CONVS 16
 
 typedef enum fm_status {
@@ -99,7 +99,11 @@ typedef struct fm_step_noise {    /* draws of one CTMC step, in the reference's 
     const float* q_a;  const float* u1_a;  const float* u2_a;    /* (N,na) Exp(1), (N) U, (N) U */
     const float* q_c;  const float* u1_c;  const float* u2_c;
     const float* q_e;  const float* u1_e;  const float* u2_e;    /* (U,ne), (U), (U) */
+    /* dfm_type FM_DFM_GAT: one Categorical draw per modality over K+1 classes (mask included), so q_* are
+     * (rows, K+1) and u1_*, u2_* are unused (may be NULL) */
 } fm_step_noise;
+
+enum fm_dfm_type { FM_DFM_CAMPBELL = 0, FM_DFM_GAT = 1 };   /* reference ctmc_vector_field.py:357 / :373 */
 
 typedef struct fm_step_scalars {  /* host-computed with the reference's float32 arithmetic */
     float t;                      /* t_i */
@@ -108,8 +112,14 @@ typedef struct fm_step_scalars {  /* host-computed with the reference's float32 
     float unmask_prob[3];         /* a, c, e: clamp(dt*(alpha' + eta*alpha)/(1-alpha), 0, 1) */
     float mask_prob[3];           /* clamp(dt*eta, 0, 1) */
     float hc_thresh;              /* purity threshold; 0 = uniform unmasking branch */
-    float cat_temperature;        /* 0.05 by default */
+    float cat_temperature;        /* cat_temp_func(t_i): 0.05 by default, or the 'decay' schedule */
     int32_t last_step;
+    /* --- ABI 2 */
+    float x_scale;                /* inv_temp_func(t_i) of the reference's step(): x_t += (dt*vf)*x_scale; 1 by default */
+    int32_t dfm_type;             /* fm_dfm_type */
+    float gat_cf[3];              /* a, c, e: alpha'/(1 - alpha)        (gat_step, ctmc_vector_field.py:481) */
+    float gat_cb[3];              /* a, c, e: alpha'/(alpha + 1e-8)     (:488) */
+    float gat_fw, gat_bw;         /* forward_weight_func(t_i) and forward_weight - 1 (:491-492) */
 } fm_step_scalars;
 
 typedef struct fm_sampled {       /* sampled endpoint tokens of a step ("*_1_pred"), optional (may be NULL) */

@@ -454,9 +454,27 @@ class OracleVF:
         xt[will_unmask] = x1[will_unmask]
         return F.one_hot(xt, num_classes=n_classes).float(), F.one_hot(x1, num_classes=n_classes).float()
 
+    def gat_step(self, p_1_given_t, xt, alpha_t, alpha_t_prime, forward_weight, dt, n_classes, mask_index, noise):
+        """ctmc_vector_field.py:463-510: one draw from the clamped transition distribution over K+1 classes."""
+        p_1_given_t = torch.cat([p_1_given_t, torch.zeros_like(p_1_given_t[:, :1])], dim=-1)
+        delta_xt = F.one_hot(xt, num_classes=n_classes).float()
+        u_forward = alpha_t_prime / (1 - alpha_t) * (p_1_given_t - delta_xt)
+        delta_mask = torch.zeros_like(delta_xt)
+        delta_mask[:, mask_index] = 1
+        u_backward = alpha_t_prime / (alpha_t + 1e-8) * (delta_xt - delta_mask)
+        backward_weight = forward_weight - 1
+        pvel = forward_weight * u_forward - backward_weight * u_backward
+        p_step = torch.clamp(delta_xt + dt * pvel, min=1.0e-9, max=1)
+        pn = p_step / p_step.sum(-1, keepdim=True)            # Categorical normalises; sample == argmax(pn/q)
+        q = noise.exp_like(pn)
+        x_dt = torch.argmax(pn / q, dim=-1)
+        return F.one_hot(x_dt, num_classes=n_classes).float()
+
     def step(self, batch: Batch, state: Dict[str, torch.Tensor], s_i, t_i, alpha_t_i, alpha_t_prime_i,
-             prev, eta, hc_thresh, last_step, noise, cat_temp=None):
-        """CTMCVectorField.step, ctmc_vector_field.py:287-411 (dfm_type='campbell', inv_temp=1)."""
+             prev, eta, hc_thresh, last_step, noise, cat_temp=None, dfm_type='campbell', forward_weight=None,
+             inv_temp=1.0):
+        """CTMCVectorField.step, ctmc_vector_field.py:287-411.  cat_temp / forward_weight / inv_temp are the VALUES
+        of cat_temp_func(t_i) / forward_weight_func(t_i) / inv_temp_func(t_i)."""
         cfg = self.cfg
         dev = state['x_t'].device
         dst = self.forward(batch, state['x_t'], state['a_t'], state['c_t'], state['e_t'],
@@ -467,7 +485,7 @@ class OracleVF:
         x_1 = dst['x']
         x_t = state['x_t']
         vf = alpha_t_prime_i[0] / (1 - alpha_t_i[0]) * (x_1 - x_t)
-        new = {'x_t': x_t + dt * vf * 1.0, 'x_1_pred': x_1.detach().clone()}
+        new = {'x_t': x_t + dt * vf * inv_temp, 'x_1_pred': x_1.detach().clone()}
         m = batch.upper_edge_mask
         temperature = cfg.cat_temperature if cat_temp is None else cat_temp
         for fi, feat in enumerate(['x', 'a', 'c', 'e']):
@@ -479,8 +497,13 @@ class OracleVF:
             p = F.softmax(torch.log(dst[feat]) / temperature, dim=-1)
             bidx = batch.edge_batch_idx[m] if feat == 'e' else batch.node_batch_idx
             n_cls = {'a': self.na, 'c': self.nc, 'e': self.ne}[feat] + 1
-            xt1h, x11h = self.campbell_step(p, xt, eta, hc_thresh, alpha_t_i[fi], alpha_t_prime_i[fi], dt,
-                                            batch.B, n_cls, self.mask_idx[feat], last_step, bidx, noise)
+            if dfm_type == 'campbell':
+                xt1h, x11h = self.campbell_step(p, xt, eta, hc_thresh, alpha_t_i[fi], alpha_t_prime_i[fi], dt,
+                                                batch.B, n_cls, self.mask_idx[feat], last_step, bidx, noise)
+            else:
+                x11h = torch.cat([p, torch.zeros_like(p[:, :1])], dim=-1)      # ctmc_vector_field.py:375
+                xt1h = self.gat_step(p, xt, alpha_t_i[fi], alpha_t_prime_i[fi], forward_weight, dt, n_cls,
+                                     self.mask_idx[feat], noise)
             if feat == 'e':
                 e_t = torch.zeros_like(state['e_t'])
                 e_t[m] = xt1h
@@ -494,8 +517,11 @@ class OracleVF:
         return new, dst
 
     def integrate(self, batch: Batch, prior: Dict[str, torch.Tensor], n_timesteps: int, eta=None, hc_thresh=None,
-                  noise=None, visualize=False, tspan=None, step_hook=None):
-        """CTMCVectorField.integrate, ctmc_vector_field.py:145-285."""
+                  noise=None, visualize=False, tspan=None, step_hook=None, dfm_type='campbell', cat_temp_func=None,
+                  forward_weight_func=None, inv_temp_func=None):
+        """CTMCVectorField.integrate, ctmc_vector_field.py:145-285.  The *_func arguments are callables of the
+        0-dim tensor t_i like the reference's (defaults: the configured constant temperature, forward weight 1,
+        inverse temperature 1)."""
         cfg = self.cfg
         eta = cfg.stochasticity if eta is None else eta
         hc_thresh = cfg.high_confidence_threshold if hc_thresh is None else hc_thresh
@@ -511,8 +537,12 @@ class OracleVF:
         dst = None
         for s_idx in range(1, t.shape[0]):
             last = s_idx == t.shape[0] - 1
-            new, dst = self.step(batch, state, t[s_idx], t[s_idx - 1], alpha_t[s_idx - 1], alpha_tp[s_idx - 1],
-                                 prev=dst, eta=eta, hc_thresh=hc_thresh, last_step=last, noise=noise)
+            t_i = t[s_idx - 1]
+            new, dst = self.step(batch, state, t[s_idx], t_i, alpha_t[s_idx - 1], alpha_tp[s_idx - 1],
+                                 prev=dst, eta=eta, hc_thresh=hc_thresh, last_step=last, noise=noise,
+                                 cat_temp=None if cat_temp_func is None else cat_temp_func(t_i), dfm_type=dfm_type,
+                                 forward_weight=1.0 if forward_weight_func is None else forward_weight_func(t_i),
+                                 inv_temp=1.0 if inv_temp_func is None else inv_temp_func(t_i))
             state = {k: new[k] for k in ('x_t', 'a_t', 'c_t', 'e_t')}
             if step_hook is not None:
                 step_hook(s_idx, new, dst)

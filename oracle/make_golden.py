@@ -178,6 +178,43 @@ def gen_integrate(ns, name, cfg, sd, sizes, T, tag):
     np.savez_compressed(OUT / f'integrate_{name}_{tag}.npz', **_np(out))
 
 
+# integrator variants: non-uniform tspan, 'decay' temperature schedule, an inverse-temperature
+# function for the position step, and dfm_type='gat' with the 'beta' forward-weight schedule
+VARIANT_TSPAN = [0.0, 0.04, 0.12, 0.25, 0.4, 0.55, 0.7, 0.82, 0.92, 0.97, 1.0]
+
+
+def variant_inv_temp(t):
+    return 1 - 0.25 * t
+
+
+def gen_integrate_variant(ns, name, cfg, sd, sizes, tag, dfm_type):
+    vf = ref_standin.build_reference_vf(ns, cfg, sd, cat_temperature_schedule='decay', cat_temp_decay_max=0.8,
+                                        cat_temp_decay_a=2, forward_weight_schedule='beta')
+    n_atoms = torch.tensor(sizes)
+    g, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
+    torch.manual_seed(5)
+    x0 = ns.centered_normal_prior_batched_graph(g, nb)
+    g.ndata['x_0'] = x0
+    g.ndata['a_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_atom_types)
+    g.ndata['c_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_charges)
+    g.edata['e_0'] = ns.edge_prior(upper, {'type': 'ctmc', 'kwargs': {}}, explicit_aromaticity=False)
+    tspan = torch.tensor(VARIANT_TSPAN)
+    torch.manual_seed(6)
+    with torch.no_grad(), _Tape() as tp:
+        gout, frames = vf.integrate(g, nb, upper_edge_mask=upper, n_timesteps=len(VARIANT_TSPAN), visualize=True,
+                                    dfm_type=dfm_type, stochasticity=None, high_confidence_threshold=None,
+                                    tspan=tspan, inv_temp_func=variant_inv_temp)
+    out = {'n_atoms': n_atoms, 'tspan': tspan, 'x_0': x0,
+           'x_1': gout.ndata['x_1'], 'a_1': gout.ndata['a_1'].argmax(-1), 'c_1': gout.ndata['c_1'].argmax(-1),
+           'e_1_upper': gout.edata['e_1'][upper].argmax(-1)}
+    for i, t in enumerate(tp.tape):
+        out[f'noise.{i:05d}'] = t
+    out['traj0.x'] = frames[0]['x']
+    out['traj0.a'] = frames[0]['a'].argmax(-1)
+    out['traj0.a_1_pred'] = frames[0]['a_1_pred'].argmax(-1)
+    np.savez_compressed(OUT / f'integrate_{name}_{tag}.npz', **_np(out))
+
+
 def gen_misc(ns):
     out = {}
     t = torch.tensor([0.0, 0.004016064, 0.5, 0.9959839, 1.0])
@@ -242,6 +279,9 @@ def main():
     gen_integrate(ns, 'qm9', cfg, sd, [18] * 8, 20, 'C1')          # BASELINE.json configs[0]
     cfg = presets.geom_ctmc(); sd = weights.synth_state_dict(cfg, 0)
     gen_integrate(ns, 'geom_ctmc', cfg, sd, [5, 17, 8, 30], 16, 'C5s')
+    cfg = presets.qm9(); sd = weights.synth_state_dict(cfg, 0)
+    gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'gat', 'gat')
+    gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'sched', 'campbell')
     for f in sorted(OUT.glob('*.npz')):
         print(f.name, f.stat().st_size // 1024, 'KiB')
 

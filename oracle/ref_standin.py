@@ -192,7 +192,7 @@ def import_reference():
     return ns
 
 
-def build_reference_vf(ns, cfg, state_dict):
+def build_reference_vf(ns, cfg, state_dict, **overrides):
     """Instantiate the reference CTMCVectorField for ``cfg`` and load ``state_dict`` (strict)."""
     sched = ns.InterpolantScheduler(canonical_feat_order=['x', 'a', 'c', 'e'],
                                     schedule_type={k: 'linear' for k in 'xace'})
@@ -210,7 +210,7 @@ def build_reference_vf(ns, cfg, state_dict):
         message_norm=cfg.message_norm, rbf_dmax=cfg.rbf_dmax, rbf_dim=cfg.rbf_dim,
         time_embedding_dim=cfg.time_embedding_dim, a_token_dim=cfg.a_token_dim,
         c_token_dim=cfg.c_token_dim, e_token_dim=cfg.e_token_dim,
-        cat_temperature_schedule=cfg.cat_temperature,
+        **{'cat_temperature_schedule': cfg.cat_temperature, **overrides},
     )
     vf.load_state_dict(state_dict, strict=True)
     vf.eval()

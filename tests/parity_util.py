@@ -129,3 +129,49 @@ def integrate_golden(eng, cfg, g, chunk=8, device=None):
     res['traj0_x_rel'] = float((traj['x'][:, :n0].cpu() - g['traj0.x'][1:]).abs().max() / g['traj0.x'].abs().max())
     res['traj0_a_flips'] = int((traj['a'][:, :n0].cpu().long() != g['traj0.a'][1:]).sum())
     return res, state
+
+
+# the schedule used by oracle/make_golden.py:gen_integrate_variant (fixtures integrate_qm9_gat / integrate_qm9_sched)
+def variant_inv_temp(t):
+    return 1 - 0.25 * t
+
+
+def variant_cfg(cfg):
+    """The preset with the variant fixtures' sampling schedules: 'decay' temperature, 'beta' forward weight."""
+    import dataclasses
+    return dataclasses.replace(cfg, cat_temperature_schedule='decay', cat_temp_decay_max=0.8, cat_temp_decay_a=2,
+                               forward_weight_schedule='beta')
+
+
+def integrate_variant_golden(eng, cfg, g, dfm_type, chunk=4, device=None):
+    """Engine run of the variant fixtures (non-uniform tspan, decay temperature, inverse-temperature function,
+    dfm_type campbell|gat) with the reference's recorded noise."""
+    from flowmol_amd.engine import StepNoise, cat_temp_schedule, forward_weight_schedule, make_step_plan
+    device = device or eng.device
+    vcfg = variant_cfg(cfg)
+    eng.bind(g['n_atoms'])
+    tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
+    plan = make_step_plan(0, vcfg.stochasticity, vcfg.high_confidence_threshold, cat_temp_schedule(vcfg), tspan=g['tspan'],
+                          dfm_type=dfm_type, forward_weight_func=forward_weight_schedule(vcfg), inv_temp_func=variant_inv_temp)
+    n_steps = len(plan.scalars)
+    state = eng.prior_state(g['x_0'])
+    pos = [0]
+
+    def noise_for_step(i, last):
+        nz, pos[0] = StepNoise.from_tape(tape, pos[0], last, device, dfm_type=dfm_type)
+        return nz
+    i32 = dict(dtype=torch.int32, device=device)
+    traj = {'x': torch.zeros(n_steps, eng.N, 3, device=device), 'a': torch.zeros(n_steps, eng.N, **i32),
+            'a1': torch.zeros(n_steps, eng.N, **i32)}
+    eng.integrate(state, plan, noise_for_step, chunk=chunk, traj=traj)
+    assert pos[0] == len(tape)
+    n0 = int(g['n_atoms'][0])
+    return {
+        'a_flips': int((state['a_t'].cpu().long() != g['a_1']).sum()),
+        'c_flips': int((state['c_t'].cpu().long() != g['c_1']).sum()),
+        'e_flips': int((state['e_t'].cpu().long() != g['e_1_upper']).sum()),
+        'x_rel': float((state['x_t'].cpu() - g['x_1']).abs().max() / g['x_1'].abs().max()),
+        'traj0_x_rel': float((traj['x'][:, :n0].cpu() - g['traj0.x'][1:]).abs().max() / g['traj0.x'].abs().max()),
+        'traj0_a_flips': int((traj['a'][:, :n0].cpu().long() != g['traj0.a'][1:]).sum()),
+        'traj0_a1_flips': int((traj['a1'][:, :n0].cpu().long() != g['traj0.a_1_pred']).sum()),
+    }

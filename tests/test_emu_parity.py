@@ -107,3 +107,41 @@ def test_sample_kwargs_tspan_cat_temp_and_prior_on_emulation(emu_lib):
     via_prior, _ = model.sample(n_atoms, n_timesteps=4, device='cpu', return_tensors=True, prior=prior)
     assert torch.equal(via_prior['a'], base['a']) and torch.equal(via_prior['e'], base['e'])
     assert torch.allclose(via_prior['x'], base['x'], atol=1e-6)
+
+
+@pytest.mark.parametrize('fname,dfm_type', [('integrate_qm9_gat.npz', 'gat'), ('integrate_qm9_sched.npz', 'campbell')])
+def test_integrator_variants_on_emulation(emu_lib, golden_dir, fname, dfm_type):
+    """SURVEY 8f rank 4 through the C ABI: tspan, 'decay' temperature, inv_temp_func and dfm_type 'gat'
+    (ctmc_vector_field.py:71-95, 287-340, 463-510) against the reference's own run with its recorded noise."""
+    from flowmol_amd.engine import Engine
+    from parity_util import integrate_variant_golden
+    cfg = presets.qm9()
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / fname).items()}
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
+    res = integrate_variant_golden(eng, cfg, g, dfm_type)
+    assert res['a_flips'] == 0 and res['c_flips'] == 0 and res['e_flips'] == 0, res
+    assert res['traj0_a_flips'] == 0 and res['traj0_a1_flips'] == 0, res
+    assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res       # BASELINE.json: 1e-4 relative coordinate error
+
+
+def test_sample_accepts_variant_kwargs_on_emulation(emu_lib):
+    """dfm_type / forward_weight_func / inv_temp_func flow through sample() like the reference's **kwargs; a model
+    configured with dfm_type='gat' uses it by default; unknown kwargs and dfm types are errors."""
+    import dataclasses
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu_lib)
+    n_atoms = torch.tensor([4, 3])
+    torch.manual_seed(0)
+    gat, _ = model.sample(n_atoms, n_timesteps=4, device='cpu', return_tensors=True, dfm_type='gat',
+                          forward_weight_func=lambda t: 1.5, inv_temp_func=lambda t: 0.9)
+    assert torch.isfinite(gat['x']).all()
+    assert int(gat['a'].max()) <= model.cfg.n_atom_types and int(gat['e'].max()) <= model.cfg.n_bond_types
+    model.cfg = dataclasses.replace(model.cfg, dfm_type='gat', forward_weight_schedule=1.5)
+    torch.manual_seed(0)
+    gat2, _ = model.sample(n_atoms, n_timesteps=4, device='cpu', return_tensors=True, inv_temp_func=lambda t: 0.9)
+    for k in 'xace':
+        assert torch.equal(gat[k], gat2[k])
+    with pytest.raises(ValueError):
+        model.sample(n_atoms, n_timesteps=4, device='cpu', dfm_type='euler')
+    with pytest.raises(TypeError):
+        model.sample(n_atoms, n_timesteps=4, device='cpu', not_an_argument=1)

@@ -84,6 +84,20 @@ def test_integrate_matches_reference_golden(golden_dir, fname, name):
     assert (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()   # no mask tokens left
 
 
+@pytest.mark.parametrize('fname,dfm_type', [('integrate_qm9_gat.npz', 'gat'), ('integrate_qm9_sched.npz', 'campbell')])
+def test_integrator_variants_match_reference_golden(golden_dir, fname, dfm_type):
+    """SURVEY 8f rank 4 on the GPU: non-uniform tspan, 'decay' temperature schedule, inv_temp_func, and dfm_type
+    'gat' with the 'beta' forward weight (ctmc_vector_field.py:71-95, 287-340, 463-510) vs the reference's own run."""
+    from parity_util import integrate_variant_golden
+    cfg, sd, eng, orc = engine_for('qm9')
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / fname).items()}
+    res = integrate_variant_golden(eng, cfg, g, dfm_type, device='cuda:0')
+    _report(f'integrate_variant[{fname}]', res)
+    assert res['a_flips'] == 0 and res['c_flips'] == 0 and res['e_flips'] == 0, res
+    assert res['traj0_a_flips'] == 0 and res['traj0_a1_flips'] == 0, res
+    assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res
+
+
 def test_ctmc_step_teacher_forced_bit_exact():
     """Given the oracle's probabilities and the same noise, the sampled indices are bit-exact
     (incl. purity-sampling edge cases: hc=0 branch, last step)."""

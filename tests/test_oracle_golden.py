@@ -99,6 +99,36 @@ def test_integrate_matches_reference(golden_dir, fname, name):
     assert (out['e_1'].argmax(-1) != cfg.n_bond_types).all()
 
 
+@pytest.mark.parametrize('fname,dfm_type', [('integrate_qm9_gat.npz', 'gat'), ('integrate_qm9_sched.npz', 'campbell')])
+def test_integrator_variants_match_reference(golden_dir, fname, dfm_type):
+    """non-uniform tspan + 'decay' temperature schedule + inv_temp_func, with dfm_type 'campbell'
+    and 'gat' ('beta' forward-weight schedule): oracle vs the reference's own run, recorded noise."""
+    from parity_util import variant_cfg, variant_inv_temp
+    sys_cfg = variant_cfg(presets.qm9())
+    g = _load(golden_dir, fname)
+    orc = cpu_ref.OracleVF(sys_cfg, weights.synth_state_dict(sys_cfg, 0))
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
+    prior = {'x_0': g['x_0'], 'a_0': cpu_ref.ctmc_masked_prior(batch.N, sys_cfg.n_atom_types),
+             'c_0': cpu_ref.ctmc_masked_prior(batch.N, sys_cfg.n_charges),
+             'e_0': cpu_ref.edge_prior(batch.upper_edge_mask, sys_cfg.n_bond_types)}
+    noise = cpu_ref.TapeNoise(tape)
+    ctf = lambda t: 0.8 * torch.pow(1 - t, 2)                                  # ctmc_vector_field.py:74
+    fwf = lambda t: 1 + 10.0 * torch.pow(t, 0.25) * torch.pow(1 - t, 0.25)     # :87
+    with torch.no_grad():
+        out, frames = orc.integrate(batch, prior, 0, noise=noise, visualize=True, tspan=g['tspan'], dfm_type=dfm_type,
+                                    cat_temp_func=ctf, forward_weight_func=fwf, inv_temp_func=variant_inv_temp)
+    assert noise.pos == len(tape)
+    m = batch.upper_edge_mask
+    assert torch.equal(out['a_1'].argmax(-1), g['a_1'])
+    assert torch.equal(out['c_1'].argmax(-1), g['c_1'])
+    assert torch.equal(out['e_1'][m].argmax(-1), g['e_1_upper'])
+    torch.testing.assert_close(out['x_1'], g['x_1'], rtol=1e-5, atol=1e-5)
+    n0 = int(g['n_atoms'][0])
+    torch.testing.assert_close(torch.stack([f[:n0] for f in frames['x']]), g['traj0.x'], rtol=1e-5, atol=1e-5)
+    assert torch.equal(torch.stack([f[:n0].argmax(-1) for f in frames['a_1_pred']]), g['traj0.a_1_pred'])
+
+
 def test_misc_matches_reference(golden_dir):
     g = _load(golden_dir, 'misc.npz')
     torch.testing.assert_close(cpu_ref.time_embedding(g['temb.t'], 64), g['temb.out'], **TOL)
