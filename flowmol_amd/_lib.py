@@ -84,6 +84,7 @@ _EXPORTS = {
     'fm_set_tap': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     'fm_clear_taps': (C.c_int, [C.c_void_p]),
     'fm_batch_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p]),
+    'fm_stability': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'fm_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'fm_profile_get': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -6,12 +6,16 @@
 
 Writes an SDF of the sampled molecules (V2000 blocks written without RDKit; RDKit's writer is used when RDKit
 is installed), or with --xt_traj / --ep_traj one ``<stem>_<i>_xt.sdf`` / ``<stem>_<i>_ep.sdf`` per molecule.
-``--metrics`` (RDKit / PoseBusters analysis) is outside the hot path and not implemented.
+``--metrics`` writes ``<stem>_metrics.txt`` / ``.pkl`` like the reference (test.py:153-199) with the metrics that need
+no RDKit: valence stability against the dataset's shipped valency table and bond-graph connectivity, counted on the
+GPU (flowmol_amd/metrics.py); ``--n_subsets k`` reports mean and 95 % CI over k subsets.  RDKit validity, REOS/rings
+and PoseBusters are outside the MI355X hot path.
 """
 from __future__ import annotations
 
 import argparse
 import math
+import pickle
 import time
 from pathlib import Path
 
@@ -31,7 +35,9 @@ def parse_args(argv=None):
     p.add_argument('--n_timesteps', type=int, default=250)
     p.add_argument('--xt_traj', action='store_true')
     p.add_argument('--ep_traj', action='store_true')
-    p.add_argument('--metrics', action='store_true')
+    p.add_argument('--metrics', action='store_true', help='valence-stability / connectivity metrics of the samples')
+    p.add_argument('--n_subsets', type=int, default=None, help='split the samples into subsets for mean / 95%% CI of the metrics')
+    p.add_argument('--metrics_dataset', type=str, default=None, help='valency table to use (default: the model\'s dataset)')
     p.add_argument('--max_batch_size', type=int, default=128)
     p.add_argument('--stochasticity', type=float, default=None)
     p.add_argument('--hc_thresh', type=float, default=None)
@@ -42,8 +48,6 @@ def parse_args(argv=None):
         raise ValueError('specify exactly one of --model_dir, --checkpoint, --preset')
     if args.hc_thresh is not None and not (0 <= args.hc_thresh <= 1):
         raise ValueError('hc_thresh must be on the interval [0, 1]')
-    if args.metrics:
-        raise NotImplementedError('--metrics needs RDKit/PoseBusters and is outside the MI355X hot path (SURVEY.md §8)')
     return args
 
 
@@ -60,6 +64,33 @@ def write_sdf(path: Path, blocks):
         for b in blocks:
             f.write(b)
             f.write('$$$$\n')
+
+
+def write_metrics(args, model, molecules, out: Path):
+    """test.py:153-199: whole-set metrics, or mean and 95 % CI over --n_subsets subsets."""
+    from .metrics import SampleAnalyzer
+    analyzer = SampleAnalyzer(model, dataset=args.metrics_dataset)
+    if args.n_subsets is not None and args.n_subsets > 1:
+        per = len(molecules) / args.n_subsets
+        subs = []
+        for i in range(args.n_subsets):
+            lo = int(i * per)
+            subs.append(analyzer.analyze(molecules[lo:min(int(lo + per), len(molecules))]))
+        metrics = {}
+        for key in subs[0]:
+            vals = torch.tensor([d[key] for d in subs], dtype=torch.float64)
+            metrics[key] = float(vals.mean())
+            metrics[f'{key}_ci95'] = float(1.96 * vals.std(unbiased=False) / math.sqrt(len(subs)))
+    else:
+        metrics = analyzer.analyze(molecules)
+    txt, pkl = out.parent / f'{out.stem}_metrics.txt', out.parent / f'{out.stem}_metrics.pkl'
+    print(f'Writing metrics to {txt} and {pkl}')
+    with open(txt, 'w') as f:
+        for k, v in metrics.items():
+            f.write(f'{k}: {v}\n')
+    with open(pkl, 'wb') as f:
+        pickle.dump(metrics, f)
+    return metrics
 
 
 def run(args, engine_lib=None):
@@ -84,6 +115,8 @@ def run(args, engine_lib=None):
         base = args.model_dir if args.model_dir is not None else Path('.')
         out = base / 'samples' / 'sampled_mols.sdf'
     out.parent.mkdir(parents=True, exist_ok=True)
+    if args.metrics:
+        write_metrics(args, model, molecules, out)
     if out.suffix != '.sdf':
         raise ValueError('output file must be an sdf file')
     if not (args.xt_traj or args.ep_traj):

@@ -61,6 +61,7 @@ struct fm_ctx {
     int tab_rows = 0, tab_kp = 0;
     // ---- batch binding
     bool bound = false;
+    int nmax = 0;             // atoms of the largest molecule of the bound batch
     FmBatch b{};
     int n_tiles_e = 0, n_tiles_n = 0, n_tiles_u = 0;
     float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
@@ -648,7 +649,7 @@ int fm_destroy(fm_ctx* c) {
 
 // ---------------------------------------------------------------------------------------- workspace
 struct WsLayout {
-    int B, N, E, U, P, tab_rows, tab_kp;
+    int B, N, E, U, P, nmax, tab_rows, tab_kp;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_stab, off_tabin, off_bx, off_ba,
         off_bc, off_be, off_cnt, off_hc, off_sa1, off_sc1, off_se1, total;
@@ -668,7 +669,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     if (N > 0x7fffffffLL / 1024) return fail(c, FM_ERR_INVALID, "batch too large: %lld nodes (limit %lld per bind; split the batch)", N, 0x7fffffffLL / 1024);
     const int V = c->V;
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
-    w.P = (nmax - 2) / c->tm_edge + 2;
+    w.P = (nmax - 2) / c->tm_edge + 2; w.nmax = nmax;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -733,7 +734,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     const int work = w.E > w.N ? w.E : w.N;
     L("batch_setup", fm_k_batch_setup, dim3((work + 255) / 256), dim3(256), 0, b);
     if (L.rc) return L.rc;
-    c->bound = true;
+    c->bound = true; c->nmax = w.nmax;
     return FM_OK;
 }
 
@@ -831,6 +832,19 @@ int fm_tlog_read(unsigned long long* out, int reset) {
     return 0;
 }
 #endif
+
+int fm_stability(fm_ctx* c, void* stream, const fm_state* state, const uint32_t* table, int n_types, int fake_atom_token,
+                 int explicit_aromaticity, int32_t* out) {
+    if (!c || !state || !table || !out) return fail(c, FM_ERR_INVALID, "fm_stability: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_stability: no batch bound");
+    if (!state->a_t || !state->c_t || !state->e_t) return fail(c, FM_ERR_INVALID, "fm_stability: state tokens missing");
+    Launch L{c, (hipStream_t)stream};
+    FmStabArgs a{};
+    a.b = c->b; a.a = state->a_t; a.c = state->c_t; a.e = state->e_t; a.table = table; a.n_types = n_types; a.n_charges = c->nc;
+    a.fake_tok = fake_atom_token; a.ne = c->ne; a.arom = explicit_aromaticity; a.out = out;
+    L("stability", fm_k_stability, dim3(c->b.B), dim3(64), (size_t)c->nmax * 8, a);
+    return L.rc;
+}
 
 int fm_profile_enable(fm_ctx* c, int on) {
     if (!c) return FM_ERR_INVALID;

@@ -924,3 +924,87 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_gat(FmGatArgs a) {
     a.xt[i] = best;
     a.x1[i] = amax;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Valence stability + connectivity of the sampled molecules straight from the final tokens (reference
+// flowmol/analysis/metrics.py:96-117,333-363 with molecule_builder.py:138-157,217-265: fake atoms removed,
+// mask bond token = no bond, valency = sum of bond orders with aromatic = 1.5).  One workgroup per molecule.
+//   table[a * n_charges + c]: bit v set <=> valency v is valid for atom token a with charge token c
+//   (explicit aromaticity: bit n_arom*8 + v for the (n_arom, v) pairs of the aromatic tables); 0 = charge not listed.
+//   out[m] = {stable atoms, real atoms, connected components of the real atoms, size of the largest component}
+// ------------------------------------------------------------------------------------------------
+struct FmStabArgs {
+    FmBatch b;
+    const int* a; const int* c; const int* e;     // tokens: (N), (N), (U)
+    const unsigned* table; int n_types, n_charges;
+    int fake_tok;                                  // atom token of the fake atom ('Sn'), -1 if the model has none
+    int ne;                                        // number of bond types; token ne = mask = no bond
+    int arom;                                      // explicit aromaticity: bond token 4 = aromatic (1.5)
+    int* out;                                      // (B,4)
+};
+
+__global__ void __launch_bounds__(64) fm_k_stability(FmStabArgs s) {
+    HIP_DYNAMIC_SHARED(int, sm)
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int n0 = s.b.mol_node_off[m], n = s.b.mol_node_off[m + 1] - n0, p0 = s.b.mol_pair_off[m];
+    int* label = sm;            // [n]
+    int* cnt = sm + n;          // [n]
+    __shared__ int acc[4];
+    __shared__ int changed;
+    if (tid < 4) acc[tid] = 0;
+    __syncthreads();
+    auto bond = [&](int i, int j) {       // bond token of the unordered pair, mask -> 0
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int t = s.e[p0 + lo * (2 * n - lo - 1) / 2 + (hi - lo - 1)];
+        return t == s.ne ? 0 : t;
+    };
+    for (int i = tid; i < n; i += 64) {
+        const int at = s.a[n0 + i];
+        const bool real = at != s.fake_tok;
+        label[i] = real ? i : -1;
+        cnt[i] = 0;
+        if (!real) continue;
+        int val2 = 0, narom = 0;           // valency in half-bond units
+        for (int j = 0; j < n; ++j) {
+            if (j == i || s.a[n0 + j] == s.fake_tok) continue;
+            const int t = bond(i, j);
+            if (s.arom && t == 4) { val2 += 3; ++narom; }
+            else val2 += 2 * t;
+        }
+        const int v = s.arom ? (val2 - 3 * narom) / 2 : val2 / 2;
+        const int bit = s.arom ? narom * 8 + v : v;
+        const int ct = s.c[n0 + i];
+        bool stable = false;
+        if (at < s.n_types && ct < s.n_charges && bit < 32 && (!s.arom || v < 8))
+            stable = (s.table[at * s.n_charges + ct] >> bit) & 1u;
+        atomicAdd(&acc[1], 1);
+        if (stable) atomicAdd(&acc[0], 1);
+    }
+    __syncthreads();
+    // connected components by min-label propagation (monotone, so in-place updates are safe)
+    for (int it = 0; it < n; ++it) {
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 64) {
+            int l = label[i];
+            if (l < 0) continue;
+            for (int j = 0; j < n; ++j) {
+                const int lj = label[j];
+                if (j != i && lj >= 0 && lj < l && bond(i, j) != 0) l = lj;
+            }
+            if (l != label[i]) { label[i] = l; changed = 1; }
+        }
+        __syncthreads();
+        const int ch = changed;
+        __syncthreads();
+        if (!ch) break;
+    }
+    for (int i = tid; i < n; i += 64) if (label[i] >= 0) atomicAdd(&cnt[label[i]], 1);
+    __syncthreads();
+    for (int i = tid; i < n; i += 64) {
+        if (label[i] == i) atomicAdd(&acc[2], 1);
+        if (cnt[i] > 0) atomicMax(&acc[3], cnt[i]);
+    }
+    __syncthreads();
+    if (tid < 4) s.out[m * 4 + tid] = acc[tid];
+}

@@ -322,6 +322,19 @@ class Engine:
             self._check(self.lib.fm_remove_com(self._ctx, self._stream(), _ptr(x)), 'fm_remove_com')
         return x
 
+    def stability(self, state, table: torch.Tensor, fake_atom_token: int = -1, explicit_aromaticity: bool = False) -> torch.Tensor:
+        """Valence stability + connectivity of the bound batch's molecules from their tokens, on the device
+        (see fm_stability).  table: (n_types, n_charges) int32 bit masks.  Returns (B,4) int32:
+        stable atoms, real atoms, connected components, largest component."""
+        tab = table.detach().to(self.device, torch.int32).contiguous()
+        assert tab.dim() == 2 and tab.shape[1] == self.cfg.n_charges
+        out = torch.empty(self.B, 4, dtype=torch.int32, device=self.device)
+        st = self._state_struct(state)
+        with self._dev():
+            self._check(self.lib.fm_stability(self._ctx, self._stream(), C.byref(st), _ptr(tab), int(tab.shape[0]),
+                                              int(fake_atom_token), int(bool(explicit_aromaticity)), _ptr(out)), 'fm_stability')
+        return out
+
     # ------------------------------------------------------------------ hot path
     def forward(self, state, t: float, prev=None, bootstrap=False, remove_com=True, out=None, taps: Optional[Dict[str, torch.Tensor]] = None):
         """One network evaluation -> dst dict of probabilities (EndpointVectorField.forward with

@@ -177,6 +177,14 @@ int fm_set_tap(fm_ctx* ctx, const char* name, void* dst);
 int fm_clear_taps(fm_ctx* ctx);
 int fm_batch_query(fm_ctx* ctx, void* stream, const char* name, int32_t* dst);
 
+/* Valence stability and connectivity of the molecules in `state` (tokens), computed on the device
+ * (reference flowmol/analysis/metrics.py:96-117 + check_stability :333-363; SampledMolecule.compute_valencies,
+ * molecule_builder.py:138-157).  table: device array of n_types * n_charges uint32 bit masks (bit v = valency v valid;
+ * explicit aromaticity: bit n_arom*8+v); fake_atom_token: token of the fake atom or -1; out: device (n_mols,4) int32 =
+ * {stable atoms, real atoms, connected components, largest component}. */
+int fm_stability(fm_ctx* ctx, void* stream, const fm_state* state, const uint32_t* table, int n_types,
+                 int fake_atom_token, int explicit_aromaticity, int32_t* out);
+
 /* per-kernel timing of the last fm_forward / fm_integrate when enabled (HIP events on `stream`):
  * fm_profile_enable(ctx, 1); ... ; fm_profile_get(ctx, "edge_message", &total_ms, &launches) */
 int fm_profile_enable(fm_ctx* ctx, int on);

@@ -590,3 +590,58 @@ def extract_moldata(x_1, a_1, c_1, e_1, n_atoms: int, atom_type_map: List[str], 
     src, dst = e[0, :u], e[1, :u]
     ok = keep[src] & keep[dst] & (bt != 0)
     return positions, symbols, charges, bt[ok], new_id[src[ok]], new_id[dst[ok]]
+
+
+# --------------------------------------------------------------------------------------
+# valence stability: flowmol/analysis/molecule_builder.py:138-157 and
+# flowmol/analysis/metrics.py:333-363, on the output of extract_moldata
+# --------------------------------------------------------------------------------------
+def compute_valencies(n_atoms: int, bond_types, bond_src, bond_dst, arom_dependent: bool = False):
+    """SampledMolecule.compute_valencies (molecule_builder.py:138-157)."""
+    adj = torch.zeros((n_atoms, n_atoms)).float()
+    bt = bond_types.clone().float()
+    bt[bt == 4] = 1.5
+    adj[bond_src, bond_dst] = bt
+    adj[bond_dst, bond_src] = bt
+    val = torch.sum(adj, dim=-1)
+    if arom_dependent:
+        n_arom = (adj == 1.5).sum(dim=-1)
+        val = torch.stack([n_arom, (val - n_arom * 1.5).long()], dim=1)
+    return val
+
+
+def check_stability(atom_types: List[str], valencies, charges, valid_valency_table: dict, explicit_aromaticity: bool = False):
+    """metrics.py:333-363 for a molecule whose fake atoms are already removed (extract_moldata drops them; the
+    reference's 'Sn' branch therefore never fires on sampled molecules).  Returns (n_stable_atoms, mol_stable)."""
+    n_stable = 0
+    for atom_type, valency, charge in zip(atom_types, valencies.tolist(), charges):
+        if not explicit_aromaticity:
+            valency = int(valency)
+        charge = int(charge)
+        if atom_type not in valid_valency_table:
+            continue                      # e.g. a surviving mask atom 'Se' (the reference would raise KeyError)
+        by_charge = valid_valency_table[atom_type]
+        if charge not in by_charge:
+            continue
+        if valency in by_charge[charge]:
+            n_stable += 1
+    return n_stable, n_stable == len(atom_types)
+
+
+def bond_graph_components(n_atoms: int, bond_src, bond_dst):
+    """Connected components of the bond graph: what Chem.GetMolFrags reports for the same bonds
+    (metrics.py:172-186).  Returns (number of components, size of the largest)."""
+    parent = list(range(n_atoms))
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+    for s, d in zip(bond_src.tolist(), bond_dst.tolist()):
+        parent[find(s)] = find(d)
+    sizes: Dict[int, int] = {}
+    for i in range(n_atoms):
+        r = find(i)
+        sizes[r] = sizes.get(r, 0) + 1
+    return len(sizes), (max(sizes.values()) if sizes else 0)

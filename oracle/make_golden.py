@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 from flowmol_amd import presets, weights          # noqa: E402
-from oracle import ref_standin                    # noqa: E402
+from oracle import cpu_ref, ref_standin           # noqa: E402
 
 OUT = ROOT / 'tests' / 'golden'
 
@@ -215,6 +215,82 @@ def gen_integrate_variant(ns, name, cfg, sd, sizes, tag, dfm_type):
     np.savez_compressed(OUT / f'integrate_{name}_{tag}.npz', **_np(out))
 
 
+def _ref_function(path, name, cls=None):
+    """Source-level import of ONE function (or method of class ``cls``) of a reference module that cannot be
+    imported here as a whole (rdkit at module scope): parsed with ast, compiled and executed in this container
+    only, to produce fixtures."""
+    import ast
+    tree = ast.parse(Path(path).read_text())
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    fn = next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
+    fn.decorator_list = []
+    for a in fn.args.args + fn.args.kwonlyargs:
+        a.annotation = None
+    fn.returns = None
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    env = {'torch': torch}
+    exec(compile(mod, str(path), 'exec'), env)
+    return env[name]
+
+
+def gen_stability():
+    """Random token molecules -> the reference's own compute_valencies + check_stability verdicts."""
+    import json
+    from types import SimpleNamespace
+    ref = Path('/root/reference/flowmol')
+    check = _ref_function(ref / 'analysis' / 'metrics.py', 'check_stability')
+    comp_val = _ref_function(ref / 'analysis' / 'molecule_builder.py', 'compute_valencies', cls='SampledMolecule')
+    out = {}
+    gen = torch.Generator().manual_seed(11)
+    for tag, dataset, arom, fake in (('kek', 'geom_full_kekulized', False, True), ('arom', 'geom_5_aromatic', True, False)):
+        fn = 'train_data_valencies_aromatic.json' if arom else 'train_data_valencies_kekulized.json'
+        raw = json.loads((Path('/root/reference/data') / dataset / fn).read_text())
+        table = {a: {int(c): v for c, v in cs.items()} for a, cs in raw.items()}      # metrics.py:76-79
+        atom_map = ['C', 'H', 'N', 'O', 'F', 'P', 'S', 'Cl', 'Br', 'I']
+        nb = 5 if arom else 4
+        sizes = [2, 5, 9, 14, 23, 31, 6, 7]
+        A, C_, E, res = [], [], [], []
+        for n in sizes:
+            u = n * (n - 1) // 2
+            if n == 6:      # methane + one extra atom (the fake atom, bonded to C, where the model has one; else a lone F-)
+                a = torch.tensor([0, 1, 1, 1, 1, 10 if fake else 4])
+                c = torch.tensor([2, 2, 2, 2, 2, 2 if fake else 1])
+                e = torch.zeros(u, dtype=torch.long)
+                e[0:4] = 1
+                e[4] = 1 if fake else nb         # C-fake single bond (dropped with the atom) / a masked pair
+            elif n == 7:    # ammonium + hydroxide: two fragments, every atom stable
+                a = torch.tensor([2, 1, 1, 1, 1, 3, 1]) if not arom else torch.tensor([2, 1, 1, 1, 1, 3, 1])
+                c = torch.tensor([3, 2, 2, 2, 2, 1, 2])
+                e = torch.zeros(u, dtype=torch.long)
+                e[0:4] = 1                       # N-H x4
+                e[5] = 0                         # N-O none
+                pair = lambda i, j: i * (2 * n - i - 1) // 2 + (j - i - 1)
+                e[pair(5, 6)] = 1; e[pair(4, 5)] = 0
+            else:
+                # chemistry-like sparsity so that a fair share of atoms is stable
+                a = torch.multinomial(torch.tensor([4., 5, 1, 1, .3, .1, .2, .2, .1, .1] + ([1.0] if fake else [])), n, True, generator=gen)
+                c = torch.multinomial(torch.tensor([.02, .05, 1., .08, .02, .01]), n, True, generator=gen)
+                pe = torch.tensor([1 - 2.2 / n if n > 3 else .3, 2.0 / n, .25 / n, .05 / n] + ([.5 / n] if arom else []) + [.1 / n]).clamp(min=1e-3)
+                e = torch.multinomial(pe, u, True, generator=gen)       # last index = mask token
+            A.append(a); C_.append(c); E.append(e)
+            x = torch.zeros(n, 3)
+            oh = lambda t, k: torch.nn.functional.one_hot(t, k).float()
+            pos, sym, chg, bt, bs, bd = cpu_ref.extract_moldata(x, oh(a, len(atom_map) + (2 if fake else 1)), oh(c, 6),
+                                                                torch.cat([oh(e, nb + 1)] * 2), n, atom_map, fake, nb)
+            mol = SimpleNamespace(num_atoms=len(sym), bond_types=bt, bond_src_idxs=bs, bond_dst_idxs=bd, atom_types=sym,
+                                  atom_charges=chg, fake_atoms=fake)
+            mol.valencies = comp_val(mol, arom_dependent=arom)
+            n_stable, mol_stable, n_fake = check(mol, table, explicit_aromaticity=arom)
+            res.append([n_stable, int(mol_stable), len(sym)])
+        out[f'{tag}.n_atoms'] = torch.tensor(sizes)
+        out[f'{tag}.a'] = torch.cat(A); out[f'{tag}.c'] = torch.cat(C_); out[f'{tag}.e'] = torch.cat(E)
+        out[f'{tag}.expect'] = torch.tensor(res)            # n_stable_atoms, mol_stable, real atoms
+    np.savez_compressed(OUT / 'stability.npz', **_np(out))
+
+
 def gen_misc(ns):
     out = {}
     t = torch.tensor([0.0, 0.004016064, 0.5, 0.9959839, 1.0])
@@ -267,6 +343,7 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     ns = ref_standin.import_reference()
     gen_misc(ns)
+    gen_stability()
     for name in ('flowmol3', 'geom_ctmc', 'qm9'):
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, seed=0)

@@ -159,6 +159,7 @@ static inline float __fsub_rn(float a, float b) { return a - b; }
 static inline float __fdiv_rn(float a, float b) { return a / b; }
 
 // ---------------------------------------------------------------- atomics (blocks may run on several OS threads)
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }   /* lanes run one at a time on the host */
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline float atomicAdd(float* p, float v) {

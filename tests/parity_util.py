@@ -175,3 +175,34 @@ def integrate_variant_golden(eng, cfg, g, dfm_type, chunk=4, device=None):
         'traj0_a_flips': int((traj['a'][:, :n0].cpu().long() != g['traj0.a'][1:]).sum()),
         'traj0_a1_flips': int((traj['a1'][:, :n0].cpu().long() != g['traj0.a_1_pred']).sum()),
     }
+
+
+def stability_compare(eng, g, tag, dataset, arom, fake):
+    """fm_stability on the fixture's token molecules vs (a) the reference's own check_stability verdicts stored in
+    tests/golden/stability.npz and (b) the oracle's bond-graph components.  Returns the list of mismatches."""
+    import torch.nn.functional as F
+    from flowmol_amd import metrics
+    from oracle import cpu_ref
+    atom_map = ['C', 'H', 'N', 'O', 'F', 'P', 'S', 'Cl', 'Br', 'I']
+    nb = 5 if arom else 4
+    table, ar = metrics.load_valency_table(dataset)
+    enc = metrics.encode_valency_table(table, atom_map, 6, arom)
+    n_atoms = g[f'{tag}.n_atoms']
+    eng.bind(n_atoms)
+    state = eng.make_state(torch.zeros(eng.N, 3), g[f'{tag}.a'], g[f'{tag}.c'], g[f'{tag}.e'])
+    got = eng.stability(state, enc, len(atom_map) if fake else -1, arom).cpu()
+    bad = []
+    no = po = 0
+    for i, n in enumerate(n_atoms.tolist()):
+        u = n * (n - 1) // 2
+        a, c, e = g[f'{tag}.a'][no:no + n], g[f'{tag}.c'][no:no + n], g[f'{tag}.e'][po:po + u]
+        no += n; po += u
+        pos, sym, chg, bt, bs, bd = cpu_ref.extract_moldata(torch.zeros(n, 3), F.one_hot(a, len(atom_map) + (2 if fake else 1)).float(),
+                                                            F.one_hot(c, 6).float(), torch.cat([F.one_hot(e, nb + 1).float()] * 2), n,
+                                                            atom_map, fake, nb)
+        ncomp, largest = cpu_ref.bond_graph_components(len(sym), bs, bd)
+        n_stable, _, n_real = g[f'{tag}.expect'][i].tolist()
+        want = [n_stable, n_real, ncomp, largest]
+        if got[i].tolist() != want:
+            bad.append((i, got[i].tolist(), want))
+    return bad

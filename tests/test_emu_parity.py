@@ -78,6 +78,18 @@ def test_cli_writes_sdf_and_trajectories_on_emulation(emu_lib, tmp_path):
     ep = (tmp_path / 'tr_0_ep.sdf').read_text()
     assert xt.count('$$$$') == 3 and ep.count('$$$$') == 2          # T frames / T-1 endpoint frames
     assert ' Se ' in xt                                               # masked atoms of early frames show up as Se
+    # --metrics: valence stability / connectivity files like test.py:190-199 (qm9 ships no valency table -> choose one)
+    import pickle
+    args = cli.parse_args(['--preset', 'qm9', '--n_mols', '4', '--n_atoms_per_mol', '4', '--n_timesteps', '3', '--seed', '1',
+                           '--device', 'cpu', '--metrics', '--metrics_dataset', 'geom_full_kekulized', '--n_subsets', '2',
+                           '--output_file', str(tmp_path / 'm.sdf')])
+    cli.run(args, engine_lib=emu_lib)
+    met = pickle.loads((tmp_path / 'm_metrics.pkl').read_bytes())
+    assert {'frac_atoms_stable', 'frac_mols_stable_valence', 'frac_atoms_stable_ci95', 'frac_connected'} <= set(met)
+    assert 0.0 <= met['frac_atoms_stable'] <= 1.0 and 'frac_mols_stable_valence:' in (tmp_path / 'm_metrics.txt').read_text()
+    with pytest.raises(FileNotFoundError):
+        cli.run(cli.parse_args(['--preset', 'qm9', '--n_mols', '1', '--n_atoms_per_mol', '3', '--n_timesteps', '2', '--device', 'cpu',
+                                '--metrics', '--output_file', str(tmp_path / 'n.sdf')]), engine_lib=emu_lib)
 
 
 def test_sample_kwargs_tspan_cat_temp_and_prior_on_emulation(emu_lib):
@@ -145,3 +157,19 @@ def test_sample_accepts_variant_kwargs_on_emulation(emu_lib):
         model.sample(n_atoms, n_timesteps=4, device='cpu', dfm_type='euler')
     with pytest.raises(TypeError):
         model.sample(n_atoms, n_timesteps=4, device='cpu', not_an_argument=1)
+
+
+@pytest.mark.parametrize('tag,dataset,arom,fake,preset', [('kek', 'geom_full_kekulized', False, True, 'flowmol3'),
+                                                          ('arom', 'geom_5_aromatic', True, False, None)])
+def test_stability_kernel_on_emulation(emu_lib, golden_dir, tag, dataset, arom, fake, preset):
+    """the device valence-stability / connectivity counts vs the reference's check_stability
+    verdicts (fixture made by oracle/make_golden.py from the reference's own functions)."""
+    import dataclasses
+    from flowmol_amd.engine import Engine
+    from parity_util import stability_compare
+    cfg = presets.flowmol3()
+    if preset is None:      # an explicit-aromaticity model without fake atoms (geom_5_aromatic-style)
+        cfg = dataclasses.replace(cfg, fake_atoms=False, n_bond_types=5, explicit_aromaticity=True)
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'stability.npz').items()}
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
+    assert stability_compare(eng, g, tag, dataset, arom, fake) == []

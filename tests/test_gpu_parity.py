@@ -98,6 +98,21 @@ def test_integrator_variants_match_reference_golden(golden_dir, fname, dfm_type)
     assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res
 
 
+@pytest.mark.parametrize('tag,dataset,arom,fake', [('kek', 'geom_full_kekulized', False, True), ('arom', 'geom_5_aromatic', True, False)])
+def test_stability_kernel_matches_reference_verdicts(golden_dir, tag, dataset, arom, fake):
+    """device valence-stability / connectivity counts vs the reference's check_stability verdicts."""
+    import dataclasses
+    from flowmol_amd import _lib
+    from flowmol_amd.engine import Engine
+    from parity_util import stability_compare
+    cfg = presets.flowmol3()
+    if arom:
+        cfg = dataclasses.replace(cfg, fake_atoms=False, n_bond_types=5, explicit_aromaticity=True)
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'stability.npz').items()}
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', lib=_lib.get_lib())
+    assert stability_compare(eng, g, tag, dataset, arom, fake) == []
+
+
 def test_ctmc_step_teacher_forced_bit_exact():
     """Given the oracle's probabilities and the same noise, the sampled indices are bit-exact
     (incl. purity-sampling edge cases: hc=0 branch, last step)."""

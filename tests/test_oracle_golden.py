@@ -154,3 +154,27 @@ def test_campbell_step_matches_reference(golden_dir, case):
                                    torch.tensor(dt), sizes.shape[0], 12, 11, bool(last), bidx, cpu_ref.TapeNoise(tape))
     assert torch.equal(xt1h.argmax(-1), g[f'ctmc.{case}.xt_new'])
     assert torch.equal(x11h.argmax(-1), g[f'ctmc.{case}.x1'])
+
+
+@pytest.mark.parametrize('tag,dataset,arom,fake', [('kek', 'geom_full_kekulized', False, True), ('arom', 'geom_5_aromatic', True, False)])
+def test_stability_restatement_matches_reference(golden_dir, tag, dataset, arom, fake):
+    """oracle compute_valencies + check_stability vs the verdicts of the reference's own functions
+    (molecule_builder.py:138-157, metrics.py:333-363) on the token molecules of tests/golden/stability.npz."""
+    import torch.nn.functional as F
+    from flowmol_amd import metrics
+    g = _load(golden_dir, 'stability.npz')
+    table, ar = metrics.load_valency_table(dataset)
+    assert ar == arom
+    atom_map = ['C', 'H', 'N', 'O', 'F', 'P', 'S', 'Cl', 'Br', 'I']
+    nb = 5 if arom else 4
+    no = po = 0
+    for i, n in enumerate(g[f'{tag}.n_atoms'].tolist()):
+        u = n * (n - 1) // 2
+        a, c, e = g[f'{tag}.a'][no:no + n], g[f'{tag}.c'][no:no + n], g[f'{tag}.e'][po:po + u]
+        no += n; po += u
+        pos, sym, chg, bt, bs, bd = cpu_ref.extract_moldata(torch.zeros(n, 3), F.one_hot(a, len(atom_map) + (2 if fake else 1)).float(),
+                                                            F.one_hot(c, 6).float(), torch.cat([F.one_hot(e, nb + 1).float()] * 2), n,
+                                                            atom_map, fake, nb)
+        val = cpu_ref.compute_valencies(len(sym), bt, bs, bd, arom_dependent=arom)
+        n_stable, mol_stable = cpu_ref.check_stability(sym, val, chg, table, explicit_aromaticity=arom)
+        assert [n_stable, int(mol_stable), len(sym)] == g[f'{tag}.expect'][i].tolist()
