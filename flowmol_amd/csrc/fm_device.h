@@ -349,7 +349,6 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     float bias_s[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bias_s[j] = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
-    const float bias_g = w.bg[(wave % (VOP / 16)) * 16 + (lane & 15)];   // gate job `wave` has column tile wave % (VOP/16)
 
     if (!FIRST) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
@@ -428,23 +427,32 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         __syncthreads();
     }
     FM_MARKB(5);
-    // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128): (TM/16) x (VOP/16) single-tile jobs, K = 256
-    for (int job = wave; job < (TM / 16) * (VOP / 16); job += NW) {
+    // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128): NJ = (TM/16) x (VOP/16) single-tile jobs, K = 256.
+    // With fewer jobs than half the waves, K is split in two: waves [0,NJ) take k < 128 and write G, waves [NJ,2NJ)
+    // take k >= 128 and write G2 (in Vh, dead since the scalar GEMM); the gating loop adds the halves and the bias.
+    // (The 64-MFMA dependent chain of an unsplit job was the critical path of this phase: profiles/r01c.)
+    constexpr int NJ = (TM / 16) * (VOP / 16);
+    constexpr int KS = (NW >= 2 * NJ) ? 2 : 1;
+    float* G2 = Vh;
+    for (int jw = wave; jw < NJ * KS; jw += NW) {
+        const int job = jw % NJ, half = jw / NJ;
         const int m0 = job / (VOP / 16), n0 = job % (VOP / 16);
-        const f32x4 g = fm_wave_gemm_1x1<32, 8>(X + (size_t)m0 * 16 * FM_LDX, FM_LDX, w.Wg, VOP / 16, n0, lane);
-        const int col = n0 * 16 + (lane & 15);
-        const float bg = (job == wave) ? bias_g : w.bg[col];
+        const f32x4 g = fm_wave_gemm_1x1<32 / KS, 8>(X + (size_t)m0 * 16 * FM_LDX + half * (256 / KS), FM_LDX,
+                                                     w.Wg + (size_t)half * (32 / KS) * (VOP / 16) * 64, VOP / 16, n0, lane);
+        float* go = (half ? G2 : G) + (m0 * 16 + 4 * (lane >> 4)) * FM_LDG + n0 * 16 + (lane & 15);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = g[r] + bg;
-            G[(m0 * 16 + 4 * (lane >> 4) + r) * FM_LDG + col] = SIGMOID ? fm_sigmoid(v) : v;
-        }
+        for (int r = 0; r < 4; ++r) go[r * FM_LDG] = g[r];
     }
     FM_MARKB(6);
     __syncthreads();
-    for (int idx = tid; idx < 3 * TM * VOUT; idx += NTH) {
-        const int row = idx / VOUT, u = idx % VOUT;
-        Vin[row * T::LDVI + u] *= G[(row % TM) * FM_LDG + u];
+    // gating: one (row, channel) pair per thread and iteration, its gate applied to the three spatial components
+    for (int idx = tid; idx < TM * VOUT; idx += NTH) {
+        const int r = idx / VOUT, u = idx % VOUT;
+        float gv = G[r * FM_LDG + u] + w.bg[u];
+        if (KS == 2) gv += G2[r * FM_LDG + u];
+        if (SIGMOID) gv = fm_sigmoid(gv);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Vin[(c * TM + r) * T::LDVI + u] *= gv;
     }
     __syncthreads();
     FM_MARKB(7);
