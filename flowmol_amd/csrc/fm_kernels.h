@@ -406,22 +406,22 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     {
         // thread -> (row chunk q, column j of a 16-wide block); chunk = (xyz c, block cb, row r).  With TM*16 == NTH the
         // chunk's (c, cb) is the unrolled loop index and r = q, so every address is one VGPR + an immediate.
-        constexpr int CB = (V + 16) / 16, NCH = 3 * CB * TM, QN = NTH / 16, NP = NCH / QN;
-        static_assert(NCH % QN == 0, "Vh fill must divide evenly");
+        constexpr int CB = (V + 16) / 16, NCH = 3 * CB * TM, QN = NTH / 16, NP = (NCH + QN - 1) / QN;
         const int q = tid >> 4, j = tid & 15;
         const auto rs = fm_buf(a.PV, (unsigned)a.b.N * (unsigned)(3 * (V + 16) * 4));
         float pv[NP], w0v[NP];
 #pragma unroll
         for (int p_ = 0; p_ < NP; ++p_) {
             const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
-            const int sidx = m_src[r];
+            const int sidx = (NCH % QN == 0 || ch < NCH) ? m_src[r] : -1;
             pv[p_] = fm_buf_f32(rs, sidx >= 0 ? sidx * (3 * (V + 16) * 4) + j * 4 : FM_BUF_OOB, (c * (V + 16) + cb * 16) * 4);
             w0v[p_] = a.w0[cb * 16 + j];
         }
 #pragma unroll
         for (int p_ = 0; p_ < NP; ++p_) {
             const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
-            Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = (m_src[r] >= 0) ? pv[p_] + m_geo[4 * r + c] * w0v[p_] : 0.f;
+            if (NCH % QN == 0 || ch < NCH)
+                Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = (m_src[r] >= 0) ? pv[p_] + m_geo[4 * r + c] * w0v[p_] : 0.f;
         }
     }
     for (int idx = tid; idx < TM * 32; idx += NTH) {
