@@ -115,11 +115,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one process per GPU; FM_BENCH_BACKEND=gloo lets several ranks share a device to exercise this path on a 1-GPU box
+    backend = os.environ.get('FM_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from flowmol_amd import presets, weights, shard
     from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan

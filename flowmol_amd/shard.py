@@ -54,29 +54,37 @@ def gather_results(local: Dict[str, torch.Tensor], n_atoms_all: torch.Tensor, pa
         nr = n_all[parts[r]]
         sizes.append((int(nr.sum()), int((nr * (nr - 1) // 2).sum())))
     nbytes = [N * 14 + U for N, U in sizes]
-    cap = max(nbytes)
+    cap = (max(nbytes) + 15) // 16 * 16          # 16-byte slots: the fp32 view of a rank's slice needs 4-byte alignment
     dev = local['x'].device
     send = torch.zeros(cap, dtype=torch.uint8, device=dev)
     mine = pack_results(local['x'], local['a'], local['c'], local['e'])
     send[:mine.numel()] = mine
     recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
-    # scatter back to the original molecule order
+    # scatter back to the original molecule order (index arithmetic vectorised: no per-molecule Python work)
     Ntot = int(n_all.sum())
-    Utot = int((n_all * (n_all - 1) // 2).sum())
-    node_off = torch.zeros(len(n_all) + 1, dtype=torch.int64)
-    node_off[1:] = torch.cumsum(n_all, 0)
-    pair_off = torch.zeros(len(n_all) + 1, dtype=torch.int64)
-    pair_off[1:] = torch.cumsum(n_all * (n_all - 1) // 2, 0)
+    pairs_all = n_all * (n_all - 1) // 2
+    Utot = int(pairs_all.sum())
+    node_off = torch.cumsum(n_all, 0) - n_all
+    pair_off = torch.cumsum(pairs_all, 0) - pairs_all
     out = {'x': torch.empty(Ntot, 3, device=dev), 'a': torch.empty(Ntot, dtype=torch.int32, device=dev),
            'c': torch.empty(Ntot, dtype=torch.int32, device=dev), 'e': torch.empty(Utot, dtype=torch.int32, device=dev)}
     for r in range(world):
         N, U = sizes[r]
         got = unpack_results(recv[r * cap:r * cap + nbytes[r]], N, U)
-        nidx = torch.cat([torch.arange(node_off[i], node_off[i + 1]) for i in parts[r].tolist()]) if len(parts[r]) else torch.zeros(0, dtype=torch.int64)
-        pidx = torch.cat([torch.arange(pair_off[i], pair_off[i + 1]) for i in parts[r].tolist()]) if len(parts[r]) else torch.zeros(0, dtype=torch.int64)
-        out['x'][nidx.to(dev)] = got['x']
-        out['a'][nidx.to(dev)] = got['a']
-        out['c'][nidx.to(dev)] = got['c']
-        out['e'][pidx.to(dev)] = got['e']
+        nidx = _ranges(node_off[parts[r]], n_all[parts[r]]).to(dev)
+        pidx = _ranges(pair_off[parts[r]], pairs_all[parts[r]]).to(dev)
+        out['x'][nidx] = got['x']
+        out['a'][nidx] = got['a']
+        out['c'][nidx] = got['c']
+        out['e'][pidx] = got['e']
     return out
+
+
+def _ranges(starts: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+    """Concatenation of arange(starts[i], starts[i] + lens[i]) for all i."""
+    total = int(lens.sum())
+    if total == 0:
+        return torch.zeros(0, dtype=torch.int64)
+    first = torch.cumsum(lens, 0) - lens                      # position of each range in the output
+    return torch.arange(total, dtype=torch.int64) + torch.repeat_interleave(starts - first, lens)
