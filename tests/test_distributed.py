@@ -45,8 +45,13 @@ def _worker(rank, world, port, n_atoms, q):
     dist.destroy_process_group()
 
 
-def test_shard_and_gather_world2():
-    n_atoms = torch.tensor([5, 47, 12, 30, 8, 64, 3, 21, 47])
+import pytest
+
+
+@pytest.mark.parametrize('sizes', [[5, 47, 12, 30, 8, 64, 3, 21, 47],
+                                   [3, 2]])      # packed payloads of 45 and 29 bytes: slot size must be padded for the fp32 view
+def test_shard_and_gather_world2(sizes):
+    n_atoms = torch.tensor(sizes)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
