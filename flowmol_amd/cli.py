@@ -4,6 +4,9 @@
         [--n_mols 100] [--n_atoms_per_mol N] [--n_timesteps 250] [--max_batch_size 128]
         [--xt_traj] [--ep_traj] [--stochasticity eta] [--hc_thresh p] [--seed s] [--output_file out.sdf]
 
+Under ``torchrun --nproc-per-node N`` the molecules of every batch are sharded over the N GPUs of the node
+(``FlowMol.sample_distributed``: one RCCL all-gather per batch) and rank 0 writes the files.
+
 Writes an SDF of the sampled molecules (V2000 blocks written without RDKit; RDKit's writer is used when RDKit
 is installed), or with --xt_traj / --ep_traj one ``<stem>_<i>_xt.sdf`` / ``<stem>_<i>_ep.sdf`` per molecule.
 ``--metrics`` writes ``<stem>_metrics.txt`` / ``.pkl`` like the reference (test.py:153-199) with the metrics that need
@@ -93,22 +96,51 @@ def write_metrics(args, model, molecules, out: Path):
     return metrics
 
 
+def _dist_setup(args):
+    """torchrun launch (one process per GPU): RCCL process group, this rank's device.  Returns (world, rank)."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return 1, 0
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.device.startswith('cuda'):
+        args.device = f'cuda:{local}'
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device(args.device))
+    else:
+        dist.init_process_group('gloo')
+    return world, dist.get_rank()
+
+
 def run(args, engine_lib=None):
+    world, rank = _dist_setup(args)
+    if world > 1 and (args.xt_traj or args.ep_traj):
+        raise NotImplementedError('trajectory output is single-GPU (sample_distributed gathers final states only)')
     if args.seed is not None:
         torch.manual_seed(args.seed)        # the reference uses lightning's seed_everything (test.py:70-71)
     model = load_model(args, engine_lib).to(args.device).eval()
     molecules = []
     n_batches = math.ceil(args.n_mols / args.max_batch_size)
     start = time.time()
-    for _ in range(n_batches):
+    for b in range(n_batches):
         bs = min(args.n_mols - len(molecules), args.max_batch_size)
-        common = dict(device=args.device, n_timesteps=args.n_timesteps, xt_traj=args.xt_traj, ep_traj=args.ep_traj,
-                      stochasticity=args.stochasticity, high_confidence_threshold=args.hc_thresh)
-        if args.n_atoms_per_mol is None:
-            molecules.extend(model.sample_random_sizes(bs, **common))
+        common = dict(n_timesteps=args.n_timesteps, stochasticity=args.stochasticity, high_confidence_threshold=args.hc_thresh)
+        n_atoms = model.sample_n_atoms(bs) if args.n_atoms_per_mol is None else torch.full((bs,), args.n_atoms_per_mol, dtype=torch.long)
+        if world == 1:
+            molecules.extend(model.sample(n_atoms, device=args.device, xt_traj=args.xt_traj, ep_traj=args.ep_traj, **common))
         else:
-            molecules.extend(model.sample(torch.full((bs,), args.n_atoms_per_mol, dtype=torch.long), **common))
+            # every rank must shard the SAME size list: rank 0's draw is broadcast; noise streams differ per rank
+            import torch.distributed as dist
+            nb = n_atoms.to(args.device if args.device.startswith('cuda') else 'cpu')
+            dist.broadcast(nb, src=0)
+            if args.seed is not None:
+                torch.manual_seed(args.seed + 7919 * (b + 1) + rank)
+            molecules.extend(model.sample_distributed(nb.cpu(), **common))
     sampling_time = time.time() - start
+    if rank != 0:            # every rank holds the gathered batch; rank 0 writes
+        return molecules, sampling_time
     if args.output_file is not None:
         out = args.output_file
     else:

@@ -150,6 +150,33 @@ class FlowMol:
                            high_confidence_threshold=high_confidence_threshold, xt_traj=xt_traj, ep_traj=ep_traj, **kwargs)
 
     @torch.no_grad()
+    def sample_distributed(self, n_atoms: torch.Tensor, n_timesteps: int = None, group=None, return_tensors=False,
+                           **kwargs):
+        """Multi-GPU sampling (no reference counterpart): every rank of ``group`` calls this with the
+        SAME ``n_atoms``; the molecules are dealt to the ranks by cost (``shard.partition_lpt``), each rank integrates its
+        shard on its own GPU with no communication, and ONE all-gather of the packed results (``shard.gather_results``,
+        RCCL over xGMI with backend "nccl") gives every rank the full batch in the caller's order.  Each rank draws from
+        its own torch RNG stream (seed it per rank), so results depend on the world size; trajectories are not gathered."""
+        import torch.distributed as dist
+        from . import shard
+        if kwargs.get('xt_traj') or kwargs.get('ep_traj') or kwargs.get('prior') is not None:
+            raise NotImplementedError('sample_distributed gathers final states only (no trajectories / caller-supplied priors)')
+        n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        parts = shard.partition_lpt(n_atoms, world)
+        dev = self.engine.device
+        if len(parts[rank]):
+            out, _ = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors=True, **kwargs)
+            local = {k: out[k].to(dev) for k in 'xace'}
+        else:
+            i32 = dict(dtype=torch.int32, device=dev)
+            local = {'x': torch.zeros(0, 3, device=dev), 'a': torch.zeros(0, **i32), 'c': torch.zeros(0, **i32), 'e': torch.zeros(0, **i32)}
+        full = {k: v.cpu() for k, v in shard.gather_results(local, n_atoms, parts, group=group).items()}
+        if return_tensors:
+            return full, n_atoms
+        return self._package(full, n_atoms, None, False, False)
+
+    @torch.no_grad()
     def sample(self, n_atoms: torch.Tensor, n_timesteps: int = None, device=None, stochasticity=None,
                high_confidence_threshold=None, xt_traj=False, ep_traj=False, prior=None, return_tensors=False,
                **kwargs):

@@ -63,3 +63,86 @@ def test_shard_and_gather_world2(sizes):
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert all(n == int(n_atoms.sum()) for _, _, n in res)
+
+
+def _sample_worker(rank, world, port, sizes, q):
+    """Each rank: emulated engine on the CPU, its own RNG stream, sample_distributed over gloo."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pathlib import Path
+    import flowmol_amd as flowmol
+    from flowmol_amd import _lib
+    emu = _lib.load(Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so')
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu).to('cpu')
+    torch.manual_seed(100 + rank)
+    full, n = model.sample_distributed(torch.tensor(sizes), n_timesteps=3, return_tensors=True)
+    q.put((rank, {k: v.clone() for k, v in full.items()}))
+    dist.destroy_process_group()
+
+
+def test_sample_distributed_world2_matches_per_rank_runs():
+    """FlowMol.sample_distributed on 2 gloo ranks (emulated kernels): every rank gets the whole batch in the caller's
+    order, and each molecule equals what its owning rank computes alone with the same seed."""
+    from pathlib import Path
+    import flowmol_amd as flowmol
+    from flowmol_amd import _lib
+    from flowmol_amd.shard import partition_lpt
+    emu_path = Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so'
+    if not emu_path.exists():
+        pytest.skip('host emulation not built (tests/test_emu_parity.py builds it)')
+    sizes = [4, 6, 3, 5]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for k in 'xace':
+        assert torch.equal(res[0][k], res[1][k])            # both ranks hold the same gathered batch
+    n_atoms = torch.tensor(sizes)
+    parts = partition_lpt(n_atoms, 2)
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=_lib.load(emu_path)).to('cpu')
+    node_off = torch.cumsum(n_atoms, 0) - n_atoms
+    for r in range(2):
+        torch.manual_seed(100 + r)
+        alone, _ = model.sample(n_atoms[parts[r]], n_timesteps=3, return_tensors=True)
+        o = 0
+        for i in parts[r].tolist():
+            n = sizes[i]
+            assert torch.equal(res[0]['a'][node_off[i]:node_off[i] + n], alone['a'][o:o + n])
+            assert torch.allclose(res[0]['x'][node_off[i]:node_off[i] + n], alone['x'][o:o + n])
+            o += n
+
+
+def _cli_worker(rank, world, port, out_path):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'LOCAL_RANK': str(rank),
+                       'WORLD_SIZE': str(world)})
+    from pathlib import Path
+    from flowmol_amd import _lib, cli
+    emu = _lib.load(Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so')
+    args = cli.parse_args(['--preset', 'qm9', '--n_mols', '5', '--n_timesteps', '2', '--max_batch_size', '3', '--seed', '3',
+                           '--device', 'cpu', '--output_file', out_path])
+    cli.run(args, engine_lib=emu)
+    dist.destroy_process_group()
+
+
+def test_cli_under_two_ranks_writes_once(tmp_path):
+    """The CLI launched as two ranks (torchrun-style environment, gloo on the CPU emulation): sizes drawn on rank 0 are
+    broadcast, each batch is sharded, rank 0 writes all molecules exactly once."""
+    from pathlib import Path
+    if not (Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so').exists():
+        pytest.skip('host emulation not built (tests/test_emu_parity.py builds it)')
+    out = tmp_path / 'dist.sdf'
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, str(out))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert out.read_text().count('$$$$') == 5
