@@ -81,16 +81,14 @@ def _sample_worker(rank, world, port, sizes, q):
     dist.destroy_process_group()
 
 
-def test_sample_distributed_world2_matches_per_rank_runs():
+def test_sample_distributed_world2_matches_per_rank_runs(emu_lib_path):
     """FlowMol.sample_distributed on 2 gloo ranks (emulated kernels): every rank gets the whole batch in the caller's
     order, and each molecule equals what its owning rank computes alone with the same seed."""
     from pathlib import Path
     import flowmol_amd as flowmol
     from flowmol_amd import _lib
     from flowmol_amd.shard import partition_lpt
-    emu_path = Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so'
-    if not emu_path.exists():
-        pytest.skip('host emulation not built (tests/test_emu_parity.py builds it)')
+    emu_path = emu_lib_path
     sizes = [4, 6, 3, 5]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -130,12 +128,9 @@ def _cli_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_cli_under_two_ranks_writes_once(tmp_path):
+def test_cli_under_two_ranks_writes_once(tmp_path, emu_lib_path):
     """The CLI launched as two ranks (torchrun-style environment, gloo on the CPU emulation): sizes drawn on rank 0 are
     broadcast, each batch is sharded, rank 0 writes all molecules exactly once."""
-    from pathlib import Path
-    if not (Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so').exists():
-        pytest.skip('host emulation not built (tests/test_emu_parity.py builds it)')
     out = tmp_path / 'dist.sdf'
     ctx = mp.get_context('spawn')
     port = _free_port()

@@ -13,19 +13,6 @@ from flowmol_amd import _lib, presets, weights
 from oracle import cpu_ref
 from parity_util import forward_compare
 
-HERE = Path(__file__).resolve().parent
-EMU = HERE / 'emu' / 'libflowmol_emu.so'
-
-
-@pytest.fixture(scope='module')
-def emu_lib():
-    cxx = '/opt/rocm/lib/llvm/bin/clang++'
-    if not Path(cxx).exists() and not shutil.which('clang++'):
-        pytest.skip('no clang++ to build the host emulation')
-    srcs = [HERE / 'emu' / 'emu_rt.cpp', HERE / 'emu' / 'hip' / 'hip_runtime.h'] + sorted((HERE.parent / 'flowmol_amd' / 'csrc').glob('*'))
-    if not EMU.exists() or any(s.stat().st_mtime > EMU.stat().st_mtime for s in srcs):
-        subprocess.run([str(HERE / 'emu' / 'build_emu.sh')], check=True, capture_output=True)
-    return _lib.load(EMU)
 
 
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False)])
