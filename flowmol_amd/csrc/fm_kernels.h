@@ -550,43 +550,70 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = Vh + T::VH_FLOATS;
     const int tid = threadIdx.x, row0 = blockIdx.x * TM;
-    const int N = a.b.N;
-    // s + sum(pieces)/z
-    for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
-        const int r = idx >> 8, c = idx & 255, n = row0 + r;
-        float val = 0.f;
+    const int N = a.b.N, P = a.b.P;
+    const int rows = N - row0 < TM ? N - row0 : TM;                // rows of this tile that exist
+    // Number of partial-sum pieces of each row, once per row (G is free until the first gate GEMM).  Everything after
+    // it is 16-byte buffer loads through tile-relative descriptors, all of a thread's requests issued back to back:
+    // rows beyond N and pieces beyond a row's count read 0 through the range check (a per-element version of this
+    // prologue with its dependent index loads was the latency of the whole kernel at small batch sizes).
+    int* r_np = reinterpret_cast<int*>(G);
+    if (tid < TM) {
+        const int n = row0 + tid;
+        int np = 0;
         if (n < N) {
             const int m = a.b.node_mol[n];
             const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
-            float acc = 0.f;
             if (deg > 0) {
                 const int fe = a.b.node_first_edge[n];
-                const int np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
-                for (int p = 0; p < np; ++p) acc += a.part_s[((size_t)n * a.b.P + p) * 256 + c];
+                np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
             }
-            acc *= a.inv_z;
-            if (a.agg_s) a.agg_s[(size_t)n * 256 + c] = acc;
-            val = a.s[(size_t)n * 256 + c] + acc;
         }
-        X[r * FM_LDX + c] = val;
+        r_np[tid] = np;
     }
-    for (int idx = tid; idx < TM * 3 * V; idx += FM_THREADS) {
-        const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
-        float val = 0.f;
-        if (n < N) {
-            const int m = a.b.node_mol[n];
-            const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
-            float acc = 0.f;
-            if (deg > 0) {
-                const int fe = a.b.node_first_edge[n];
-                const int np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
-                for (int p = 0; p < np; ++p) acc += a.part_v[(((size_t)n * a.b.P + p) * 3 + c) * V + u];
+    __syncthreads();
+    const auto rs_s = fm_buf(a.s + (size_t)row0 * 256, (unsigned)rows * 1024u);
+    const auto rs_v = fm_buf(a.v + (size_t)row0 * 3 * V, (unsigned)rows * (3 * V * 4));
+    {
+        // s + sum(pieces)/z
+        const auto rs_p = fm_buf(a.part_s + (size_t)row0 * P * 256, (unsigned)rows * (unsigned)P * 1024u);
+        constexpr int NQ = TM * 64 / FM_THREADS;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS, r = idx >> 6, c4 = idx & 63;
+            const int np = r_np[r];
+            const float4 sv = fm_buf_f32x4(rs_s, (r * 256 + c4 * 4) * 4, 0);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p0 = 0; p0 < P; p0 += 4) {
+                float4 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = fm_buf_f32x4(rs_p, p0 + j < np ? ((r * P + p0 + j) * 256 + c4 * 4) * 4 : FM_BUF_OOB, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc.x += q[j].x; acc.y += q[j].y; acc.z += q[j].z; acc.w += q[j].w; }
             }
-            acc *= a.inv_z;
-            if (a.agg_v) a.agg_v[((size_t)n * 3 + c) * V + u] = acc;
-            val = a.v[((size_t)n * 3 + c) * V + u] + acc;
+            acc.x *= a.inv_z; acc.y *= a.inv_z; acc.z *= a.inv_z; acc.w *= a.inv_z;
+            if (a.agg_s && r < rows) *reinterpret_cast<float4*>(a.agg_s + (size_t)(row0 + r) * 256 + c4 * 4) = acc;
+            *reinterpret_cast<float4*>(X + r * FM_LDX + c4 * 4) = make_float4(sv.x + acc.x, sv.y + acc.y, sv.z + acc.z, sv.w + acc.w);
         }
-        Vin[(c * TM + r) * T::LDVI + u] = val;
+    }
+    {
+        const auto rs_p = fm_buf(a.part_v + (size_t)row0 * P * 3 * V, (unsigned)rows * (unsigned)P * (3 * V * 4));
+        constexpr int V4 = V / 4, NCHK = TM * 3 * V4;
+        for (int idx = tid; idx < NCHK; idx += FM_THREADS) {
+            const int r = idx / (3 * V4), rem = idx % (3 * V4), c = rem / V4, u4 = rem % V4;
+            const int np = r_np[r];
+            const float4 vv = fm_buf_f32x4(rs_v, ((r * 3 + c) * V + u4 * 4) * 4, 0);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p0 = 0; p0 < P; p0 += 4) {
+                float4 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = fm_buf_f32x4(rs_p, p0 + j < np ? (((r * P + p0 + j) * 3 + c) * V + u4 * 4) * 4 : FM_BUF_OOB, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc.x += q[j].x; acc.y += q[j].y; acc.z += q[j].z; acc.w += q[j].w; }
+            }
+            acc.x *= a.inv_z; acc.y *= a.inv_z; acc.z *= a.inv_z; acc.w *= a.inv_z;
+            if (a.agg_v && r < rows) *reinterpret_cast<float4*>(a.agg_v + ((size_t)(row0 + r) * 3 + c) * V + u4 * 4) = acc;
+            *reinterpret_cast<float4*>(Vin + (c * TM + r) * T::LDVI + u4 * 4) = make_float4(vv.x + acc.x, vv.y + acc.y, vv.z + acc.z, vv.w + acc.w);
+        }
     }
     __syncthreads();
     fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v);     // s1, v1 -> HBM (needed for the residual)
@@ -597,13 +624,28 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
         fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
     }
-    for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
-        const int r = idx >> 8, c = idx & 255, n = row0 + r;
-        if (n < N) X[r * FM_LDX + c] += a.s[(size_t)n * 256 + c];
-    }
-    for (int idx = tid; idx < TM * 3 * V; idx += FM_THREADS) {
-        const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
-        if (n < N) Vin[(c * TM + r) * T::LDVI + u] += a.v[((size_t)n * 3 + c) * V + u];
+    {   // residual: + (s1, v1), re-read from HBM with 16-byte loads (rows beyond N read 0)
+        constexpr int NQ = TM * 64 / FM_THREADS;
+        float4 sv[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) { const int idx = tid + k * FM_THREADS; sv[k] = fm_buf_f32x4(rs_s, ((idx >> 6) * 256 + (idx & 63) * 4) * 4, 0); }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            float4* xp = reinterpret_cast<float4*>(X + (idx >> 6) * FM_LDX + (idx & 63) * 4);
+            float4 x = *xp;
+            x.x += sv[k].x; x.y += sv[k].y; x.z += sv[k].z; x.w += sv[k].w;
+            *xp = x;
+        }
+        constexpr int V4 = V / 4, NCHK = TM * 3 * V4;
+        for (int idx = tid; idx < NCHK; idx += FM_THREADS) {
+            const int r = idx / (3 * V4), rem = idx % (3 * V4), c = rem / V4, u4 = rem % V4;
+            const float4 vv = fm_buf_f32x4(rs_v, ((r * 3 + c) * V + u4 * 4) * 4, 0);
+            float4* vp = reinterpret_cast<float4*>(Vin + (c * TM + r) * T::LDVI + u4 * 4);
+            float4 x = *vp;
+            x.x += vv.x; x.y += vv.y; x.z += vv.z; x.w += vv.w;
+            *vp = x;
+        }
     }
     __syncthreads();
     fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v);

@@ -1,0 +1,44 @@
+"""Per-step latency of the integration loop vs batch size (whole fm_integrate path, wall clock around a synchronised
+window of steps), flowmol3 architecture, 47-atom molecules.  python tools/latency_sweep.py [sizes...]"""
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch                                             # noqa: E402
+from flowmol_amd import presets, weights                 # noqa: E402
+from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan   # noqa: E402
+
+sizes = [int(a) for a in sys.argv[1:]] or [1, 8, 32, 128, 512]
+cfg = presets.flowmol3()
+eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0')
+dev = eng.device
+for B in sizes:
+    eng.bind(torch.full((B,), 47, dtype=torch.int64))
+    N, U = eng.N, eng.U
+    plan = make_step_plan(250, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    x0 = torch.randn(N, 3, device=dev)
+    eng.remove_com(x0)
+    state = eng.prior_state(x0)
+    run = IntegrationRun(eng, state, plan, lambda i, last: StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev))
+    run.run(0, 8, chunk=8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.run(8, 72, chunk=32)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 64
+    eng.profile(True)
+    run.run(72, 74, chunk=2)
+    torch.cuda.synchronize()
+    gpu_ms = 0.0
+    nl = 0
+    for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head',
+              'node_head', 'ctmc_pass1', 'ctmc_pass2', 'embed_table', 'embed_in', 'remove_com', 'x_step'):
+        ms, cnt = eng.profile_get(k)
+        gpu_ms += ms
+        nl += cnt
+    eng.profile(False)
+    print(json.dumps({'mols': B, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
+                      'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2)}))
