@@ -106,32 +106,56 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
             X[r * a.ldx + c] = (row0 + r < a.rows) ? a.in[(size_t)(row0 + r) * a.in_ld + c] : 0.f;
         }
     } else if (MODE == FM_MLP_SC_NODE) {
+        float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64] |x_t - x1_prev| per row
         if (tid < FM_TM) {
             const int n = row0 + tid;
-            meta[tid] = (n < a.rows) ? a.tok_a[n] * a.n_c1 + a.tok_c[n] : -1;
+            int tok = -1; float d = 0.f;
+            if (n < a.rows) {
+                tok = a.tok_a[n] * a.n_c1 + a.tok_c[n];
+                d = fm_norm3(a.x_t[n * 3 + 0] - a.prev_x[n * 3 + 0], a.x_t[n * 3 + 1] - a.prev_x[n * 3 + 1], a.x_t[n * 3 + 2] - a.prev_x[n * 3 + 2]);
+            }
+            meta[tid] = tok; dd[tid] = d;
         }
         __syncthreads();
-        const int kin = 256 + a.na + a.nc + 32;
-        for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
-            const int r = idx / a.K1p, c = idx % a.K1p;
+        {   // columns 0..255: the (a,c)-token embedding row, 16-byte loads (rows without a node read 0 via the range check)
+            const auto rs = fm_buf(a.s_tab, 0x7fffffffu);
+            constexpr int NQ = FM_TM * 64 / FM_THREADS;
+            float4 q[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int idx = tid + k * FM_THREADS, r = idx >> 6, c4 = idx & 63;
+                const int tok = meta[r];
+                q[k] = fm_buf_f32x4(rs, tok >= 0 ? tok * 1024 + c4 * 16 : FM_BUF_OOB, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const int idx = tid + k * FM_THREADS, r = idx >> 6, c4 = idx & 63;
+                *reinterpret_cast<float4*>(X + r * a.ldx + c4 * 4) = q[k];
+            }
+        }
+        const int kin = a.na + a.nc + 32, kw = a.K1p - 256;     // [p_a | p_c | rbf | zero padding]
+        for (int idx = tid; idx < FM_TM * kw; idx += FM_THREADS) {
+            const int r = idx / kw, c = idx % kw;
             const int n = row0 + r;
             float v = 0.f;
-            if (n < a.rows && c < kin) {
-                if (c < 256) v = a.s_tab[(size_t)meta[r] * 256 + c];
-                else if (c < 256 + a.na) v = a.prev_a[(size_t)n * a.na + (c - 256)];
-                else if (c < 256 + a.na + a.nc) v = a.prev_c[(size_t)n * a.nc + (c - 256 - a.na)];
-                else {
-                    const float d = fm_norm3(a.x_t[n * 3 + 0] - a.prev_x[n * 3 + 0], a.x_t[n * 3 + 1] - a.prev_x[n * 3 + 1],
-                                             a.x_t[n * 3 + 2] - a.prev_x[n * 3 + 2]);
-                    v = fm_rbf(d, c - 256 - a.na - a.nc, a.rbf_mu_step, a.rbf_inv_sigma);
-                }
+            if (meta[r] >= 0 && c < kin) {
+                if (c < a.na) v = a.prev_a[(size_t)n * a.na + c];
+                else if (c < a.na + a.nc) v = a.prev_c[(size_t)n * a.nc + (c - a.na)];
+                else v = fm_rbf(dd[r], c - a.na - a.nc, a.rbf_mu_step, a.rbf_inv_sigma);
             }
-            X[r * a.ldx + c] = v;
+            X[r * a.ldx + 256 + c] = v;
         }
     } else if (MODE == FM_MLP_NODE_HEAD) {
-        for (int idx = tid; idx < FM_TM * 256; idx += FM_THREADS) {
-            const int r = idx >> 8, c = idx & 255;
-            X[r * a.ldx + c] = (row0 + r < a.rows) ? a.in[(size_t)(row0 + r) * 256 + c] : 0.f;
+        const int left = a.rows - row0;
+        const auto rs = fm_buf(a.in + (size_t)row0 * 256, (unsigned)(left < FM_TM ? left : FM_TM) * 1024u);
+        constexpr int NQ = FM_TM * 64 / FM_THREADS;
+        float4 q[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) q[k] = fm_buf_f32x4(rs, (tid + k * FM_THREADS) * 16, 0);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS, r = idx >> 6, c4 = idx & 63;
+            *reinterpret_cast<float4*>(X + r * a.ldx + c4 * 4) = q[k];
         }
     } else if (MODE == FM_MLP_EDGE_HEAD) {
         int* pr = meta + 3 * FM_TM;                              // [64] second edge of the pair
@@ -221,9 +245,16 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
             for (int c = sub; c < a.O; c += 8)
                 a.out[(size_t)grow * a.out_ld + c] = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
     } else if (MODE == FM_MLP_SC_NODE) {
-        if (grow < a.rows)
-            for (int c = sub; c < 256; c += 8)
-                a.out[(size_t)grow * 256 + c] = a.s_tab[(size_t)meta[r] * 256 + c] + X[r * a.ldx + c];
+        if (grow < a.rows) {
+            const float* trow = a.s_tab + (size_t)meta[r] * 256;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = (j * 8 + sub) * 4;
+                const float4 t = *reinterpret_cast<const float4*>(trow + c);
+                const float4 x = *reinterpret_cast<const float4*>(X + r * a.ldx + c);
+                *reinterpret_cast<float4*>(a.out + (size_t)grow * 256 + c) = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
+            }
+        }
     } else if (MODE == FM_MLP_SC_EDGE) {
         if (grow < a.rows) {
             const int ea = meta[4 * FM_TM + r], eb = meta[3 * FM_TM + r], tok = meta[r];
@@ -306,9 +337,22 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
         *reinterpret_cast<float4*>(d) = val;        // one ds_write_b128 (16-B aligned: row pitch and column offset are multiples of 16 B)
     }
     if (a.PV) {
-        for (int idx = tid; idx < FM_TM * 3 * V; idx += FM_THREADS) {
-            const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, ch = rem % V;
-            Vt[(c * FM_TM + r) * LDV + ch] = (row0 + r < a.N) ? a.v[((size_t)(row0 + r) * 3 + c) * V + ch] : 0.f;
+        const int rows = a.N - row0 < FM_TM ? a.N - row0 : FM_TM;
+        const auto rs_v = fm_buf(a.v + (size_t)row0 * 3 * V, (unsigned)rows * (3 * V * 4));
+        constexpr int V4 = V / 4, NCHK = FM_TM * 3 * V4, NV = (NCHK + FM_THREADS - 1) / FM_THREADS;
+        float4 qv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            qv[k] = fm_buf_f32x4(rs_v, idx < NCHK ? idx * 16 : FM_BUF_OOB, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            if (idx < NCHK) {
+                const int r = idx / (3 * V4), rem = idx % (3 * V4), c = rem / V4, u4 = rem % V4;
+                *reinterpret_cast<float4*>(Vt + (c * FM_TM + r) * LDV + u4 * 4) = qv[k];
+            }
         }
     }
     __syncthreads();
@@ -670,13 +714,32 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_pos_update(FmPosArgs a) {
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = Vh + T::VH_FLOATS;
     const int tid = threadIdx.x, row0 = blockIdx.x * TM;
-    for (int idx = tid; idx < TM * 256; idx += FM_THREADS) {
-        const int r = idx >> 8, c = idx & 255, n = row0 + r;
-        X[r * FM_LDX + c] = (n < a.N) ? a.s[(size_t)n * 256 + c] : 0.f;
-    }
-    for (int idx = tid; idx < TM * 3 * V; idx += FM_THREADS) {
-        const int r = idx / (3 * V), rem = idx % (3 * V), c = rem / V, u = rem % V, n = row0 + r;
-        Vin[(c * TM + r) * T::LDVI + u] = (n < a.N) ? a.v[((size_t)n * 3 + c) * V + u] : 0.f;
+    {   // tile of (s, v): 16-byte buffer loads, all requests of a thread issued before the LDS stores; rows beyond N read 0
+        const int rows = a.N - row0 < TM ? a.N - row0 : TM;
+        const auto rs_s = fm_buf(a.s + (size_t)row0 * 256, (unsigned)rows * 1024u);
+        const auto rs_v = fm_buf(a.v + (size_t)row0 * 3 * V, (unsigned)rows * (3 * V * 4));
+        constexpr int NQ = TM * 64 / FM_THREADS, V4 = V / 4, NCHK = TM * 3 * V4, NV = (NCHK + FM_THREADS - 1) / FM_THREADS;
+        float4 q[NQ], qv[NV];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) q[k] = fm_buf_f32x4(rs_s, (tid + k * FM_THREADS) * 16, 0);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            qv[k] = fm_buf_f32x4(rs_v, idx < NCHK ? idx * 16 : FM_BUF_OOB, 0);       // (r, c, u4) is the memory order of v
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            *reinterpret_cast<float4*>(X + (idx >> 6) * FM_LDX + (idx & 63) * 4) = q[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            if (idx < NCHK) {
+                const int r = idx / (3 * V4), rem = idx % (3 * V4), c = rem / V4, u4 = rem % V4;
+                *reinterpret_cast<float4*>(Vin + (c * TM + r) * T::LDVI + u4 * 4) = qv[k];
+            }
+        }
     }
     __syncthreads();
     {
