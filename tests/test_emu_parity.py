@@ -160,3 +160,17 @@ def test_stability_kernel_on_emulation(emu_lib, golden_dir, tag, dataset, arom, 
     g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'stability.npz').items()}
     eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
     assert stability_compare(eng, g, tag, dataset, arom, fake) == []
+
+
+def test_batch_limits_are_reported(emu_lib):
+    """A batch beyond the 31-bit gather offsets (2,097,151 nodes) or with a 1-atom molecule is refused with the C ABI's
+    error text instead of being mis-addressed."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.qm9()
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
+    with pytest.raises(_lib.FlowMolHipError, match='batch too large'):
+        eng.bind(torch.full((12000,), 181, dtype=torch.int64))
+    with pytest.raises(_lib.FlowMolHipError, match='needs >= 2'):
+        eng.bind(torch.tensor([5, 1, 4]))
+    eng.bind(torch.tensor([5, 2, 4]))          # still usable afterwards
+    assert eng.N == 11
