@@ -72,8 +72,8 @@ def gather_results(local: Dict[str, torch.Tensor], n_atoms_all: torch.Tensor, pa
     for r in range(world):
         N, U = sizes[r]
         got = unpack_results(recv[r * cap:r * cap + nbytes[r]], N, U)
-        nidx = _ranges(node_off[parts[r]], n_all[parts[r]]).to(dev)
-        pidx = _ranges(pair_off[parts[r]], pairs_all[parts[r]]).to(dev)
+        nidx = _ranges(node_off[parts[r]].to(dev), n_all[parts[r]].to(dev))      # index arithmetic on the device: only the
+        pidx = _ranges(pair_off[parts[r]].to(dev), pairs_all[parts[r]].to(dev))  # per-molecule offsets cross PCIe
         out['x'][nidx] = got['x']
         out['a'][nidx] = got['a']
         out['c'][nidx] = got['c']
@@ -85,6 +85,6 @@ def _ranges(starts: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
     """Concatenation of arange(starts[i], starts[i] + lens[i]) for all i."""
     total = int(lens.sum())
     if total == 0:
-        return torch.zeros(0, dtype=torch.int64)
+        return torch.zeros(0, dtype=torch.int64, device=starts.device)
     first = torch.cumsum(lens, 0) - lens                      # position of each range in the output
-    return torch.arange(total, dtype=torch.int64) + torch.repeat_interleave(starts - first, lens)
+    return torch.arange(total, dtype=torch.int64, device=starts.device) + torch.repeat_interleave(starts - first, lens, output_size=total)
