@@ -169,17 +169,28 @@ def main():
             pos += m
             k -= m
 
+    def gather_all():
+        """The single collective of the sampling path: packed results over RCCL/xGMI, every rank gets the whole batch."""
+        parts = [torch.arange(r * B, (r + 1) * B) for r in range(world)]
+        return shard.gather_results({'x': state['x_t'], 'a': state['a_t'], 'c': state['c_t'], 'e': state['e_t']},
+                                    torch.full((B * world,), n, dtype=torch.int64), parts)
+
     advance(args.warmup)
+    if world > 1:
+        gather_all()             # untimed warm-up of the collective (communicator setup, first-use kernel loads)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     advance(args.steps)
-    if world > 1:   # the single collective of the sampling path: packed results over RCCL/xGMI
-        parts = [torch.arange(r * B, (r + 1) * B) for r in range(world)]
-        shard.gather_results({'x': state['x_t'], 'a': state['a_t'], 'c': state['c_t'], 'e': state['e_t']},
-                             torch.full((B * world,), n, dtype=torch.int64), parts)
+    gather_ms = None
+    if world > 1:   # inside the timed region: the job is not done until every rank holds the results
+        torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
+        gather_all()
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg) * 1e3
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -234,7 +245,7 @@ def main():
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
                    'value_formula': 'global_molecules / (n_timesteps * ms_per_step/1000)', 'weights': 'synthetic by name (seed 0)',
                    'finite': finite},
-        'network_eval_ms': ms_per_step,
+        'network_eval_ms': ms_per_step, 'final_gather_ms': gather_ms,
         'whole_path_fp32_tflops_per_gpu': whole, 'whole_path_frac_of_fp32_peak': whole / FP32_PEAK_TFLOPS,
         'kernels': kern,
     }
