@@ -46,9 +46,8 @@ struct fm_ctx {
     fm_config cfg{};
     std::string err;
     int V = 32, na = 0, nc = 0, ne = 0;
-    int tm_edge = 32, tm_node = 32, tm_eupd = 32;
+    int tm_edge = 32, tm_node = 32, tm_eupd = 32;   // rows per workgroup tile (FM_TILE_EDGE / FM_TILE_NODE / FM_TILE_EUPD override)
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
-    int prio_mode = 0, skew_blocks = 0, skew_steps = 1;   // edge-message de-phasing (FM_PRIO / FM_SKEW_BLOCKS / FM_SKEW_STEPS override)        // rows per workgroup tile of the GVP kernels (FM_TILE_EDGE / FM_TILE_NODE override)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
     char* arena = nullptr; size_t arena_bytes = 0;
