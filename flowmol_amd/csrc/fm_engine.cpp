@@ -46,7 +46,12 @@ struct fm_ctx {
     fm_config cfg{};
     std::string err;
     int V = 32, na = 0, nc = 0, ne = 0;
-    int tm_edge = 32, tm_node = 32, tm_eupd = 32;   // rows per workgroup tile (FM_TILE_EDGE / FM_TILE_NODE / FM_TILE_EUPD override)
+    // Rows per workgroup tile of the GVP kernels, chosen per bound batch (ws_layout): 32 once the chip is full, 16 while
+    // the 32-row tiling would leave CUs idle (fewer tiles than CUs) - half the work per tile, i.e. lower step latency
+    // for small batches.  FM_TILE_EDGE / FM_TILE_NODE (16|32|64) force a size; FM_TILE_EUPD (32|64) for EdgeUpdate.
+    int tm_edge = 32, tm_node = 32, tm_eupd = 32;
+    int tm_edge_forced = 0, tm_node_forced = 0;
+    int n_cus = 256;
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
@@ -350,8 +355,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
 
 int evaluate_dispatch(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out, bool taps_on) {
 #define FM_EVAL(V_, TE_, TN_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_) return evaluate<V_, TE_, TN_>(c, st, state, prev, remove_com, out, taps_on);
-    FM_EVAL(32, 32, 32) FM_EVAL(32, 32, 64) FM_EVAL(32, 64, 32) FM_EVAL(32, 64, 64)
-    FM_EVAL(16, 32, 32) FM_EVAL(16, 32, 64) FM_EVAL(16, 64, 32) FM_EVAL(16, 64, 64)
+#define FM_EVAL_V(V_) FM_EVAL(V_, 16, 16) FM_EVAL(V_, 16, 32) FM_EVAL(V_, 16, 64) FM_EVAL(V_, 32, 16) FM_EVAL(V_, 32, 32) FM_EVAL(V_, 32, 64) \
+                      FM_EVAL(V_, 64, 16) FM_EVAL(V_, 64, 32) FM_EVAL(V_, 64, 64)
+    FM_EVAL_V(32) FM_EVAL_V(16)
+#undef FM_EVAL_V
 #undef FM_EVAL
     return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d", c->V, c->tm_edge, c->tm_node);
 }
@@ -617,17 +624,23 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (e != hipSuccess) { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_HIP, "fm_create: weight upload failed: %s", hipGetErrorString(e)); }
     for (const Fix& f : B.fix) *f.slot = c->arena + f.off * sizeof(float);
     // ---- dynamic LDS opt-in (up to 160 KiB per workgroup on gfx950)
-    if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge = atoi(e1);
-    if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node = atoi(e2);
+    if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge_forced = atoi(e1);
+    if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node_forced = atoi(e2);
     if (const char* e4 = getenv("FM_XCD_SWIZZLE")) c->xcd_swizzle = atoi(e4);
     if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
-    if ((c->tm_edge != 32 && c->tm_edge != 64) || (c->tm_node != 32 && c->tm_node != 64)) {
+    auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
+    if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
         (void)hipFree(c->arena); delete c;
-        return fail(nullptr, FM_ERR_INVALID, "fm_create: FM_TILE_EDGE / FM_TILE_NODE must be 32 or 64");
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: FM_TILE_EDGE / FM_TILE_NODE must be 16, 32 or 64");
+    }
+    {
+        int dev = 0; hipDeviceProp_t prop{};
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            c->n_cus = prop.multiProcessorCount;
     }
 #define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_>, lds_gvp(V_, T_, false)); \
     set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
-    FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 32) FM_SET(16, 64)
+    FM_SET(32, 16) FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 16) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_edge_update<32>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64>, lds_edge_upd(64));
@@ -648,7 +661,7 @@ int fm_destroy(fm_ctx* c) {
 
 // ---------------------------------------------------------------------------------------- workspace
 struct WsLayout {
-    int B, N, E, U, P, nmax, tab_rows, tab_kp;
+    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_stab, off_tabin, off_bx, off_ba,
         off_bc, off_be, off_cnt, off_hc, off_sa1, off_sc1, off_se1, total;
@@ -668,7 +681,10 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     if (N > 0x7fffffffLL / 1024) return fail(c, FM_ERR_INVALID, "batch too large: %lld nodes (limit %lld per bind; split the batch)", N, 0x7fffffffLL / 1024);
     const int V = c->V;
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
-    w.P = (nmax - 2) / c->tm_edge + 2; w.nmax = nmax;
+    // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
+    w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
+    w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 31) / 32 <= c->n_cus ? 16 : 32);
+    w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -733,7 +749,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     const int work = w.E > w.N ? w.E : w.N;
     L("batch_setup", fm_k_batch_setup, dim3((work + 255) / 256), dim3(256), 0, b);
     if (L.rc) return L.rc;
-    c->bound = true; c->nmax = w.nmax;
+    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node;
     return FM_OK;
 }
 

@@ -15,11 +15,14 @@ from parity_util import forward_compare
 
 
 
+@pytest.mark.parametrize('tile', [16, 32])
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False)])
-def test_emulated_forward_matches_oracle(emu_lib, name, sizes, t, prev):
+def test_emulated_forward_matches_oracle(emu_lib, monkeypatch, name, sizes, t, prev, tile):
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
     sd = weights.synth_state_dict(cfg, 0)
+    monkeypatch.setenv('FM_TILE_EDGE', str(tile))          # read at fm_create; unset = chosen per batch (16 for these sizes)
+    monkeypatch.setenv('FM_TILE_NODE', str(tile))
     eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
     orc = cpu_ref.OracleVF(cfg, sd)
     errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev)

@@ -33,13 +33,29 @@ def _report(name, obj):
 _engines = {}
 
 
-def engine_for(name):
+def engine_for(name, tile=0):
+    """Engine + oracle per preset.  tile = 0: the library chooses the row-tile size per batch (16 rows for batches that
+    do not fill the chip, else 32); 16 / 32: forced through FM_TILE_EDGE / FM_TILE_NODE (read at fm_create)."""
     from flowmol_amd.engine import Engine
-    if name not in _engines:
+    if (name, tile) not in _engines:
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, 0)
-        _engines[name] = (cfg, sd, Engine(cfg, sd, device='cuda:0'), cpu_ref.OracleVF(cfg, sd))
-    return _engines[name]
+        old = {k: os.environ.get(k) for k in ('FM_TILE_EDGE', 'FM_TILE_NODE')}
+        try:
+            for k in old:
+                if tile:
+                    os.environ[k] = str(tile)
+                else:
+                    os.environ.pop(k, None)
+            eng = Engine(cfg, sd, device='cuda:0')
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        _engines[(name, tile)] = (cfg, sd, eng, cpu_ref.OracleVF(cfg, sd))
+    return _engines[(name, tile)]
 
 
 def test_native_library_is_the_hip_build():
@@ -59,10 +75,11 @@ def test_native_library_is_the_hip_build():
     ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False),
     ('qm9', [18] * 8, 0.7, True),
 ])
-def test_forward_matches_oracle(name, sizes, t, prev):
-    cfg, sd, eng, orc = engine_for(name)
+@pytest.mark.parametrize('tile', [16, 32])
+def test_forward_matches_oracle(name, sizes, t, prev, tile):
+    cfg, sd, eng, orc = engine_for(name, tile)
     errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev)
-    _report(f'forward[{name},{sizes},{t}]', errs)
+    _report(f'forward[{name},{sizes},{t},tile{tile}]', errs)
     bad = {k: v for k, v in errs.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
     assert not bad, f'stages out of tolerance: {bad}\nall: {errs}'
     for k in 'ace':     # probabilities are normalised
