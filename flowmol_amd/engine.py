@@ -154,6 +154,14 @@ class StepNoise:
                 out[f'u2_{tag}'] = tape[pos].to(device, torch.float32).contiguous(); pos += 1
         return StepNoise(**out), pos
 
+    def take_rows(self, node_rows: torch.Tensor, pair_rows: torch.Tensor) -> "StepNoise":
+        """The draws of a subset of the batch's nodes / unordered pairs (sharded runs that replicate the full-batch noise)."""
+        out = {}
+        for k in self.__slots__:
+            t = getattr(self, k)
+            out[k] = None if t is None else t[pair_rows if k.endswith('_e') else node_rows].contiguous()
+        return StepNoise(**out)
+
     def c_struct(self) -> fm_step_noise:
         s = fm_step_noise()
         for k in self.__slots__:

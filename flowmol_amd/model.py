@@ -151,20 +151,32 @@ class FlowMol:
 
     @torch.no_grad()
     def sample_distributed(self, n_atoms: torch.Tensor, n_timesteps: int = None, group=None, return_tensors=False,
-                           **kwargs):
+                           noise: str = 'per_rank', **kwargs):
         """Multi-GPU sampling (no reference counterpart): every rank of ``group`` calls this with the
         SAME ``n_atoms``; the molecules are dealt to the ranks by cost (``shard.partition_lpt``), each rank integrates its
         shard on its own GPU with no communication, and ONE all-gather of the packed results (``shard.gather_results``,
-        RCCL over xGMI with backend "nccl") gives every rank the full batch in the caller's order.  Each rank draws from
-        its own torch RNG stream (seed it per rank), so results depend on the world size; trajectories are not gathered."""
+        RCCL over xGMI with backend "nccl") gives every rank the full batch in the caller's order.
+
+        ``noise='per_rank'``: each rank draws only its shard's noise from its own torch RNG stream (seed it per rank);
+        results depend on the world size.  ``noise='replicated'`` (parity mode): every rank, seeded identically, draws the
+        full batch's prior and per-step noise and keeps its molecules' rows, so the result reproduces the single-GPU
+        ``sample(n_atoms)`` with that seed (to float summation order), at world_size times the (cheap) RNG work.  Trajectories are not gathered."""
         import torch.distributed as dist
         from . import shard
         if kwargs.get('xt_traj') or kwargs.get('ep_traj') or kwargs.get('prior') is not None:
             raise NotImplementedError('sample_distributed gathers final states only (no trajectories / caller-supplied priors)')
+        if noise not in ('per_rank', 'replicated'):
+            raise ValueError(f"noise must be 'per_rank' or 'replicated', got {noise!r}")
         n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         parts = shard.partition_lpt(n_atoms, world)
         dev = self.engine.device
+        if noise == 'replicated':
+            pairs = n_atoms * (n_atoms - 1) // 2
+            mine = parts[rank]
+            node_rows = shard._ranges((torch.cumsum(n_atoms, 0) - n_atoms)[mine], n_atoms[mine]).to(dev)
+            pair_rows = shard._ranges((torch.cumsum(pairs, 0) - pairs)[mine], pairs[mine]).to(dev)
+            kwargs['_rows'] = (int(n_atoms.sum()), int(pairs.sum()), node_rows, pair_rows)
         if len(parts[rank]):
             out, _ = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors=True, **kwargs)
             local = {k: out[k].to(dev) for k in 'xace'}
@@ -194,7 +206,7 @@ class FlowMol:
         dfm_type = kwargs.get('dfm_type') or self.cfg.dfm_type
         if dfm_type not in ('campbell', 'gat'):
             raise ValueError(f"Invalid dfm_type: {dfm_type}")
-        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func'}
+        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         visualize = bool(xt_traj or ep_traj)
@@ -203,8 +215,9 @@ class FlowMol:
         N, U = eng.N, eng.U
         cfg = self.cfg
         # ---- prior (flowmol.py:417-448 / 534-545)
+        rows = kwargs.get('_rows')     # sample_distributed(noise='replicated'): (N_full, U_full, node rows, pair rows) of this shard
         if prior is None:
-            x0 = torch.randn(N, 3, device=dev)
+            x0 = torch.randn(N, 3, device=dev) if rows is None else torch.randn(rows[0], 3, device=dev)[rows[2]].contiguous()
             eng.remove_com(x0)
             state = eng.prior_state(x0)
         else:
@@ -226,7 +239,10 @@ class FlowMol:
             init = {k: state[f'{k}_t'].clone() for k in 'xace'}
 
         def noise_for_step(i, last):
-            return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, dfm_type=dfm_type)
+            if rows is None:
+                return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, dfm_type=dfm_type)
+            full = StepNoise.draw(rows[0], rows[1], cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, dfm_type=dfm_type)
+            return full.take_rows(rows[2], rows[3])
 
         eng.integrate(state, plan, noise_for_step, traj=traj)
         out = {k: state[f'{k}_t'].cpu() for k in 'xace'}

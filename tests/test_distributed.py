@@ -65,8 +65,9 @@ def test_shard_and_gather_world2(sizes):
     assert all(n == int(n_atoms.sum()) for _, _, n in res)
 
 
-def _sample_worker(rank, world, port, sizes, q):
-    """Each rank: emulated engine on the CPU, its own RNG stream, sample_distributed over gloo."""
+def _sample_worker(rank, world, port, sizes, q, noise='per_rank'):
+    """Each rank: emulated engine on the CPU, its own RNG stream (or the same one in replicated-noise mode),
+    sample_distributed over gloo."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -75,8 +76,8 @@ def _sample_worker(rank, world, port, sizes, q):
     from flowmol_amd import _lib
     emu = _lib.load(Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so')
     model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu).to('cpu')
-    torch.manual_seed(100 + rank)
-    full, n = model.sample_distributed(torch.tensor(sizes), n_timesteps=3, return_tensors=True)
+    torch.manual_seed(100 + (rank if noise == 'per_rank' else 0))
+    full, n = model.sample_distributed(torch.tensor(sizes), n_timesteps=3, return_tensors=True, noise=noise)
     q.put((rank, {k: v.clone() for k, v in full.items()}))
     dist.destroy_process_group()
 
@@ -141,3 +142,28 @@ def test_cli_under_two_ranks_writes_once(tmp_path, emu_lib_path):
         p.join(timeout=300)
         assert p.exitcode == 0
     assert out.read_text().count('$$$$') == 5
+
+
+def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path):
+    """Parity mode of the sharded path: with every rank drawing the full batch's noise from the same seed, two ranks
+    reproduce the single-process sample(n_atoms): identical tokens, coordinates to summation order (molecules are
+    independent: SURVEY.md §8e)."""
+    import flowmol_amd as flowmol
+    from flowmol_amd import _lib
+    sizes = [4, 6, 3, 5]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q, 'replicated')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=_lib.load(emu_lib_path)).to('cpu')
+    torch.manual_seed(100)
+    single, _ = model.sample(torch.tensor(sizes), n_timesteps=3, return_tensors=True)
+    for r in range(2):
+        for k in 'ace':
+            assert torch.equal(res[r][k], single[k].to(res[r][k].dtype))
+        torch.testing.assert_close(res[r]['x'], single['x'], rtol=1e-5, atol=1e-5)    # tile alignment changes the summation order

@@ -312,3 +312,27 @@ def test_c3_full_size_geom_properties():
     # x_1 == last endpoint prediction (Appendix C.10), which is COM-free per molecule
     com = out['x'].reshape(1024, 47, 3).mean(1)
     assert com.abs().max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_shards_with_replicated_noise_equal_the_full_batch():
+    """SURVEY.md §8e on one GPU: the three shards of an LPT partition, each integrated alone with the full batch's
+    noise rows (what sample_distributed(noise='replicated') does per rank), reproduce the unsharded run: identical
+    tokens, coordinates to float summation order (where a destination's in-edges are cut into tiles depends on the
+    molecule's offset in the batch, so the order of its partial sums does)."""
+    import flowmol_amd as flowmol
+    from flowmol_amd import shard
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda()
+    sizes = torch.tensor([12, 30, 5, 47, 9, 21, 33, 2, 16, 40, 7, 25])
+    torch.manual_seed(5)
+    full, _ = model.sample(sizes, n_timesteps=6, return_tensors=True)
+    pairs = sizes * (sizes - 1) // 2
+    noff, poff = torch.cumsum(sizes, 0) - sizes, torch.cumsum(pairs, 0) - pairs
+    for mine in shard.partition_lpt(sizes, 3):
+        rows = (int(sizes.sum()), int(pairs.sum()), shard._ranges(noff[mine], sizes[mine]).cuda(), shard._ranges(poff[mine], pairs[mine]).cuda())
+        torch.manual_seed(5)
+        part, _ = model.sample(sizes[mine], n_timesteps=6, return_tensors=True, _rows=rows)
+        nidx, pidx = rows[2].cpu(), rows[3].cpu()
+        assert torch.equal(part['a'], full['a'][nidx]) and torch.equal(part['c'], full['c'][nidx])
+        assert torch.equal(part['e'], full['e'][pidx])
+        torch.testing.assert_close(part['x'], full['x'][nidx], rtol=1e-5, atol=1e-5)
