@@ -405,7 +405,8 @@ class IntegrationRun:
     def __init__(self, eng: Engine, state, plan: StepPlan, noise_for_step, traj=None):
         self.eng, self.state, self.plan, self.noise_for_step, self.traj = eng, state, plan, noise_for_step, traj
         tt = eng.cfg.time_embedding_dim
-        self.temb_all = torch.stack([time_embedding_host(sc.t, tt) for sc in plan.scalars]).to(eng.device).contiguous()
+        self.temb_all = (torch.stack([time_embedding_host(sc.t, tt) for sc in plan.scalars]) if plan.scalars
+                         else torch.zeros(0, tt)).to(eng.device).contiguous()      # n_timesteps = 1: no step, the prior is the result
         self.dst = [eng.new_dst(), eng.new_dst()]
         self._dsts = [eng._dst_struct(self.dst[0]), eng._dst_struct(self.dst[1])]
         self._st = eng._state_struct(state)

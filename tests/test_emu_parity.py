@@ -177,3 +177,14 @@ def test_batch_limits_are_reported(emu_lib):
         eng.bind(torch.tensor([5, 1, 4]))
     eng.bind(torch.tensor([5, 2, 4]))          # still usable afterwards
     assert eng.N == 11
+
+
+def test_single_timepoint_returns_the_prior(emu_lib):
+    """n_timesteps=1: linspace(0,1,1) has no step (ctmc_vector_field.py:205 loop body never runs); the result is the
+    prior: centred Gaussian positions and mask tokens everywhere."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu_lib).to('cpu')
+    torch.manual_seed(0)
+    out, _ = model.sample(torch.tensor([3, 4]), n_timesteps=1, return_tensors=True)
+    assert (out['a'] == model.cfg.n_atom_types).all() and (out['c'] == model.cfg.n_charges).all() and (out['e'] == model.cfg.n_bond_types).all()
+    assert torch.allclose(out['x'][:3].mean(0), torch.zeros(3), atol=1e-6) and torch.allclose(out['x'][3:].mean(0), torch.zeros(3), atol=1e-6)
