@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mols-per-gpu', type=int, default=1024)
     ap.add_argument('--n-atoms', type=int, default=47)
+    ap.add_argument('--size-dist', default=None, help="draw the molecule sizes from a shipped training-set histogram (e.g. geom_full_kekulized) instead of --n-atoms; secondary measurement, the headline line uses fixed sizes")
     ap.add_argument('--timesteps', type=int, default=250)
     ap.add_argument('--preset', default='flowmol3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -134,7 +135,16 @@ def main():
     sd = weights.synth_state_dict(cfg, 0)
     eng = Engine(cfg, sd, device=dev)
     B, n, T = args.mols_per_gpu, args.n_atoms, args.timesteps
-    n_atoms = torch.full((B,), n, dtype=torch.int64)
+    def sizes_of(r):
+        """Molecule sizes of rank r's shard (fixed size, or a seeded draw from the shipped size histogram)."""
+        if args.size_dist is None:
+            return torch.full((B,), n, dtype=torch.int64)
+        from flowmol_amd.model import load_n_atoms_hist
+        vals, counts = load_n_atoms_hist(args.size_dist)
+        g_ = torch.Generator().manual_seed(1000 + r)
+        return vals[torch.multinomial(counts.double(), B, replacement=True, generator=g_)]
+
+    n_atoms = sizes_of(rank)
     eng.bind(n_atoms)
     N, U, E = eng.N, eng.U, eng.E
     plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
@@ -173,7 +183,7 @@ def main():
         """The single collective of the sampling path: packed results over RCCL/xGMI, every rank gets the whole batch."""
         parts = [torch.arange(r * B, (r + 1) * B) for r in range(world)]
         return shard.gather_results({'x': state['x_t'], 'a': state['a_t'], 'c': state['c_t'], 'e': state['e_t']},
-                                    torch.full((B * world,), n, dtype=torch.int64), parts)
+                                    torch.cat([sizes_of(r) for r in range(world)]), parts)
 
     advance(args.warmup)
     if world > 1:
@@ -218,7 +228,7 @@ def main():
     traffic = None
     try:     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (same workload only)
         tj = json.loads((ROOT / 'profiles' / 'r01p_traffic.json').read_text())
-        if tj['mols_per_gpu'] == B and tj['n_atoms'] == n and args.preset == 'flowmol3':
+        if tj['mols_per_gpu'] == B and tj['n_atoms'] == n and args.preset == 'flowmol3' and args.size_dist is None:
             traffic = tj['hbm_bytes_per_launch']
     except Exception:
         pass
@@ -234,12 +244,12 @@ def main():
                     'algorithmic_flop_per_launch': flops,
                     'note': 'algorithmic FLOPs = 2*312,251 MAC per directed edge (reference-executed count) x E edges per launch; '
                             'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32)'}
-    whole = mols_per_s / world * 250 * network_flops(n) / 1e12
+    whole = 250 * sum(network_flops(int(k)) for k in n_atoms.tolist()) / B * mols_per_s / world / 1e12
     out = {
         'metric': 'molecules/sec at 250 timesteps (GEOM-drugs-sized graphs)', 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'{args.preset} GEOM-drugs model, {B} molecules/GPU x {n} atoms, n_timesteps={T} '
+        'config': {'workload': f'{args.preset} GEOM-drugs model, {B} molecules/GPU x ' + (f'{n} atoms' if args.size_dist is None else f'sizes ~ {args.size_dist} histogram (mean {float(n_atoms.double().mean()):.1f}, max {int(n_atoms.max())})') + f', n_timesteps={T} '
                                f'(BASELINE.json configs[2]; configs[3] at 8 GPUs)',
                    'global_molecules': B * world, 'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'parallelism': f'molecule-shard x{world}',
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
