@@ -432,7 +432,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
             // x_diff = x[src] - x[dst]; d = sqrt(max(|.|^2,1e-8)) + 1e-8; xhat = x_diff / d  (vector_field.py:381-383)
             const float dx = a.x[s * 3] - a.x[d * 3], dy = a.x[s * 3 + 1] - a.x[d * 3 + 1], dz = a.x[s * 3 + 2] - a.x[d * 3 + 2];
             dist = fm_norm3(dx, dy, dz) + 1e-8f;
-            gx = dx / dist; gy = dy / dist; gz = dz / dist;
+            const float inv_d = __builtin_amdgcn_rcpf(dist);       // one v_rcp_f32 instead of three IEEE divisions on the tile's start-up path
+            gx = dx * inv_d; gy = dy * inv_d; gz = dz * inv_d;
         }
         m_src[tid] = s; m_dst[tid] = d; m_piece[tid] = piece;
         m_geo[4 * tid] = gx; m_geo[4 * tid + 1] = gy; m_geo[4 * tid + 2] = gz; m_geo[4 * tid + 3] = dist;
@@ -568,7 +569,8 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     }
     #pragma unroll
     for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
-    const float vn = sqrtf(q / (float)V + 1e-5f) + 1e-5f;
+    const float vn = __builtin_amdgcn_sqrtf(q * (1.0f / (float)V) + 1e-5f) + 1e-5f;
+    const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
     const bool valid = row0 + r < nrows;
     for (int c = sub; c < 256; c += LPR) {
         const float y = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
@@ -578,7 +580,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     for (int u = sub; u < V; u += LPR)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float y = Vin[(c * TM + r) * T::LDVI + u] / vn;
+            const float y = Vin[(c * TM + r) * T::LDVI + u] * inv_vn;
             Vin[(c * TM + r) * T::LDVI + u] = y;
             if (out_v && valid) out_v[((size_t)(row0 + r) * 3 + c) * V + u] = y;
         }

@@ -150,6 +150,8 @@ static inline void emu_raw_buffer_store_b128(emu_u32x4 d, emu_rsrc r, int voff, 
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)
+#define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 // correctly-rounded, never-contracted f32 ops (the emulation is built with -ffp-contract=off)
