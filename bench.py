@@ -227,7 +227,7 @@ def main():
     eng.profile(False)
     traffic = None
     try:     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (same workload only)
-        tj = json.loads((ROOT / 'profiles' / 'r01p_traffic.json').read_text())
+        tj = json.loads((ROOT / 'profiles' / 'r01s_traffic.json').read_text())
         if tj['mols_per_gpu'] == B and tj['n_atoms'] == n and args.preset == 'flowmol3' and args.size_dist is None:
             traffic = tj['hbm_bytes_per_launch']
     except Exception:
@@ -238,7 +238,7 @@ def main():
         ach = flops / (kern['edge_message']['avg_us'] * 1e-6) / 1e12
         roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
-                    'traffic_note': 'HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01p_traffic.json (rocprofv3 PMC, gfx950 FETCH correction); '
+                    'traffic_note': 'HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01s_traffic.json (rocprofv3 PMC, gfx950 FETCH correction); '
                                     'algorithmic compulsory bytes/launch = E*(512+8) + partial sums = 1.29e9',
                     'avg_launch_us': kern['edge_message']['avg_us'],
                     'algorithmic_flop_per_launch': flops,
