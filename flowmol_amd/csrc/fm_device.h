@@ -383,15 +383,19 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
         X[r * FM_LDX + SOFF + H + p] = fm_norm3(cx, cy, cz);
     }
-    for (int idx = tid; idx < TM * (V + 8); idx += NTH) {
-        const int r = idx / (V + 8), c = idx % (V + 8);
-        if (c < H) {
-            const float vx = Vh[(0 * TM + r) * T::LDVH + c];
-            const float vy = Vh[(1 * TM + r) * T::LDVH + c];
-            const float vz = Vh[(2 * TM + r) * T::LDVH + c];
-            X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
-        } else if (c >= H + 4) {
-            X[r * FM_LDX + SOFF + c] = 0.f;
+    // thread -> (row, 16-column group): no integer division by V+8 in the index math
+    for (int r = tid >> 4; r < TM; r += NTH / 16) {
+#pragma unroll
+        for (int j = 0; j < (V + 8 + 15) / 16; ++j) {
+            const int c = (tid & 15) + 16 * j;
+            if (c < H) {
+                const float vx = Vh[(0 * TM + r) * T::LDVH + c];
+                const float vy = Vh[(1 * TM + r) * T::LDVH + c];
+                const float vz = Vh[(2 * TM + r) * T::LDVH + c];
+                X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
+            } else if (c >= H + 4 && c < V + 8) {
+                X[r * FM_LDX + SOFF + c] = 0.f;
+            }
         }
     }
     __syncthreads();
