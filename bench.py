@@ -241,6 +241,8 @@ def main():
                     'traffic_note': 'HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01s_traffic.json (rocprofv3 PMC, gfx950 FETCH correction); '
                                     'algorithmic compulsory bytes/launch = E*(512+8) + partial sums = 1.29e9',
                     'avg_launch_us': kern['edge_message']['avg_us'],
+                    'hbm_gb_per_s': (traffic / (kern['edge_message']['avg_us'] * 1e-6) / 1e9) if traffic else None,
+                    'hbm_frac_of_8tb_per_s': (traffic / (kern['edge_message']['avg_us'] * 1e-6) / 8e12) if traffic else None,
                     'algorithmic_flop_per_launch': flops,
                     'note': 'algorithmic FLOPs = 2*312,251 MAC per directed edge (reference-executed count) x E edges per launch; '
                             'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32)'}
