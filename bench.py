@@ -51,6 +51,70 @@ def network_flops(n, V=32):
     return 4.8744e6 * n * (n - 1) + 6.50e6 * n
 
 
+def executed_macs(cfg):
+    """MACs the kernels actually issue on the matrix pipe per directed edge / per node and network evaluation (padded GEMM
+    shapes of flowmol_amd/csrc, after the algebraic hoists of DESIGN.md §3), next to the reference-executed counts the
+    algorithmic figures use.  Returned per kernel so every roofline fraction can be quoted both ways."""
+    V, S, F, R = cfg.n_vec_channels, cfg.n_hidden_scalars, cfg.n_hidden_edge_feats, cfg.rbf_dim
+    p8 = lambda k: (k + 7) // 8 * 8
+    p16 = lambda k: (k + 15) // 16 * 16
+    def gvp(first, vout):            # one GVP on one row (fm_gvp_core): [Wh|Wcp] (hoisted for the first edge GVP), Wu, Ws, gates
+        vop = max(16, vout)
+        return (0 if first else 3 * V * (V + 16)) + 3 * (V + 8) * vop + ((R + F if first else S) + V + 8) * S + S * vop
+    msg = gvp(True, V) + 2 * gvp(False, V)
+    n_upd = sum(1 for u in cfg.update_schedule() if u >= 0)
+    eupd = (F + R) * F + F * F
+    sc_e = (p8(cfg.n_bond_types + R) * F + F * F) / 2 if cfg.self_conditioning else 0          # per unordered pair
+    head_e = (F * F + F * 16) / 2
+    per_edge = cfg.n_convs * msg + n_upd * eupd + sc_e + head_e
+    node_upd = 3 * gvp(False, V)
+    pos = 2 * gvp(False, V) + gvp(False, 1)
+    proj = S * S + 3 * V * (V + 16)
+    sc_n = (p8(S + cfg.n_atom_types + cfg.n_charges + R) * S + S * S) if cfg.self_conditioning else 0
+    head_n = S * S + S * p16(cfg.n_atom_types + cfg.n_charges)
+    per_node = cfg.n_convs * (node_upd + proj) + n_upd * (pos + S * S) + sc_n + head_n
+    return {'edge_message_per_edge': msg, 'edge_update_per_edge': eupd, 'per_edge': per_edge, 'per_node': per_node}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU, the
+    driver's own launch line) and fail loudly when the node cannot host them."""
+    import subprocess
+    have = torch.cuda.device_count()
+    backend = os.environ.get('FM_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node; refusing to run fewer ranks than requested '
+                         f'(FM_BENCH_BACKEND=gloo lets ranks share a device for harness tests only)')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def api_end_to_end(args, B, n, T, dev):
+    """Secondary figure: ONE full `model.sample(B x n atoms, n_timesteps=T)` through the drop-in API -- bind, prior, all T-1 steps
+    with torch-generated noise, device->host copy and the per-molecule SampledMolecule packaging -- as wall time."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset(args.preset).to(dev).eval()
+    sizes = torch.full((B,), n, dtype=torch.int64)
+    model.sample(sizes[:8], n_timesteps=3)                   # engine creation + first-use costs are not part of the figure
+    torch.manual_seed(7)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    mols = model.sample(sizes, n_timesteps=T)
+    wall = time.perf_counter() - t0
+    timing = dict(getattr(model, 'last_timing', {}))
+    model.to('cpu')                                           # releases the second engine's workspace
+    return {'wall_s': wall, 'molecules': len(mols), 'molecules_per_s': len(mols) / wall, 'n_timesteps': T,
+            'breakdown_s': timing, 'note': 'FlowMol.sample() incl. packaging into SampledMolecule objects (no RDKit in this image)'}
+
+
 def _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, threads):
     """Warm-up step (with the bootstrap evaluation) + `steps` timed integration steps of the CPU oracle."""
     from oracle import cpu_ref
@@ -106,18 +170,23 @@ def main():
     ap.add_argument('--timesteps', type=int, default=250)
     ap.add_argument('--preset', default='flowmol3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
     ap.add_argument('--cpu-mols', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        _self_launch(args)                 # never returns
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     # one process per GPU; FM_BENCH_BACKEND=gloo lets several ranks share a device to exercise this path on a 1-GPU box
     backend = os.environ.get('FM_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible')
     dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -127,6 +196,9 @@ def main():
             dist.init_process_group('nccl', device_id=dev)       # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f'bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}')
+        world = dist.get_world_size()
 
     from flowmol_amd import presets, weights, shard
     from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan
@@ -202,51 +274,79 @@ def main():
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
     torch.cuda.synchronize(dev)
+    own_elapsed = time.perf_counter() - t0          # this rank's steps + its part of the gather, before waiting for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [own_elapsed * 1e3 / args.steps]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        mine = torch.tensor([own_elapsed * 1e3 / args.steps, gather_ms], device=dev, dtype=torch.float64)
+        every = torch.empty(world, 2, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_ms = every[:, 0].tolist()
+        gather_ms = float(every[:, 1].max())
     ms_per_step = elapsed * 1e3 / args.steps
     mols_per_s = B * world / (T * ms_per_step / 1e3)
 
-    # ---- per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel
+    # ---- per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel: a separate
+    #      event-instrumented pass of 2 more steps AFTER the timed region (event pairs around every launch add ~1 % to
+    #      the step, so the sum of these averages slightly exceeds ms_per_step)
     finite = bool(torch.isfinite(state['x_t']).all().item())
     eng.profile(True)
     advance(2)
     torch.cuda.synchronize(dev)
     kern = {}
     for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node',
-              'edge_head', 'node_head', 'ctmc_pass1', 'ctmc_pass2', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step'):
+              'edge_head', 'node_head', 'ctmc', 'ctmc_pass1', 'ctmc_pass2', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step',
+              'heads_post'):
         ms, cnt = eng.profile_get(k)
         if cnt:
             kern[k] = {'avg_us': ms * 1e3 / cnt, 'launches_per_step': cnt / 2}
     eng.profile(False)
-    traffic = None
-    try:     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (same workload only)
-        tj = json.loads((ROOT / 'profiles' / 'r01s_traffic.json').read_text())
-        if tj['mols_per_gpu'] == B and tj['n_atoms'] == n and args.preset == 'flowmol3' and args.size_dist is None:
-            traffic = tj['hbm_bytes_per_launch']
+    launches_per_step = sum(v['launches_per_step'] for v in kern.values())
+    # counters of the dominant kernel from the committed rocprofv3 PMC passes (same workload only); never measured by this run
+    pmc = None
+    try:
+        pj = json.loads((ROOT / 'profiles' / 'current_pmc.json').read_text())
+        if pj['mols_per_gpu'] == B and pj['n_atoms'] == n and pj['preset'] == args.preset and args.size_dist is None:
+            pmc = pj
     except Exception:
         pass
+    ex = executed_macs(cfg)
     roofline = None
     if 'edge_message' in kern:
+        us = kern['edge_message']['avg_us']
         flops = conv_message_flops_per_edge(cfg.n_vec_channels) * E
-        ach = flops / (kern['edge_message']['avg_us'] * 1e-6) / 1e12
+        ex_flops = 2 * ex['edge_message_per_edge'] * E
+        ach = flops / (us * 1e-6) / 1e12
+        traffic = pmc['hbm_bytes_per_launch'] if pmc else None
         roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
-                    'traffic_note': 'HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01s_traffic.json (rocprofv3 PMC, gfx950 FETCH correction); '
-                                    'algorithmic compulsory bytes/launch = E*(512+8) + partial sums = 1.29e9',
-                    'avg_launch_us': kern['edge_message']['avg_us'],
-                    'hbm_gb_per_s': (traffic / (kern['edge_message']['avg_us'] * 1e-6) / 1e9) if traffic else None,
-                    'hbm_frac_of_8tb_per_s': (traffic / (kern['edge_message']['avg_us'] * 1e-6) / 8e12) if traffic else None,
+                    'traffic_source': (f"committed profile {pmc['source']} (library of commit {pmc['commit']}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
+                                       f"rocprofv3 PMC with the gfx950 FETCH correction; not measured by this run") if pmc else None,
+                    'algorithmic_bytes_per_launch': E * (512 + 8) + N * 4 * (256 + 3 * cfg.n_vec_channels) * 2,
+                    'avg_launch_us': us,
+                    'hbm_gb_per_s': (traffic / (us * 1e-6) / 1e9) if traffic else None,
+                    'hbm_frac_of_8tb_per_s': (traffic / (us * 1e-6) / 8e12) if traffic else None,
                     'algorithmic_flop_per_launch': flops,
-                    'note': 'algorithmic FLOPs = 2*312,251 MAC per directed edge (reference-executed count) x E edges per launch; '
-                            'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32)'}
-    whole = 250 * sum(network_flops(int(k)) for k in n_atoms.tolist()) / B * mols_per_s / world / 1e12
+                    'executed_flop_per_launch': ex_flops,
+                    'executed_tflops': ex_flops / (us * 1e-6) / 1e12,
+                    'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
+                    'mfma_busy_frac': pmc.get('mfma_busy_frac') if pmc else None,
+                    'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library of commit {pmc['commit']})"
+                                         if pmc and pmc.get('mfma_busy_frac') else None),
+                    'note': 'frac = ALGORITHMIC FLOPs (2*312,251 MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
+                            'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
+                            f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
+                            'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
+    n_list = n_atoms.tolist()
+    evals_per_s = mols_per_s / world * T / B                      # network evaluations of this rank's batch per second
+    alg_tf = sum(network_flops(int(k)) for k in n_list) * evals_per_s / 1e12
+    exe_tf = 2 * (ex['per_edge'] * E + ex['per_node'] * N) * evals_per_s / 1e12
     out = {
         'metric': 'molecules/sec at 250 timesteps (GEOM-drugs-sized graphs)', 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -257,12 +357,21 @@ def main():
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
                    'value_formula': 'global_molecules / (n_timesteps * ms_per_step/1000)', 'weights': 'synthetic by name (seed 0)',
                    'finite': finite},
-        'network_eval_ms': ms_per_step, 'final_gather_ms': gather_ms,
-        'whole_path_fp32_tflops_per_gpu': whole, 'whole_path_frac_of_fp32_peak': whole / FP32_PEAK_TFLOPS,
+        'network_eval_ms': ms_per_step, 'per_rank_ms_per_step': per_rank_ms, 'final_gather_ms': gather_ms,
+        'launches_per_step': launches_per_step,
+        'whole_path': {'algorithmic_tflops_per_gpu': alg_tf, 'executed_tflops_per_gpu': exe_tf,
+                       'executed_frac': exe_tf / FP32_PEAK_TFLOPS,
+                       'algorithmic_over_executed': alg_tf / exe_tf,
+                       'note': 'algorithmic = the reference-executed FLOP count of a network evaluation (BASELINE.md section 2) per second; executed = MFMA FLOPs '
+                               'the kernels issue (per-source terms hoisted to per-node GEMMs, few-input embeddings tabulated); only executed_frac is a '
+                               'fraction of the f32 peak -- the algorithmic rate may exceed the peak because fewer FLOPs are executed'},
         'kernels': kern,
+        'kernels_note': 'per-kernel averages come from a separate HIP-event-instrumented pass of 2 steps after the timed region',
     }
     if roofline:
         out['roofline'] = roofline
+    if rank == 0 and world == 1 and not args.no_api_e2e:
+        out['api_end_to_end'] = api_end_to_end(args, B, n, T, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, sd, n, args.cpu_mols, args.cpu_steps, T)
     if rank == 0:

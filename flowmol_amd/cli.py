@@ -42,6 +42,8 @@ def parse_args(argv=None):
     p.add_argument('--n_subsets', type=int, default=None, help='split the samples into subsets for mean / 95%% CI of the metrics')
     p.add_argument('--metrics_dataset', type=str, default=None, help='valency table to use (default: the model\'s dataset)')
     p.add_argument('--max_batch_size', type=int, default=128)
+    p.add_argument('--baseline_comparison', action='store_true',
+                   help='write (molecules, sampling_time) as a pickle like the reference (test.py:145-150)')
     p.add_argument('--stochasticity', type=float, default=None)
     p.add_argument('--hc_thresh', type=float, default=None)
     p.add_argument('--seed', type=int, default=None)
@@ -97,21 +99,23 @@ def write_metrics(args, model, molecules, out: Path):
 
 
 def _dist_setup(args):
-    """torchrun launch (one process per GPU): RCCL process group, this rank's device.  Returns (world, rank)."""
+    """torchrun launch (one process per GPU): RCCL process group, this rank's device.  Returns (world, rank); world is 0
+    when the process was not started by a distributed launcher (plain single-GPU run).  A launcher with ONE rank still takes the
+    sharded code path (one-rank process group), so `torchrun --nproc-per-node 1` exercises exactly what N ranks run."""
     import os
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world == 1:
-        return 1, 0
+    if 'WORLD_SIZE' not in os.environ:
+        return 0, 0
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.device.startswith('cuda'):
         args.device = f'cuda:{local}'
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device(args.device))
-    else:
+        if not dist.is_initialized():
+            dist.init_process_group('nccl', device_id=torch.device(args.device))
+    elif not dist.is_initialized():
         dist.init_process_group('gloo')
-    return world, dist.get_rank()
+    return dist.get_world_size(), dist.get_rank()
 
 
 def run(args, engine_lib=None):
@@ -128,7 +132,7 @@ def run(args, engine_lib=None):
         bs = min(args.n_mols - len(molecules), args.max_batch_size)
         common = dict(n_timesteps=args.n_timesteps, stochasticity=args.stochasticity, high_confidence_threshold=args.hc_thresh)
         n_atoms = model.sample_n_atoms(bs) if args.n_atoms_per_mol is None else torch.full((bs,), args.n_atoms_per_mol, dtype=torch.long)
-        if world == 1:
+        if world == 0 or args.xt_traj or args.ep_traj:
             molecules.extend(model.sample(n_atoms, device=args.device, xt_traj=args.xt_traj, ep_traj=args.ep_traj, **common))
         else:
             # every rank must shard the SAME size list: rank 0's draw is broadcast; noise streams differ per rank
@@ -141,12 +145,26 @@ def run(args, engine_lib=None):
     sampling_time = time.time() - start
     if rank != 0:            # every rank holds the gathered batch; rank 0 writes
         return molecules, sampling_time
+    base = args.model_dir if args.model_dir is not None else Path('.')
     if args.output_file is not None:
         out = args.output_file
+    elif args.baseline_comparison:
+        out = base / 'samples' / f'{base.resolve().name}_baseline_comparison.pkl'          # test.py:138-139
     else:
-        base = args.model_dir if args.model_dir is not None else Path('.')
         out = base / 'samples' / 'sampled_mols.sdf'
     out.parent.mkdir(parents=True, exist_ok=True)
+    if args.baseline_comparison:
+        # the reference pickles (rdkit_mols, sampling_time) -- its only timing artefact (test.py:145-150, read by
+        # fm3_evals/baselines/compute_baseline_comparison.py:38-40).  Same tuple here; without RDKit each molecule is the
+        # tensor form the RDKit molecule is built from.
+        print(f'Writing molecules to {out}')
+        items = []
+        for m in molecules:
+            rd = m.rdkit_mol
+            items.append(rd if rd is not None else m.to_record())
+        with open(out, 'wb') as f:
+            pickle.dump((items, sampling_time), f)
+        return molecules, sampling_time
     if args.metrics:
         write_metrics(args, model, molecules, out)
     if out.suffix != '.sdf':

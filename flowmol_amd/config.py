@@ -173,6 +173,17 @@ def from_reference_hparams(hp: dict) -> VFConfig:
     for k, dflt in (('cat_temp_decay_max', 0.8), ('cat_temp_decay_a', 2), ('forward_weight_schedule', 'beta'),
                     ('fw_beta_a', 0.25), ('fw_beta_b', 0.25), ('fw_beta_max', 10.0)):
         setattr(cfg, k, vf.get(k, dflt))
+    # keys of the reference's vector_field: block this loader understands; anything else would be silently ignored, so it is an error
+    known = set(ref_defaults) | {'cat_temperature_schedule', 'cat_temp_decay_max', 'cat_temp_decay_a', 'forward_weight_schedule', 'fw_beta_a',
+                                 'fw_beta_b', 'fw_beta_max', 'attention', 'dropout', 's_message_dim', 'v_message_dim', 'n_heads', 'n_expansion_gvps',
+                                 'continuous_inv_temp_schedule', 'continuous_inv_temp_max', 'dst_feat_msg_reduction_factor', 'scprop', 'has_mask',
+                                 'exclude_charges', 'n_cp_feats'}
+    unknown = sorted(set(vf) - known)
+    if unknown:
+        raise NotImplementedError(f'vector_field keys {unknown} are not understood by this loader')
+    if vf.get('exclude_charges', False):
+        raise NotImplementedError('exclude_charges is deprecated in the reference (vector_field.py:80-82) and not implemented')
+    # n_heads / n_expansion_gvps only take effect with attention / compressed messaging (rejected below); flowmol3.yml sets n_heads: 32 with attention: False
     for unsupported in ('attention', 'dropout', 's_message_dim', 'v_message_dim'):
         v = vf.get(unsupported)
         if v not in (None, False, 0, 0.0):

@@ -71,7 +71,6 @@ struct fm_ctx {
     float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
     float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *tab_in = nullptr;
     fm_dst boot{};
-    int *cnt = nullptr; unsigned char* hc_flag = nullptr;
     int32_t *sa1 = nullptr, *sc1 = nullptr, *se1 = nullptr;
     // ---- taps / profiling
     std::map<std::string, void*> taps;
@@ -395,7 +394,6 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
               const fm_step_scalars* sc, const fm_sampled* smp) {
     Launch L{c, st};
     const FmBatch& b = c->b;
-    L("x_step", fm_k_x_step, dim3((b.N * 3 + 255) / 256), dim3(256), 0, state->x_t, (const float*)dst->x, sc->x_coef, sc->dt, sc->x_scale, b.N * 3);
     struct Mod { int rows, K; const float* p; const int* mol; int* xt; int* x1; const float *q, *u1, *u2; };
     Mod mods[3] = {
         {b.N, c->na, dst->a, b.node_mol, state->a_t, (smp && smp->a1) ? smp->a1 : c->sa1, nz->q_a, nz->u1_a, nz->u2_a},
@@ -403,6 +401,7 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
         {b.U, c->ne, dst->e, b.pair_mol, state->e_t, (smp && smp->e1) ? smp->e1 : c->se1, nz->q_e, nz->u1_e, nz->u2_e},
     };
     if (sc->dfm_type == FM_DFM_GAT) {
+        L("x_step", fm_k_x_step, dim3((b.N * 3 + 255) / 256), dim3(256), 0, state->x_t, (const float*)dst->x, sc->x_coef, sc->dt, sc->x_scale, b.N * 3);
         for (int m = 0; m < 3; ++m) {
             if (mods[m].rows == 0) continue;
             FmGatArgs a{};
@@ -413,18 +412,16 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
         return L.rc;
     }
     if (sc->dfm_type != FM_DFM_CAMPBELL) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: unknown dfm_type %d", sc->dfm_type);
-    L.zero(c->cnt, (size_t)6 * b.B * 4);
+    FmCtmcFusedArgs f{};
+    const int* offs[3] = {b.mol_node_off, b.mol_node_off, b.mol_pair_off};
     for (int m = 0; m < 3; ++m) {
-        if (mods[m].rows == 0) continue;
-        FmCtmcArgs a{};
-        a.rows = mods[m].rows; a.K = mods[m].K; a.B = b.B; a.p = mods[m].p; a.row_mol = mods[m].mol; a.xt = mods[m].xt; a.x1 = mods[m].x1;
-        a.q = mods[m].q; a.u1 = mods[m].u1; a.u2 = mods[m].u2; a.inv_temp_div = sc->cat_temperature; a.hc_thresh = sc->hc_thresh;
-        a.unmask_prob = sc->unmask_prob[m]; a.mask_prob = sc->mask_prob[m]; a.last_step = sc->last_step;
-        a.cnt_m = c->cnt + 2 * m * b.B; a.cnt_h = c->cnt + (2 * m + 1) * b.B; a.hc_flag = c->hc_flag;
-        const dim3 g((a.rows + 255) / 256);
-        L("ctmc_pass1", fm_k_ctmc_pass1, g, dim3(256), 0, a);
-        L("ctmc_pass2", fm_k_ctmc_pass2, g, dim3(256), 0, a);
+        FmCtmcMod& d = f.mod[m];
+        d.K = mods[m].K; d.p = mods[m].p; d.xt = mods[m].xt; d.x1 = mods[m].x1; d.q = mods[m].q; d.u1 = mods[m].u1; d.u2 = mods[m].u2;
+        d.off = offs[m]; d.unmask_prob = sc->unmask_prob[m]; d.mask_prob = sc->mask_prob[m];
     }
+    f.temp = sc->cat_temperature; f.hc_thresh = sc->hc_thresh; f.last_step = sc->last_step;
+    f.x_t = state->x_t; f.x1 = dst->x; f.node_off = b.mol_node_off; f.coef = sc->x_coef; f.dt = sc->dt; f.scale = sc->x_scale;
+    L("ctmc", fm_k_ctmc_fused, dim3(b.B, 4), dim3(256), 0, f);
     return L.rc;
 }
 
@@ -664,7 +661,7 @@ struct WsLayout {
     int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_stab, off_tabin, off_bx, off_ba,
-        off_bc, off_be, off_cnt, off_hc, off_sa1, off_sc1, off_se1, total;
+        off_bc, off_be, off_sa1, off_sc1, off_se1, total;
 };
 
 static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
@@ -673,7 +670,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     int nmax = 0;
     for (int i = 0; i < B; ++i) {
         const int n = n_atoms[i];
-        if (n < 2) return fail(c, FM_ERR_INVALID, "molecule %d has %d atoms; the fully-connected graph needs >= 2", i, n);
+        if (n < 1) return fail(c, FM_ERR_INVALID, "molecule %d has %d atoms", i, n);      // a 1-atom molecule has no edges: its node rows simply receive no messages
         N += n; E += (long long)n * (n - 1); nmax = n > nmax ? n : nmax;
     }
     if (E > 0x7fffffffLL / 4) return fail(c, FM_ERR_INVALID, "batch too large for int32 edge indexing (%lld edges)", E);
@@ -698,7 +695,6 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.off_part_s = take((size_t)N * w.P * 256 * 4); w.off_part_v = take((size_t)N * w.P * 3 * V * 4);
     w.off_stab = take((size_t)align_up(w.tab_rows, FM_TM) * 256 * 4); w.off_tabin = take((size_t)w.tab_rows * w.tab_kp * 4);
     w.off_bx = take((size_t)N * 3 * 4); w.off_ba = take((size_t)N * c->na * 4); w.off_bc = take((size_t)N * c->nc * 4); w.off_be = take((size_t)w.U * c->ne * 4);
-    w.off_cnt = take((size_t)6 * B * 4); w.off_hc = take((size_t)(N > w.U ? N : w.U));
     w.off_sa1 = take((size_t)N * 4); w.off_sc1 = take((size_t)N * 4); w.off_se1 = take((size_t)w.U * 4);
     w.total = o;
     return FM_OK;
@@ -742,7 +738,6 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     c->part_s = (float*)(base + w.off_part_s); c->part_v = (float*)(base + w.off_part_v);
     c->s_tab = (float*)(base + w.off_stab); c->tab_in = (float*)(base + w.off_tabin);
     c->boot.x = (float*)(base + w.off_bx); c->boot.a = (float*)(base + w.off_ba); c->boot.c = (float*)(base + w.off_bc); c->boot.e = (float*)(base + w.off_be);
-    c->cnt = (int*)(base + w.off_cnt); c->hc_flag = (unsigned char*)(base + w.off_hc);
     c->sa1 = (int32_t*)(base + w.off_sa1); c->sc1 = (int32_t*)(base + w.off_sc1); c->se1 = (int32_t*)(base + w.off_se1);
     c->n_tiles_e = (w.E + FM_TM - 1) / FM_TM; c->n_tiles_n = (w.N + FM_TM - 1) / FM_TM; c->n_tiles_u = (w.U + FM_TM - 1) / FM_TM;
     Launch L{c, st};

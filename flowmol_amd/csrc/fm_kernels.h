@@ -911,78 +911,98 @@ __global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// CTMC categorical update (ctmc_vector_field.py:349-357,414-461; ctmc_utils.py:4-34)
-//   pass 1: p~ = softmax(log p / T); x1 = argmax((p~/sum p~)/q) (== torch.multinomial n=1 fast path);
-//           per-molecule counts of masked rows (m) and high-confidence masked rows (h).
+// CTMC categorical update (ctmc_vector_field.py:349-357,414-461; ctmc_utils.py:4-34) + the Euler step of the positions
+// (:331-334): the whole campbell update of one integration step in ONE launch.  Grid (B, 4): one workgroup per
+// (molecule, job), job 0..2 = modality a, c, e, job 3 = the molecule's positions.
+//   pass 1: p~ = softmax(log p / T); x1 = argmax((p~/sum p~)/q) (== torch.multinomial n=1 fast path); counts of the
+//           molecule's masked rows (m) and high-confidence masked rows (h)
 //   pass 2: per-row unmask / re-mask decisions and the new token.
+// A molecule's rows are contiguous (atoms: mol_node_off, unordered pairs: mol_pair_off), so m / h are a workgroup
+// reduction (registers -> wave shuffle -> LDS) instead of one global atomic per masked row (round 1: 1.1 M atomics onto
+// 1024 addresses at the bench size, 0.3 ms per modality), no counter-zeroing pass exists, and pass 2 re-reads only what
+// the same thread wrote in pass 1 (x1 with the high-confidence flag parked in bit 8).  Every op that must equal torch's
+// separately rounded f32 op is never-contracted (fm_*_rn); logf / expf / IEEE division as in round 1 (bit-exact vs the
+// CPU reference path on every fixture).
 // ------------------------------------------------------------------------------------------------
-struct FmCtmcArgs {
-    int rows, K, B;                 // K real categories; mask index = K
-    const float* p;                 // (rows,K) endpoint probabilities (un-tempered softmax)
-    const int* row_mol;             // (rows)
-    int* xt;                        // (rows) tokens, updated in place
-    int* x1;                        // (rows) sampled endpoint tokens (output, also "x_1_pred")
-    const float* q;                 // (rows,K) Exp(1) noise
-    const float* u1;                // (rows) unmask uniform
-    const float* u2;                // (rows) re-mask uniform (unused on the last step)
-    float inv_temp_div;             // temperature T (log p is DIVIDED by it like the reference)
-    float hc_thresh, unmask_prob, mask_prob;
+struct FmCtmcMod {
+    int K;                          // real categories; mask token = K
+    const float* p;                 // (rows,K)
+    int* xt; int* x1;               // (rows)
+    const float* q; const float* u1; const float* u2;
+    const int* off;                 // [B+1] first row of every molecule
+    float unmask_prob, mask_prob;
+};
+struct FmCtmcFusedArgs {
+    FmCtmcMod mod[3];
+    float temp, hc_thresh;
     int last_step;
-    int* cnt_m; int* cnt_h;         // (B) zeroed before pass 1
-    unsigned char* hc_flag;         // (rows) scratch
+    float* x_t; const float* x1; const int* node_off; float coef, dt, scale;     // Euler step (fm_k_x_step)
 };
 
-__global__ void __launch_bounds__(256) fm_k_ctmc_pass1(FmCtmcArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.rows) return;
-    float lp[16];
-    float mx = -INFINITY;
-    for (int k = 0; k < a.K; ++k) { lp[k] = fm_div_rn(logf(a.p[(size_t)i * a.K + k]), a.inv_temp_div); mx = fmaxf(mx, lp[k]); }
-    float sum = 0.f;
-    for (int k = 0; k < a.K; ++k) { lp[k] = expf(fm_sub_rn(lp[k], mx)); sum = fm_add_rn(sum, lp[k]); }
-    float purity = 0.f, psum = 0.f;
-    for (int k = 0; k < a.K; ++k) { lp[k] = fm_div_rn(lp[k], sum); purity = fmaxf(purity, lp[k]); psum = fm_add_rn(psum, lp[k]); }
-    int best = 0; float bestv = -1.f;
-    for (int k = 0; k < a.K; ++k) {
-        const float v = fm_div_rn(fm_div_rn(lp[k], psum), a.q[(size_t)i * a.K + k]);
-        if (v > bestv) { bestv = v; best = k; }
-    }
-    a.x1[i] = best;
-    const bool masked = a.xt[i] == a.K;
-    const bool hc = masked && (purity >= a.hc_thresh);
-    a.hc_flag[i] = hc ? 1 : 0;
-    if (a.hc_thresh > 0.f && masked) {
-        atomicAdd(&a.cnt_m[a.row_mol[i]], 1);
-        if (hc) atomicAdd(&a.cnt_h[a.row_mol[i]], 1);
-    }
-}
-
-__global__ void __launch_bounds__(256) fm_k_ctmc_pass2(FmCtmcArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.rows) return;
-    const int tok = a.xt[i];
-    const bool masked = tok == a.K;
-    bool will_unmask;
-    if (a.hc_thresh > 0.f) {
-        float prob = 0.f;
-        if (masked) {
-            const int mol = a.row_mol[i];
-            const float m = (float)a.cnt_m[mol], h = (float)a.cnt_h[mol];
-            // ph = min(unmask_prob*m/h, 1) (inf when h == 0); pl = (unmask_prob*m - ph*h)/(m-h)
-            const float um = fm_mul_rn(a.unmask_prob, m);
-            float ph = (a.cnt_h[mol] == 0) ? INFINITY : fm_div_rn(um, h);
-            ph = fminf(ph, 1.0f);
-            if (a.hc_flag[i]) prob = ph;
-            else prob = fm_div_rn(fm_sub_rn(um, fm_mul_rn(ph, h)), fm_sub_rn(m, h));
+__global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
+    __shared__ int red[2][4];
+    const int mol = blockIdx.x, job = blockIdx.y, tid = threadIdx.x;
+    if (job == 3) {
+        const int i0 = a.node_off[mol] * 3, i1 = a.node_off[mol + 1] * 3;
+        for (int i = i0 + tid; i < i1; i += 256) {
+            const float vf = fm_mul_rn(a.coef, fm_sub_rn(a.x1[i], a.x_t[i]));
+            a.x_t[i] = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
         }
-        will_unmask = a.u1[i] < prob;           // comparisons against NaN are false, as in torch
-    } else {
-        will_unmask = (a.u1[i] < a.unmask_prob) && masked;
+        return;
     }
-    int nt = tok;
-    if (!a.last_step) { if ((a.u2[i] < a.mask_prob) && !masked) nt = a.K; }
-    if (will_unmask) nt = a.x1[i];
-    a.xt[i] = nt;
+    const FmCtmcMod md = a.mod[job];
+    const int r0 = md.off[mol], r1 = md.off[mol + 1], K = md.K;
+    int cm = 0, ch = 0;
+    for (int i = r0 + tid; i < r1; i += 256) {
+        float lp[16];
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) { lp[k] = fm_div_rn(logf(md.p[(size_t)i * K + k]), a.temp); mx = fmaxf(mx, lp[k]); }
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) { lp[k] = expf(fm_sub_rn(lp[k], mx)); sum = fm_add_rn(sum, lp[k]); }
+        float purity = 0.f, psum = 0.f;
+        for (int k = 0; k < K; ++k) { lp[k] = fm_div_rn(lp[k], sum); purity = fmaxf(purity, lp[k]); psum = fm_add_rn(psum, lp[k]); }
+        int best = 0; float bestv = -1.f;
+        for (int k = 0; k < K; ++k) {
+            const float v = fm_div_rn(fm_div_rn(lp[k], psum), md.q[(size_t)i * K + k]);
+            if (v > bestv) { bestv = v; best = k; }
+        }
+        const bool masked = md.xt[i] == K;
+        const bool hc = masked && (purity >= a.hc_thresh);
+        md.x1[i] = best | (hc ? 256 : 0);
+        cm += masked ? 1 : 0; ch += hc ? 1 : 0;
+    }
+    if (a.hc_thresh > 0.f) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cm += __shfl_xor(cm, o); ch += __shfl_xor(ch, o); }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = cm; red[1][tid >> 6] = ch; }
+        __syncthreads();
+        cm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        ch = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    // per-molecule probabilities: ph = min(unmask_prob*m/h, 1) (inf when h == 0); pl = (unmask_prob*m - ph*h)/(m-h)
+    const float m = (float)cm, h = (float)ch;
+    const float um = fm_mul_rn(md.unmask_prob, m);
+    float ph = (ch == 0) ? INFINITY : fm_div_rn(um, h);
+    ph = fminf(ph, 1.0f);
+    const float pl = fm_div_rn(fm_sub_rn(um, fm_mul_rn(ph, h)), fm_sub_rn(m, h));
+    for (int i = r0 + tid; i < r1; i += 256) {
+        const int packed = md.x1[i];
+        const int x1 = packed & 255;
+        const int tok = md.xt[i];
+        const bool masked = tok == K;
+        bool will_unmask;
+        if (a.hc_thresh > 0.f) {
+            const float prob = masked ? ((packed & 256) ? ph : pl) : 0.f;
+            will_unmask = md.u1[i] < prob;           // comparisons against NaN are false, as in torch
+        } else {
+            will_unmask = (md.u1[i] < md.unmask_prob) && masked;
+        }
+        int nt = tok;
+        if (!a.last_step) { if ((md.u2[i] < md.mask_prob) && !masked) nt = K; }
+        if (will_unmask) nt = x1;
+        md.xt[i] = nt;
+        md.x1[i] = x1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,6 +64,36 @@ def read_checkpoint(path):
     return dict(ck['hyper_parameters']), ck['state_dict']
 
 
+SUPPORTED_PARAMETERIZATIONS = ('ctmc',)
+SUPPORTED_SCHEDULES = ('linear',)
+
+
+def check_reference_hparams(hp: dict) -> None:
+    """Reject -- loudly, before any weight is touched -- every checkpoint configuration the HIP path does not reproduce, so that
+    no model is ever integrated with the wrong schedule or prior.  Missing keys take the REFERENCE's defaults
+    (FlowMol.__init__ flowmol.py:29-55: parameterization='endpoint'; InterpolantScheduler interpolant_scheduler.py:9:
+    schedule_type='cosine'), so a checkpoint that relies on an unimplemented default is rejected too."""
+    par = hp.get('parameterization', 'endpoint')
+    if par not in SUPPORTED_PARAMETERIZATIONS:
+        raise NotImplementedError(f"parameterization={par!r}: implemented: {SUPPORTED_PARAMETERIZATIONS}")
+    isc = hp.get('interpolant_scheduler_config', {}) or {}
+    st = isc.get('schedule_type', 'cosine')
+    types = [st.get(f, 'cosine') for f in 'xace'] if isinstance(st, dict) else [st]
+    bad = sorted({t for t in types if t not in SUPPORTED_SCHEDULES})
+    if bad:
+        raise NotImplementedError(f'interpolant schedule_type {bad}: implemented: {SUPPORTED_SCHEDULES} '
+                                  '(a cosine-schedule checkpoint would otherwise be integrated with the wrong x and unmasking coefficients)')
+    pc = hp.get('prior_config', {}) or {}
+    xt = (pc.get('x', {}) or {}).get('type', 'centered-normal')
+    if xt != 'centered-normal':
+        raise NotImplementedError(f"position prior {xt!r}: only 'centered-normal' is implemented (a 'gaussian' prior would be centred silently)")
+    for mod in ('a', 'c', 'e'):
+        if (pc.get(mod, {}) or {}).get('type', 'ctmc') != 'ctmc':
+            raise NotImplementedError('only ctmc masked priors are supported for CTMC models (as in the reference, flowmol.py:189-193)')
+    if hp.get('exclude_charges', False):
+        raise NotImplementedError('exclude_charges=True is not implemented (no shipped v3 model uses it)')
+
+
 class FlowMol:
     canonical_feat_order = ['x', 'a', 'c', 'e']
 
@@ -96,11 +126,7 @@ class FlowMol:
     @classmethod
     def load_from_checkpoint(cls, ckpt_path, **kw) -> "FlowMol":
         hp, sd = read_checkpoint(ckpt_path)
-        if hp.get('parameterization', 'ctmc') != 'ctmc':
-            raise NotImplementedError("only parameterization='ctmc' (FlowMol2/3) is implemented")
-        for mod in ('a', 'c', 'e'):
-            if hp.get('prior_config', {}).get(mod, {}).get('type', 'ctmc') != 'ctmc':
-                raise NotImplementedError('only ctmc masked priors are supported (as in the reference, flowmol.py:189-193)')
+        check_reference_hparams(hp)
         return cls(from_reference_hparams(hp), sd, **kw)
 
     # nn.Module-ish conveniences of the documented usage (readme.md:44-49)
@@ -178,12 +204,14 @@ class FlowMol:
             pair_rows = shard._ranges((torch.cumsum(pairs, 0) - pairs)[mine], pairs[mine]).to(dev)
             kwargs['_rows'] = (int(n_atoms.sum()), int(pairs.sum()), node_rows, pair_rows)
         if len(parts[rank]):
-            out, _ = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors=True, **kwargs)
-            local = {k: out[k].to(dev) for k in 'xace'}
+            local, _ = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors='device', **kwargs)   # stays in HBM
         else:
             i32 = dict(dtype=torch.int32, device=dev)
             local = {'x': torch.zeros(0, 3, device=dev), 'a': torch.zeros(0, **i32), 'c': torch.zeros(0, **i32), 'e': torch.zeros(0, **i32)}
-        full = {k: v.cpu() for k, v in shard.gather_results(local, n_atoms, parts, group=group).items()}
+        full_dev = shard.gather_results(local, n_atoms, parts, group=group)
+        if return_tensors == 'device':
+            return full_dev, n_atoms
+        full = _to_host(full_dev)            # one packed device->host copy of the whole gathered batch (1.7 KB/molecule)
         if return_tensors:
             return full, n_atoms
         return self._package(full, n_atoms, None, False, False)
@@ -206,7 +234,7 @@ class FlowMol:
         dfm_type = kwargs.get('dfm_type') or self.cfg.dfm_type
         if dfm_type not in ('campbell', 'gat'):
             raise ValueError(f"Invalid dfm_type: {dfm_type}")
-        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows'}
+        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows', '_noise_for_step'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         visualize = bool(xt_traj or ep_traj)
@@ -244,15 +272,28 @@ class FlowMol:
             full = StepNoise.draw(rows[0], rows[1], cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, dfm_type=dfm_type)
             return full.take_rows(rows[2], rows[3])
 
-        eng.integrate(state, plan, noise_for_step, traj=traj)
-        out = {k: state[f'{k}_t'].cpu() for k in 'xace'}
+        import time
+        t0 = time.perf_counter()
+        # _noise_for_step(i, last) -> StepNoise: recorded draws instead of torch's generator (parity tests drive the public API with
+        # the oracle's RNG tape); never set by the product itself
+        eng.integrate(state, plan, kwargs.get('_noise_for_step') or noise_for_step, traj=traj)          # synchronises at the end
+        t1 = time.perf_counter()
+        out_dev = {k: state[f'{k}_t'] for k in 'xace'}
+        if return_tensors == 'device':
+            self.last_timing = {'integrate': t1 - t0}
+            return out_dev, n_atoms
+        out = _to_host(out_dev)
+        t2 = time.perf_counter()
+        self.last_timing = {'integrate': t1 - t0, 'to_host': t2 - t1}
         if return_tensors:
             return out, n_atoms
         frames = None
         if visualize:
             frames = {k: torch.cat([init[k].unsqueeze(0), traj[k]]).cpu() for k in 'xace'}
             frames.update({f'{k}_1_pred': traj[f'{k}1'].cpu() for k in 'xace'})
-        return self._package(out, n_atoms, frames, xt_traj, ep_traj)
+        mols = self._package(out, n_atoms, frames, xt_traj, ep_traj)
+        self.last_timing['package'] = time.perf_counter() - t2
+        return mols
 
     # ------------------------------------------------------------------ helpers
     def _state_from_prior(self, prior):
@@ -275,22 +316,30 @@ class FlowMol:
         return eng.make_state(prior['x_0'], a0.argmax(-1), prior['c_0'].argmax(-1), e0.argmax(-1))
 
     def _package(self, out, n_atoms, frames, xt_traj, ep_traj) -> List[SampledMolecule]:
+        """Host tensors of the whole batch -> one SampledMolecule per molecule, in batch order (flowmol.py:564-589)."""
+        sizes = n_atoms.tolist()
+        pairs = [n * (n - 1) // 2 for n in sizes]
+        xs, as_, cs = torch.split(out['x'], sizes), torch.split(out['a'], sizes), torch.split(out['c'], sizes)
+        es = torch.split(out['e'], pairs)
+        fr = None
+        if frames is not None:
+            fr = {k: torch.split(v, pairs if k.startswith('e') else sizes, dim=1) for k, v in frames.items()}
         mols = []
-        noff = poff = 0
-        for n in n_atoms.tolist():
-            u = n * (n - 1) // 2
-            tf = None
-            if frames is not None:
-                tf = {}
-                for k, v in frames.items():
-                    tf[k] = v[:, poff:poff + u] if k.startswith('e') else v[:, noff:noff + n]
-            mols.append(SampledMolecule(out['x'][noff:noff + n], out['a'][noff:noff + n], out['c'][noff:noff + n],
-                                        out['e'][poff:poff + u], self.atom_type_map, fake_atoms=self.fake_atoms,
+        for i in range(len(sizes)):
+            tf = {k: v[i] for k, v in fr.items()} if fr is not None else None
+            mols.append(SampledMolecule(xs[i], as_[i], cs[i], es[i], self.atom_type_map, fake_atoms=self.fake_atoms,
                                         ctmc_mol=True, explicit_aromaticity=self.explicit_aromaticity, traj_frames=tf,
                                         build_xt_traj=xt_traj, build_ep_traj=ep_traj))
-            noff += n
-            poff += u
         return mols
+
+
+def _to_host(dev_out: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Final state of a batch, device -> host, as ONE packed copy (x fp32 | a, c, e as bytes: 14 B/atom + 1 B/pair)."""
+    from .shard import pack_results, unpack_results
+    if dev_out['x'].device.type == 'cpu':
+        return {k: v for k, v in dev_out.items()}
+    N, U = int(dev_out['x'].shape[0]), int(dev_out['e'].shape[0])
+    return unpack_results(pack_results(dev_out['x'], dev_out['a'], dev_out['c'], dev_out['e']).cpu(), N, U)
 
 
 # names accepted by the reference's load_pretrained (flowmol/__init__.py:5-28)

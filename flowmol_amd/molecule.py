@@ -7,14 +7,17 @@ built lazily and is ``None`` when RDKit is not installed (it is not, in this ima
 """
 from __future__ import annotations
 
+import functools
 from typing import Dict, List, Optional
 
 import torch
 
 
+@functools.lru_cache(maxsize=256)
 def pair_indices(n: int):
     """(src, dst) of the unordered pairs in the reference's upper-edge order
-    (torch.triu_indices(n, n, 1), flowmol/data_processing/utils.py:4-17)."""
+    (torch.triu_indices(n, n, 1), flowmol/data_processing/utils.py:4-17).  Cached per size: packaging a batch
+    calls this once per molecule."""
     up = torch.triu_indices(n, n, offset=1)
     return up[0], up[1]
 
@@ -113,6 +116,11 @@ class SampledMolecule:
             blocks.append(mol_block(pos, sym, chg, bs, bd, bt, name=f'frame {f}'))
         return blocks
 
+    def to_record(self) -> dict:
+        """RDKit-free form of the molecule (what build_molecule, molecule_builder.py:268-300, consumes): plain Python / numpy."""
+        return {'positions': self.positions.numpy().copy(), 'atom_types': list(self.atom_types), 'atom_charges': self.atom_charges.tolist(),
+                'bond_types': self.bond_types.tolist(), 'bond_src_idxs': self.bond_src_idxs.tolist(), 'bond_dst_idxs': self.bond_dst_idxs.tolist()}
+
     def to_sdf_block(self) -> str:
         """V2000 mol block without RDKit (atoms, formal charges, bond orders)."""
         return mol_block(self.positions, self.atom_types, self.atom_charges, self.bond_src_idxs, self.bond_dst_idxs, self.bond_types)
@@ -162,15 +170,24 @@ _CHG = {3: 1, 2: 2, 1: 3, -1: 5, -2: 6, -3: 7}
 
 
 def mol_block(positions, atom_types, atom_charges, bond_src, bond_dst, bond_types, name: str = 'flowmol_amd') -> str:
-    """MDL V2000 mol block (+ '$$$$' is the caller's job)."""
+    """MDL V2000 mol block as RDKit's writer lays it out (the reference writes SDF through Chem.SDWriter, test.py:212-257):
+    counts line, atom lines with the legacy charge column, bond lines, `M  CHG` property lines (8 entries per line) for the
+    charged atoms, `M  END`.  ('$$$$' is the caller's job.)"""
     na, nb = len(atom_types), int(bond_types.shape[0])
     lines = [name, '  flowmol_amd          3D', '', f'{na:3d}{nb:3d}  0  0  0  0  0  0  0  0999 V2000']
+    charged = []
     for i, sym in enumerate(atom_types):
         x, y, z = (float(v) for v in positions[i])
-        chg = _CHG.get(int(atom_charges[i]), 0)
+        q = int(atom_charges[i])
+        chg = _CHG.get(q, 0)
+        if q != 0:
+            charged.append((i + 1, q))
         lines.append(f'{x:10.4f}{y:10.4f}{z:10.4f} {sym:<3s} 0{chg:3d}  0  0  0  0  0  0  0  0  0  0')
     for k in range(nb):
         bt = int(bond_types[k])
         lines.append(f'{int(bond_src[k]) + 1:3d}{int(bond_dst[k]) + 1:3d}{bt:3d}  0')
+    for o in range(0, len(charged), 8):
+        part = charged[o:o + 8]
+        lines.append(f'M  CHG{len(part):3d}' + ''.join(f' {a:3d} {q:3d}' for a, q in part))
     lines.append('M  END')
     return '\n'.join(lines) + '\n'

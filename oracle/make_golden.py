@@ -291,6 +291,46 @@ def gen_stability():
     np.savez_compressed(OUT / 'stability.npz', **_np(out))
 
 
+def gen_moldata():
+    """Token molecules -> the reference's OWN extract_moldata_from_graph (molecule_builder.py:217-265) run on a per-molecule
+    graph carrying the float one-hots the reference keeps (x_1, a_1, c_1, e_1, ue_mask); the function is AST-imported like
+    check_stability because its module imports RDKit.  Pins cpu_ref.extract_moldata and flowmol_amd.molecule."""
+    ref = Path('/root/reference/flowmol')
+    extract = _ref_function(ref / 'analysis' / 'molecule_builder.py', 'extract_moldata_from_graph')
+    ns = ref_standin.import_reference()
+    g_st = {k: torch.from_numpy(v) for k, v in np.load(OUT / 'stability.npz').items()}
+    oh = lambda t, k: torch.nn.functional.one_hot(t, k).float()
+    out = {}
+    gen = torch.Generator().manual_seed(23)
+    base_map = ['C', 'H', 'N', 'O', 'F', 'P', 'S', 'Cl', 'Br', 'I']
+    for tag, arom, fake in (('kek', False, True), ('arom', True, False)):
+        nb = 5 if arom else 4
+        amap = base_map + (['Sn'] if fake else []) + ['Se']            # what SampledMolecule.__init__ passes (molecule_builder.py:40-44)
+        sizes = g_st[f'{tag}.n_atoms'].tolist()
+        X, P, SYM, CHG, BT, BS, BD, cnt = [], [], [], [], [], [], [], []
+        no = po = 0
+        for n in sizes:
+            u = n * (n - 1) // 2
+            a, c, e = g_st[f'{tag}.a'][no:no + n], g_st[f'{tag}.c'][no:no + n], g_st[f'{tag}.e'][po:po + u]
+            no += n; po += u
+            x = torch.randn(n, 3, generator=gen)
+            ei = ns.build_edge_idxs(n)
+            g = ns.dgl.graph((ei[0], ei[1]), num_nodes=n)
+            g.ndata['x_1'], g.ndata['a_1'], g.ndata['c_1'] = x, oh(a, len(amap)), oh(c, 6)
+            g.edata['e_1'] = torch.cat([oh(e, nb + 1)] * 2)
+            g.edata['ue_mask'] = ns.get_upper_edge_mask(g)
+            pos, sym, chg, bt, bs, bd = extract(g, amap, exclude_charges=False, ctmc_mol=True, fake_atoms=fake,
+                                                show_fake_atoms=False, explicit_aromaticity=arom)
+            X.append(x); P.append(pos); SYM.append(torch.tensor([amap.index(s_) for s_ in sym], dtype=torch.long))
+            CHG.append(chg); BT.append(bt); BS.append(bs); BD.append(bd)
+            cnt.append([pos.shape[0], bt.shape[0]])
+        out[f'{tag}.x'] = torch.cat(X)
+        out[f'{tag}.pos'] = torch.cat(P); out[f'{tag}.sym'] = torch.cat(SYM); out[f'{tag}.chg'] = torch.cat(CHG)
+        out[f'{tag}.bt'] = torch.cat(BT); out[f'{tag}.bs'] = torch.cat(BS); out[f'{tag}.bd'] = torch.cat(BD)
+        out[f'{tag}.counts'] = torch.tensor(cnt)                       # per molecule: atoms kept, bonds kept
+    np.savez_compressed(OUT / 'moldata.npz', **_np(out))
+
+
 def gen_misc(ns):
     out = {}
     t = torch.tensor([0.0, 0.004016064, 0.5, 0.9959839, 1.0])
@@ -338,12 +378,87 @@ def gen_misc(ns):
     np.savez_compressed(OUT / 'misc.npz', **_np(out))
 
 
+def gen_ctmc_step(ns):
+    """The reference's own CTMCVectorField.step (ctmc_vector_field.py:287-411: Euler step, tempering softmax(log p / T),
+    campbell_step, purity_sampling, edge mirroring) with its network evaluation replaced by a FIXED endpoint prediction, on a
+    batch crafted to hit the purity-sampling edge cases by construction: a molecule with no high-confidence masked rows (h = 0),
+    one whose masked rows are all high-confidence (m = h), a fully unmasked molecule (m = 0), a 2-atom molecule (one pair),
+    the hc = 0 branch and the last step.  Inputs, the recorded RNG draws and the outputs go to tests/golden/ctmc_step.npz;
+    the HIP fm_ctmc_step must reproduce the outputs bit for bit (tests/test_gpu_parity.py)."""
+    cfg = presets.flowmol3()
+    vf = ref_standin.build_reference_vf(ns, cfg, weights.synth_state_dict(cfg, 0))
+    n_atoms = torch.tensor([4, 7, 2, 9, 5])
+    g0, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
+    N, E = g0.num_nodes(), g0.num_edges()
+    U = E // 2
+    pairs = n_atoms * (n_atoms - 1) // 2
+    pb = torch.arange(5).repeat_interleave(pairs)
+    gen = torch.Generator().manual_seed(17)
+    oh = torch.nn.functional.one_hot
+    out = {'n_atoms': n_atoms}
+    T = 250
+    t = torch.linspace(0, 1, T)
+    sched = ns.InterpolantScheduler(canonical_feat_order=['x', 'a', 'c', 'e'], schedule_type={k: 'linear' for k in 'xace'})
+    alpha_t, alpha_tp = sched.alpha_t(t), sched.alpha_t_prime(t)
+
+    def probs(rows, K, idx):
+        p = torch.softmax(torch.randn(rows, K, generator=gen) * 3, -1)
+        flat = torch.softmax(torch.randn(rows, K, generator=gen) * 0.05, -1)     # tempered max prob stays far below 0.9
+        sharp = torch.softmax(torch.randn(rows, K, generator=gen) * 40, -1)      # tempered max prob ~ 1
+        p[idx == 1] = flat[idx == 1]
+        p[idx == 3] = sharp[idx == 3]
+        return p
+
+    cases = [(0.9, False, 30.0, 75), (0.9, True, 30.0, T - 1), (0.0, False, 10.0, 120), (0.9, False, 30.0, 12), (0.5, False, 0.0, 200)]
+    for case, (hc, last, eta, s_idx) in enumerate(cases):
+        def toks(rows, K, idx, frac):
+            tk = torch.randint(0, K, (rows,), generator=gen)
+            tk[torch.rand(rows, generator=gen) < frac] = K
+            tk[idx == 3] = K                                    # molecule 3: every row masked  -> m = h
+            tk[idx == 4] = tk[idx == 4].clamp(max=K - 1)        # molecule 4: nothing masked    -> m = 0, h = 0
+            if case == 3:
+                tk[idx == 1] = K                                # all masked, none high-confidence -> h = 0 with m > 0
+            return tk
+        a, c = toks(N, cfg.n_atom_types, nb, 0.5), toks(N, cfg.n_charges, nb, 0.5)
+        eu = toks(U, cfg.n_bond_types, pb, 0.5)
+        x_t = torch.randn(N, 3, generator=gen)
+        dst = {'x': torch.randn(N, 3, generator=gen), 'a': probs(N, cfg.n_atom_types, nb), 'c': probs(N, cfg.n_charges, nb),
+               'e': probs(U, cfg.n_bond_types, pb)}
+        if case == 0:
+            dst['a'][0, 3] = 0.0                                 # an exact zero probability: log -> -inf -> 0 (SURVEY Appendix C.5)
+            dst['a'][0] = dst['a'][0] / dst['a'][0].sum()
+        g, _, _, _ = ref_standin.build_reference_graph(ns, n_atoms)
+        e1h = torch.zeros(E, cfg.n_bond_types + 1)
+        e1h[upper] = oh(eu, cfg.n_bond_types + 1).float(); e1h[~upper] = oh(eu, cfg.n_bond_types + 1).float()
+        g.ndata['x_t'], g.ndata['a_t'], g.ndata['c_t'], g.edata['e_t'] = x_t.clone(), oh(a, cfg.n_atom_types + 1).float(), oh(c, cfg.n_charges + 1).float(), e1h
+        vf.forward = lambda *a_, **k_: {k: v.clone() for k, v in dst.items()}       # the network evaluation is not under test here
+        torch.manual_seed(300 + case)
+        with torch.no_grad(), _Tape() as tp:
+            gout, _ = vf.step(g, t[s_idx], t[s_idx - 1], alpha_t[s_idx - 1], alpha_t[s_idx], alpha_tp[s_idx - 1], nb, eb, upper,
+                              cat_temp_func=vf.cat_temp_func, forward_weight_func=vf.forward_weight_func, prev_dst_dict=None,
+                              dfm_type='campbell', stochasticity=eta, high_confidence_threshold=hc, last_step=last)
+        del vf.forward
+        pre = f'{case}.'
+        out[pre + 'params'] = np.array([hc, float(last), eta, float(s_idx), float(T)])
+        out.update({pre + 'x_t': x_t, pre + 'a_t': a, pre + 'c_t': c, pre + 'e_t': eu})
+        out.update({pre + f'dst.{k}': v for k, v in dst.items()})
+        out.update({pre + 'x_new': gout.ndata['x_t'], pre + 'a_new': gout.ndata['a_t'].argmax(-1), pre + 'c_new': gout.ndata['c_t'].argmax(-1),
+                    pre + 'e_new': gout.edata['e_t'][upper].argmax(-1), pre + 'a_1_pred': gout.ndata['a_1_pred'].argmax(-1),
+                    pre + 'c_1_pred': gout.ndata['c_1_pred'].argmax(-1), pre + 'e_1_pred': gout.edata['e_1_pred'][upper].argmax(-1)})
+        assert torch.equal(gout.edata['e_t'][upper], gout.edata['e_t'][~upper])
+        for i, t_ in enumerate(tp.tape):
+            out[pre + f'noise{i}'] = t_
+    np.savez_compressed(OUT / 'ctmc_step.npz', **_np(out))
+
+
 def main():
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
     ns = ref_standin.import_reference()
     gen_misc(ns)
+    gen_ctmc_step(ns)
     gen_stability()
+    gen_moldata()
     for name in ('flowmol3', 'geom_ctmc', 'qm9'):
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, seed=0)

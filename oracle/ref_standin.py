@@ -73,6 +73,22 @@ class FakeGraph:
         m = msg(self)
         self._ndata.update(red(self, m))
 
+    def remove_nodes(self, nids):
+        """dgl.DGLGraph.remove_nodes on an unbatched graph (documented semantics: the nodes and every edge incident to them
+        are removed, the remaining nodes keep their relative order and are relabelled 0..n'-1, node/edge features are
+        sliced accordingly, edge order is preserved)."""
+        nids = torch.as_tensor(nids, device=self._src.device).long().reshape(-1)
+        keep = torch.ones(self._n, dtype=torch.bool, device=self._src.device)
+        keep[nids] = False
+        new_id = torch.cumsum(keep.long(), 0) - 1
+        ek = keep[self._src] & keep[self._dst]
+        self._ndata = {k: v[keep] for k, v in self._ndata.items()}
+        self._edata = {k: v[ek] for k, v in self._edata.items()}
+        self._src, self._dst = new_id[self._src[ek]], new_id[self._dst[ek]]
+        self._n = int(keep.sum())
+        self._bnn = torch.tensor([self._n], device=self._src.device)
+        self._bne = torch.tensor([int(ek.sum())], device=self._src.device)
+
     def to(self, device):
         g = FakeGraph(self._src, self._dst, self._n, device, self._bnn, self._bne)
         g._ndata = {k: v.to(device) for k, v in self._ndata.items()}

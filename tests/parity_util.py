@@ -206,3 +206,32 @@ def stability_compare(eng, g, tag, dataset, arom, fake):
         if got[i].tolist() != want:
             bad.append((i, got[i].tolist(), want))
     return bad
+
+
+def ctmc_step_golden(eng, cfg, g, case, device=None):
+    """fm_ctmc_step on the inputs and recorded RNG draws of tests/golden/ctmc_step.npz (the reference's own
+    CTMCVectorField.step with a fixed endpoint prediction; purity-sampling edge cases by construction) ->
+    token flips against the reference's outputs and the max abs error of the Euler step."""
+    from flowmol_amd.engine import StepNoise, make_step_plan
+    device = device or eng.device
+    hc, last, eta, s_idx, T = [float(v) for v in g[f'{case}.params']]
+    last, s_idx, T = bool(last), int(s_idx), int(T)
+    eng.bind(g['n_atoms'])
+    plan = make_step_plan(T, eta, hc, cfg.cat_temperature)
+    sc = plan.scalars[s_idx - 1]
+    assert bool(sc.last_step) == last
+    tape = [g[f'{case}.noise{i}'] for i in range(6 if last else 9)]
+    nz, used = StepNoise.from_tape(tape, 0, last, device)
+    assert used == len(tape)
+    state = eng.make_state(g[f'{case}.x_t'], g[f'{case}.a_t'], g[f'{case}.c_t'], g[f'{case}.e_t'])
+    dst = {k: g[f'{case}.dst.{k}'].to(device).contiguous() for k in 'xace'}
+    i32 = dict(dtype=torch.int32, device=device)
+    smp = {'a1': torch.zeros(eng.N, **i32), 'c1': torch.zeros(eng.N, **i32), 'e1': torch.zeros(eng.U, **i32)}
+    eng.ctmc_step(state, dst, nz, sc, smp)
+    eng.synchronize()
+    res = {}
+    for k in 'ace':
+        res[f'{k}_flips'] = int((state[f'{k}_t'].cpu().long() != g[f'{case}.{k}_new']).sum())
+        res[f'{k}1_flips'] = int((smp[f'{k}1'].cpu().long() != g[f'{case}.{k}_1_pred']).sum())
+    res['x_abs'] = float((state['x_t'].cpu() - g[f'{case}.x_new']).abs().max())
+    return res

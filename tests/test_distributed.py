@@ -78,7 +78,7 @@ def _sample_worker(rank, world, port, sizes, q, noise='per_rank'):
     model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu).to('cpu')
     torch.manual_seed(100 + (rank if noise == 'per_rank' else 0))
     full, n = model.sample_distributed(torch.tensor(sizes), n_timesteps=3, return_tensors=True, noise=noise)
-    q.put((rank, {k: v.clone() for k, v in full.items()}))
+    q.put((rank, {k: v.numpy().copy() for k, v in full.items()}))    # plain arrays: torch's fd-based tensor sharing needs the producer alive
     dist.destroy_process_group()
 
 
@@ -97,7 +97,7 @@ def test_sample_distributed_world2_matches_per_rank_runs(emu_lib_path):
     procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=300) for _ in procs)}
     for p in procs:
         p.join(timeout=60)
     for k in 'xace':
@@ -157,7 +157,7 @@ def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path)
     procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q, 'replicated')) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in procs)
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=300) for _ in procs)}
     for p in procs:
         p.join(timeout=60)
     model = flowmol.FlowMol.from_preset('qm9', _engine_lib=_lib.load(emu_lib_path)).to('cpu')

@@ -16,7 +16,8 @@ from parity_util import forward_compare
 
 
 @pytest.mark.parametrize('tile', [16, 32])
-@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False)])
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False),
+                                               ('flowmol3', [3, 1, 2, 1], 0.5, True)])       # 1-atom molecules: no edges, no messages
 def test_emulated_forward_matches_oracle(emu_lib, monkeypatch, name, sizes, t, prev, tile):
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
@@ -166,17 +167,17 @@ def test_stability_kernel_on_emulation(emu_lib, golden_dir, tag, dataset, arom, 
 
 
 def test_batch_limits_are_reported(emu_lib):
-    """A batch beyond the 31-bit gather offsets (2,097,151 nodes) or with a 1-atom molecule is refused with the C ABI's
-    error text instead of being mis-addressed."""
+    """A batch beyond the 31-bit gather offsets (2,097,151 nodes) or with an empty molecule is refused with the C ABI's
+    error text instead of being mis-addressed (1-atom molecules are legal: no edges, no messages)."""
     from flowmol_amd.engine import Engine
     cfg = presets.qm9()
     eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
     with pytest.raises(_lib.FlowMolHipError, match='batch too large'):
         eng.bind(torch.full((12000,), 181, dtype=torch.int64))
-    with pytest.raises(_lib.FlowMolHipError, match='needs >= 2'):
-        eng.bind(torch.tensor([5, 1, 4]))
-    eng.bind(torch.tensor([5, 2, 4]))          # still usable afterwards
-    assert eng.N == 11
+    with pytest.raises(_lib.FlowMolHipError, match='has 0 atoms'):
+        eng.bind(torch.tensor([5, 0, 4]))
+    eng.bind(torch.tensor([5, 1, 4]))          # still usable afterwards
+    assert eng.N == 10 and eng.E == 32
 
 
 def test_single_timepoint_returns_the_prior(emu_lib):
@@ -188,3 +189,15 @@ def test_single_timepoint_returns_the_prior(emu_lib):
     out, _ = model.sample(torch.tensor([3, 4]), n_timesteps=1, return_tensors=True)
     assert (out['a'] == model.cfg.n_atom_types).all() and (out['c'] == model.cfg.n_charges).all() and (out['e'] == model.cfg.n_bond_types).all()
     assert torch.allclose(out['x'][:3].mean(0), torch.zeros(3), atol=1e-6) and torch.allclose(out['x'][3:].mean(0), torch.zeros(3), atol=1e-6)
+
+
+@pytest.mark.parametrize('case', [0, 1, 2, 3, 4])
+def test_emulated_ctmc_step_matches_reference_step(emu_lib, golden_dir, case):
+    """fm_ctmc_step (emulated kernels) on the reference's own step() fixture: bit-exact tokens and Euler update."""
+    from flowmol_amd.engine import Engine
+    from parity_util import ctmc_step_golden
+    cfg = presets.flowmol3()
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'ctmc_step.npz').items()}
+    res = ctmc_step_golden(eng, cfg, g, case)
+    assert all(v == 0 for v in res.values()), res

@@ -336,3 +336,275 @@ def test_shards_with_replicated_noise_equal_the_full_batch():
         assert torch.equal(part['a'], full['a'][nidx]) and torch.equal(part['c'], full['c'][nidx])
         assert torch.equal(part['e'], full['e'][pidx])
         torch.testing.assert_close(part['x'], full['x'][nidx], rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 2: edge cases by construction, bench-size parity, packaging / CLI content, RCCL
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', [0, 1, 2, 3, 4])
+def test_ctmc_step_reference_edge_cases_bit_exact(golden_dir, case):
+    """fm_ctmc_step on the fixture generated by the reference's OWN CTMCVectorField.step (fixed endpoint prediction;
+    ctmc_vector_field.py:287-461, ctmc_utils.py:4-34): molecules with h = 0, m = h and m = 0, a one-pair molecule, an exact-zero
+    probability, the hc = 0 branch and the last step -- by construction, not by chance.  Tokens, sampled endpoints and the
+    Euler update bit-exact."""
+    from parity_util import ctmc_step_golden
+    cfg, sd, eng, orc = engine_for('flowmol3')
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'ctmc_step.npz').items()}
+    res = ctmc_step_golden(eng, cfg, g, case, device='cuda:0')
+    _report(f'ctmc_step_golden[{case}]', res)
+    assert all(v == 0 for v in res.values()), res
+
+
+def test_misc_campbell_fixture_through_the_kernel(golden_dir):
+    """tests/golden/misc.npz ctmc.{0..3} (the reference's campbell_step on ALREADY tempered probabilities) through the HIP
+    kernel: the kernel always tempers (softmax(log p / T), as step() does), so the fixture's p is fed with T = 1, which is the
+    identity up to one rounding of log/exp -- decisions must still all agree (rows are the atoms of 2..9-atom molecules)."""
+    from flowmol_amd.engine import StepNoise, make_step_plan
+    cfg, sd, eng, orc = engine_for('flowmol3')
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'misc.npz').items()}
+    sizes = g['ctmc.sizes']                                   # rows per molecule: 4, 7, 1, 9, 5 (a 1-atom molecule has no pair)
+    eng.bind(sizes)
+    N, U = eng.N, eng.U
+    gen = torch.Generator().manual_seed(0)
+    for case in range(4):
+        hc, last, eta, alpha, dt = [float(v) for v in g[f'ctmc.{case}.params']]
+        last = bool(last)
+        sc = make_step_plan(250, eta, hc, 1.0).scalars[0]
+        one, a_i, dt_t = torch.ones(()), torch.tensor(alpha), torch.tensor(dt)
+        un = float(torch.clamp(dt_t * (one + eta * a_i) / (1 - a_i), min=0, max=1))
+        mk = float(torch.clamp(dt_t * eta, min=0, max=1))
+        for k in range(3):
+            sc.unmask_prob[k] = un
+            sc.mask_prob[k] = mk
+        sc.last_step = int(last)
+        sc.cat_temperature = 1.0
+        nz = StepNoise(q_a=g[f'ctmc.{case}.noise0'].cuda(), u1_a=g[f'ctmc.{case}.noise1'].cuda(),
+                       u2_a=None if last else g[f'ctmc.{case}.noise2'].cuda(),
+                       q_c=torch.rand(N, cfg.n_charges, generator=gen).cuda() + 0.1, u1_c=torch.rand(N, generator=gen).cuda(), u2_c=torch.rand(N, generator=gen).cuda(),
+                       q_e=torch.rand(U, cfg.n_bond_types, generator=gen).cuda() + 0.1, u1_e=torch.rand(U, generator=gen).cuda(), u2_e=torch.rand(U, generator=gen).cuda())
+        state = eng.make_state(torch.zeros(N, 3), g['ctmc.xt'], torch.zeros(N, dtype=torch.long), torch.zeros(U, dtype=torch.long))
+        dst = {'x': torch.zeros(N, 3).cuda(), 'a': g['ctmc.p'].cuda().contiguous(), 'c': torch.full((N, cfg.n_charges), 1.0 / cfg.n_charges).cuda(),
+               'e': torch.full((U, cfg.n_bond_types), 1.0 / cfg.n_bond_types).cuda()}
+        smp = {'a1': torch.zeros(N, dtype=torch.int32, device='cuda:0'), 'c1': torch.zeros(N, dtype=torch.int32, device='cuda:0'),
+               'e1': torch.zeros(U, dtype=torch.int32, device='cuda:0')}
+        eng.ctmc_step(state, dst, nz, sc, smp)
+        eng.synchronize()
+        assert torch.equal(state['a_t'].cpu().long(), g[f'ctmc.{case}.xt_new']), case
+        assert torch.equal(smp['a1'].cpu().long(), g[f'ctmc.{case}.x1']), case
+
+
+def test_c3_size_forward_matches_oracle_on_selected_molecules():
+    """BASELINE configs[2] at FULL batch size (1024 molecules x 47 atoms: 48,128 nodes, 2.2 M directed edges): one network
+    evaluation at t = 0.5 with a previous endpoint; molecules 0, 127 | 128 (either side of the first XCD tile-chunk boundary:
+    69,184 tiles / 8 XCDs = 8,648 tiles = 128 molecules), 600 and 1023 are compared with the oracle run on each molecule ALONE,
+    per stage (node state after every conv, positions after every update, the last edge features) and on the outputs --
+    norm-wise like the small-batch tests and element-wise (atol + rtol) on the outputs."""
+    cfg, sd, eng, orc = engine_for('flowmol3')
+    B, n = 1024, 47
+    u = n * (n - 1) // 2
+    n_atoms = torch.full((B,), n)
+    eng.bind(n_atoms)
+    N, U, E = eng.N, eng.U, eng.E
+    gen = torch.Generator().manual_seed(77)
+    from parity_util import rand_tokens, onehots
+    a, c, eu = rand_tokens(N, cfg.n_atom_types, 0.4, gen), rand_tokens(N, cfg.n_charges, 0.4, gen), rand_tokens(U, cfg.n_bond_types, 0.4, gen)
+    x = torch.randn(N, 3, generator=gen) * 1.5
+    prev = {'x': x + 0.3 * torch.randn(N, 3, generator=gen), 'a': torch.softmax(torch.randn(N, cfg.n_atom_types, generator=gen), -1),
+            'c': torch.softmax(torch.randn(N, cfg.n_charges, generator=gen), -1), 'e': torch.softmax(torch.randn(U, cfg.n_bond_types, generator=gen), -1)}
+    state = eng.make_state(x, a, c, eu)
+    V = cfg.n_vec_channels
+    sched = cfg.update_schedule()
+    last_upd = max(i for i in range(cfg.n_convs) if sched[i] >= 0)
+    bufs = {}
+    for i in range(cfg.n_convs):
+        bufs[f'conv{i}.s'] = torch.zeros(N, 256, device='cuda:0')
+        bufs[f'conv{i}.v'] = torch.zeros(N, 3, V, device='cuda:0')
+        if sched[i] >= 0:
+            bufs[f'upd{i}.x'] = torch.zeros(N, 3, device='cuda:0')
+    bufs[f'upd{last_upd}.ef'] = torch.zeros(E, 128, device='cuda:0')
+    out = eng.forward(state, 0.5, prev={k: v.cuda().contiguous() for k, v in prev.items()}, remove_com=True, taps=bufs)
+    eng.synchronize()
+    worst = {}
+    one = torch.tensor([n])
+    batch1 = cpu_ref.build_batch(one)
+    # internal (destination-major) index of the reference's edge (src, dst) inside one molecule
+    src, dst = batch1.src, batch1.dst
+    internal = dst * (n - 1) + (src - (src > dst).long())
+    for m in (0, 127, 128, 600, 1023):
+        ns_, ps_ = slice(m * n, (m + 1) * n), slice(m * u, (m + 1) * u)
+        a1h, c1h, e1h = onehots(cfg, batch1, a[ns_], c[ns_], eu[ps_])
+        orc.taps = {}
+        with torch.no_grad():
+            ref = orc.forward(batch1, x[ns_], a1h, c1h, e1h, torch.full((1,), 0.5), prev={'x': prev['x'][ns_], 'a': prev['a'][ns_], 'c': prev['c'][ns_], 'e': prev['e'][ps_]},
+                              apply_softmax=True, remove_com=True)
+        taps_o, orc.taps = orc.taps, None
+        for k, buf in bufs.items():
+            if k.endswith('.ef'):
+                got = buf[m * n * (n - 1):(m + 1) * n * (n - 1)].cpu()[internal]
+                want = taps_o[k]
+            elif k.endswith('.v'):
+                got, want = buf[ns_].cpu(), taps_o[k].transpose(1, 2)
+            else:
+                got, want = buf[ns_].cpu(), taps_o[k]
+            worst[k] = max(worst.get(k, 0.0), float((got - want).abs().max() / want.abs().max()))
+        for k in 'xac':
+            got = out[k][ns_].cpu()
+            worst['out.' + k] = max(worst.get('out.' + k, 0.0), float((got - ref[k]).abs().max() / ref[k].abs().max()))
+            torch.testing.assert_close(got, ref[k], rtol=2e-4, atol=2e-6)        # element-wise: small-magnitude channels too
+        got = out['e'][ps_].cpu()
+        worst['out.e'] = max(worst.get('out.e', 0.0), float((got - ref['e']).abs().max() / ref['e'].abs().max()))
+        torch.testing.assert_close(got, ref['e'], rtol=2e-4, atol=2e-6)
+    _report('c3_size_forward', worst)
+    bad = {k: v for k, v in worst.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
+    assert not bad, worst
+
+
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [5, 9, 12, 3, 2], 0.5, True), ('flowmol3', [70, 2, 47, 130], 0.3, True),
+                                               ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False)])
+def test_forward_outputs_elementwise(name, sizes, t, prev):
+    """Element-wise (atol + rtol) agreement of the final outputs with the oracle: the norm-wise stage tolerance does not
+    constrain small-magnitude entries individually (probabilities near 0, coordinates near the origin)."""
+    cfg, sd, eng, orc = engine_for(name)
+    errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev, taps=False)
+    for k in 'xace':
+        torch.testing.assert_close(out[k].cpu(), ref[k], rtol=2e-4, atol=2e-6)
+
+
+def _oracle_run_with_tape(cfg, sd, n_atoms, T, seed):
+    """Oracle trajectory + its recorded RNG tape + prior, for driving the PUBLIC API with identical draws."""
+    orc = cpu_ref.OracleVF(cfg, sd)
+    batch = cpu_ref.build_batch(n_atoms)
+    torch.manual_seed(seed)
+    prior = orc.sample_prior(batch)
+    rec = cpu_ref.RecordingNoise()
+    with torch.no_grad():
+        ref = orc.integrate(batch, prior, T, noise=rec)
+    return batch, prior, rec.tape, ref
+
+
+def _tape_noise_fn(tape, device='cuda:0'):
+    from flowmol_amd.engine import StepNoise
+    pos = [0]
+
+    def noise_for_step(i, last):
+        nz, pos[0] = StepNoise.from_tape(tape, pos[0], last, device)
+        return nz
+    return noise_for_step
+
+
+def test_sampled_molecule_fields_of_a_device_run_match_oracle():
+    """SURVEY §8 a13 on the GPU: model.sample() (HIP integration + packaging) driven with the oracle's prior and RNG tape ->
+    every SampledMolecule field equals the oracle's extract_moldata (pinned to the reference's extract_moldata_from_graph by
+    tests/golden/moldata.npz) of the oracle's own final state: symbols, charges, bonds after fake-atom removal; positions 1e-4."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    cfg = model.cfg
+    sd = weights.synth_state_dict(cfg, 0)
+    n_atoms = torch.tensor([9, 14, 5, 21, 12, 7])
+    T = 12
+    batch, prior, tape, ref = _oracle_run_with_tape(cfg, sd, n_atoms, T, seed=31)
+    mols = model.sample(n_atoms, n_timesteps=T, prior={'x_0': prior['x_0'], 'a_0': prior['a_0'], 'c_0': prior['c_0'], 'e_0': prior['e_0'],
+                                                       'fake_atoms': cfg.fake_atoms}, _noise_for_step=_tape_noise_fn(tape))
+    assert len(mols) == len(n_atoms)
+    no = eo = 0
+    n_fake = 0
+    for m, n in zip(mols, n_atoms.tolist()):
+        e_n = n * (n - 1)
+        pos, sym, chg, bt, bs, bd = cpu_ref.extract_moldata(ref['x_1'][no:no + n], ref['a_1'][no:no + n], ref['c_1'][no:no + n], ref['e_1'][eo:eo + e_n], n,
+                                                            cfg.atom_type_map, cfg.fake_atoms, cfg.n_bond_types)
+        no += n; eo += e_n
+        assert m.atom_types == sym and torch.equal(m.atom_charges, chg)
+        assert torch.equal(m.bond_types, bt) and torch.equal(m.bond_src_idxs, bs) and torch.equal(m.bond_dst_idxs, bd)
+        assert m.num_atoms == len(sym)
+        torch.testing.assert_close(m.positions, pos, rtol=1e-4, atol=1e-4)
+        assert torch.equal(m.valencies, cpu_ref.compute_valencies(len(sym), bt, bs, bd))
+        n_fake += n - len(sym)
+    _report('sampled_molecule_fields', {'molecules': len(mols), 'fake_atoms_removed': n_fake})
+
+
+def test_cli_sdf_content_matches_oracle_tokens(tmp_path, monkeypatch):
+    """the CLI on the GPU (seeded, sizes drawn like test.py does), driven with the oracle's RNG tape, writes an SDF whose
+    every line equals the blocks derived from the ORACLE's final tokens (atoms, charge column, bond lines, M  CHG); coordinates
+    agree to the 4 printed decimals +- 1e-4.  The writer itself is pinned by tests/golden/cli_expected_blocks.sdf."""
+    import flowmol_amd as flowmol
+    from flowmol_amd import cli
+    from flowmol_amd.molecule import mol_block
+    seed, n_mols, T = 4, 5, 10
+    args = cli.parse_args(['--preset', 'qm9', '--n_mols', str(n_mols), '--n_timesteps', str(T), '--max_batch_size', '8', '--seed', str(seed),
+                           '--output_file', str(tmp_path / 'out.sdf'), '--baseline_comparison'])
+    probe = flowmol.FlowMol.from_preset('qm9')
+    torch.manual_seed(seed)
+    n_atoms = probe.sample_n_atoms(n_mols)                       # what the CLI will draw first from the same seed
+    cfg = probe.cfg
+    sd = weights.synth_state_dict(cfg, 0)
+    batch, prior, tape, ref = _oracle_run_with_tape(cfg, sd, n_atoms, T, seed=99)
+    orig = flowmol.FlowMol.sample
+
+    def driven(self, n_at, **kw):
+        assert torch.equal(torch.as_tensor(n_at), n_atoms)
+        return orig(self, n_at, prior={**{k: prior[k] for k in ('x_0', 'a_0', 'c_0', 'e_0')}, 'fake_atoms': cfg.fake_atoms},
+                    _noise_for_step=_tape_noise_fn(tape), **kw)
+    monkeypatch.setattr(flowmol.FlowMol, 'sample', driven)
+    mols, t_s = cli.run(args)
+    import pickle
+    items, sampling_time = pickle.load(open(tmp_path / 'out.sdf', 'rb'))      # --baseline_comparison: (molecules, sampling_time) pickle
+    assert len(items) == n_mols and sampling_time > 0 and items[0]['atom_types'] == mols[0].atom_types
+    args2 = cli.parse_args(['--preset', 'qm9', '--n_mols', str(n_mols), '--n_timesteps', str(T), '--max_batch_size', '8', '--seed', str(seed),
+                            '--output_file', str(tmp_path / 'out2.sdf')])
+    cli.run(args2)
+    got = (tmp_path / 'out2.sdf').read_text().split('$$$$\n')
+    assert len(got) == n_mols + 1 and got[-1] == ''
+    no = eo = 0
+    for blk, n in zip(got, n_atoms.tolist()):
+        e_n = n * (n - 1)
+        pos, sym, chg, bt, bs, bd = cpu_ref.extract_moldata(ref['x_1'][no:no + n], ref['a_1'][no:no + n], ref['c_1'][no:no + n], ref['e_1'][eo:eo + e_n], n,
+                                                            cfg.atom_type_map, cfg.fake_atoms, cfg.n_bond_types)
+        no += n; eo += e_n
+        want = mol_block(pos, sym, chg, bs, bd, bt).splitlines()
+        have = blk.splitlines()
+        assert len(have) == len(want)
+        for lw, lh in zip(want, have):
+            if lw == lh:
+                continue
+            # an atom line whose coordinates differ in the last printed digit: everything after the coordinates must be identical
+            assert lw[30:] == lh[30:] and len(lw) == len(lh), (lw, lh)
+            for k in range(3):
+                assert abs(float(lw[10 * k:10 * k + 10]) - float(lh[10 * k:10 * k + 10])) <= 1.0001e-4, (lw, lh)
+
+
+def test_rccl_one_rank_group_gather_and_cli(tmp_path, monkeypatch):
+    """First execution of the RCCL code path (backend 'nccl' on one MI355X, world size 1): the single all_gather_into_tensor of
+    shard.gather_results on DEVICE tensors holding a real packed result, FlowMol.sample_distributed against sample() with the
+    same seed, and the CLI launched torchrun-style as one rank."""
+    import socket
+    import torch.distributed as dist
+    import flowmol_amd as flowmol
+    from flowmol_amd import cli, shard
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    for k, v in {'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '1'}.items():
+        monkeypatch.setenv(k, v)
+    try:
+        args = cli.parse_args(['--preset', 'qm9', '--n_mols', '7', '--n_timesteps', '6', '--max_batch_size', '4', '--seed', '2',
+                               '--output_file', str(tmp_path / 'd.sdf')])
+        mols, _ = cli.run(args)                                   # initialises the one-rank nccl group, shards, gathers, writes
+        assert dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+        assert len(mols) == 7 and (tmp_path / 'd.sdf').read_text().count('$$$$') == 7
+        model = flowmol.FlowMol.from_preset('qm9').cuda().eval()
+        n_atoms = torch.tensor([9, 4, 17, 6, 12])
+        torch.manual_seed(8)
+        full, _ = model.sample_distributed(n_atoms, n_timesteps=5, return_tensors='device')
+        assert all(v.is_cuda for v in full.values())              # results stay in HBM until packaging
+        torch.manual_seed(8)
+        single, _ = model.sample(n_atoms, n_timesteps=5, return_tensors=True)
+        for k in 'xace':
+            assert torch.equal(full[k].cpu(), single[k])          # one rank owns everything: identical draws, identical result
+        # the collective itself on a packed device result with odd payload size
+        local = {k: v.clone() for k, v in full.items()}
+        out = shard.gather_results(local, n_atoms, [torch.arange(5)])
+        for k in 'xace':
+            assert out[k].is_cuda and torch.equal(out[k], full[k])
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()

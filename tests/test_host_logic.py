@@ -102,7 +102,8 @@ def test_checkpoint_reader_roundtrip(tmp_path):
     sd = {'vector_field.' + k: v for k, v in weights.synth_state_dict(cfg, 0).items()}
     hp = {'atom_type_map': presets.GEOM_ATOMS, 'n_atoms_hist_file': 'data/geom_full_kekulized/train_data_n_atoms_histogram.pt',
           'marginal_dists_file': 'x', 'n_atom_charges': 6, 'parameterization': 'ctmc', 'fake_atom_p': 0.3, 'default_n_timesteps': 250,
-          'prior_config': {k: {'type': 'ctmc'} for k in 'ace'},
+          'prior_config': {**{k: {'type': 'ctmc'} for k in 'ace'}, 'x': {'type': 'centered-normal', 'kwargs': {'std': 1.0}}},
+          'interpolant_scheduler_config': {'schedule_type': {k: 'linear' for k in 'xace'}},
           'vector_field_config': dict(self_conditioning=True, stochasticity=30.0, high_confidence_threshold=0.9, n_vec_channels=32,
                                       update_edge_w_distance=True, n_hidden_scalars=256, n_hidden_edge_feats=128, s_message_dim=None,
                                       v_message_dim=None, n_expansion_gvps=3, attention=False, n_heads=32, n_recycles=1,
@@ -119,6 +120,17 @@ def test_checkpoint_reader_roundtrip(tmp_path):
     assert model.n_atom_types == 11 and model.default_n_timesteps == 250
     with pytest.raises(RuntimeError, match='MI355X only'):
         model.sample(torch.tensor([3]))            # no silent CPU path
+    # configurations the HIP path does not reproduce are rejected at load time, with the REFERENCE's defaults for missing keys
+    from flowmol_amd.model import check_reference_hparams
+    for bad in ({**hp, 'interpolant_scheduler_config': {'schedule_type': 'tanh'}},                # not a reference schedule
+                {**hp, 'prior_config': {**hp['prior_config'], 'x': {'type': 'gaussian'}}},       # would be centred silently
+                {**hp, 'exclude_charges': True},
+                {**hp, 'parameterization': 'dirichlet'},
+                {**hp, 'vector_field_config': {**hp['vector_field_config'], 'attention': True}},
+                {**hp, 'vector_field_config': {**hp['vector_field_config'], 'made_up_key': 1}}):
+        with pytest.raises((NotImplementedError, ValueError)):
+            check_reference_hparams(bad)
+            from_reference_hparams(bad)
     with pytest.raises(FileNotFoundError):
         load_pretrained('flowmol3')
     with pytest.raises(ValueError):
@@ -160,3 +172,49 @@ def test_rigid_alignment_recovers_rotation():
         q[:, 0] = -q[:, 0]
     y = x @ q.T + torch.tensor([1.0, -2.0, 0.5])
     assert torch.allclose(rigid_alignment(x, y), y, atol=1e-5)
+
+
+def test_sampled_molecule_matches_reference_extraction(golden_dir):
+    """flowmol_amd.molecule.SampledMolecule (token tensors in, the product's packaging) against the
+    reference's own extract_moldata_from_graph outputs (tests/golden/moldata.npz): positions, symbols, charges, bond
+    list after fake-atom removal, num_atoms."""
+    from test_oracle_golden import _moldata_cases
+    from flowmol_amd.molecule import SampledMolecule
+    for k in _moldata_cases(golden_dir):
+        m = SampledMolecule(k['x'], k['a'].int(), k['c'].int(), k['e'].int(), k['base'], fake_atoms=k['fake'], ctmc_mol=True,
+                            explicit_aromaticity=k['arom'])
+        assert torch.equal(m.positions, k['pos']) and m.atom_types == k['sym'] and torch.equal(m.atom_charges, k['chg'])
+        assert torch.equal(m.bond_types, k['bt']) and torch.equal(m.bond_src_idxs, k['bs']) and torch.equal(m.bond_dst_idxs, k['bd'])
+        assert m.num_atoms == len(k['sym']) and m.atom_type_map == k['amap']
+
+
+def cli_block_token_molecules():
+    """Token form of the three hand-derived molecules of tests/golden/cli_expected_blocks.sdf (flowmol3 token tables:
+    atoms C,H,N,O,F,P,S,Cl,Br,I + fake 'Sn' (10) + mask (11); charge token = charge + 2; bond token 4 = mask):
+    (1) methane with a FAKE atom bonded to C and to an H -- the atom and both bonds disappear, the remaining atoms keep their order;
+    (2) ammonium + hydroxide: formal charges +1 / -1 -> charge column 3 / 5 and one 'M  CHG' line;
+    (3) formaldehyde with a MASKED H..H pair and explicit no-bond tokens: only the three real bonds are written."""
+    def pairs(n, bonds):
+        e = torch.zeros(n * (n - 1) // 2, dtype=torch.int32)
+        for (i, j), t in bonds.items():
+            e[i * (2 * n - i - 1) // 2 + (j - i - 1)] = t
+        return e
+    m1 = dict(x=torch.tensor([[0, 0, 0], [9.5, 9.5, 9.5], [.63, .63, .63], [-.63, -.63, .63], [-.63, .63, -.63], [.63, -.63, -.63]]),
+              a=torch.tensor([0, 10, 1, 1, 1, 1], dtype=torch.int32), c=torch.tensor([2, 2, 2, 2, 2, 2], dtype=torch.int32),
+              e=pairs(6, {(0, 1): 1, (1, 2): 2, (0, 2): 1, (0, 3): 1, (0, 4): 1, (0, 5): 1}))
+    m2 = dict(x=torch.tensor([[0, 0, 0], [.59, .59, .59], [-.59, -.59, .59], [-.59, .59, -.59], [.59, -.59, -.59], [3., 0, 0], [3.96, 0, .12349]]),
+              a=torch.tensor([2, 1, 1, 1, 1, 3, 1], dtype=torch.int32), c=torch.tensor([3, 2, 2, 2, 2, 1, 2], dtype=torch.int32),
+              e=pairs(7, {(0, 1): 1, (0, 2): 1, (0, 3): 1, (0, 4): 1, (5, 6): 1}))
+    m3 = dict(x=torch.tensor([[0, 0, 0], [1.21, 0, 0], [-.55, .94, 0], [-.55, -.94, -.00006]]),
+              a=torch.tensor([0, 3, 1, 1], dtype=torch.int32), c=torch.tensor([2, 2, 2, 2], dtype=torch.int32),
+              e=pairs(4, {(0, 1): 2, (0, 2): 1, (0, 3): 1, (2, 3): 4}))
+    return [m1, m2, m3]
+
+
+def test_sdf_writer_reproduces_hand_derived_blocks(golden_dir, tmp_path):
+    """the RDKit-free V2000 writer against hand-derived mol blocks (fake atom dropped + bonds re-indexed, masked
+    bond = no bond, formal charges in the atom column and in `M  CHG`), through the same write_sdf the CLI uses."""
+    from flowmol_amd import cli
+    mols = [SampledMolecule(m['x'].float(), m['a'], m['c'], m['e'], presets.GEOM_ATOMS, fake_atoms=True) for m in cli_block_token_molecules()]
+    cli.write_sdf(tmp_path / 'o.sdf', [m.to_sdf_block() for m in mols])
+    assert (tmp_path / 'o.sdf').read_text() == (golden_dir / 'cli_expected_blocks.sdf').read_text()

@@ -178,3 +178,71 @@ def test_stability_restatement_matches_reference(golden_dir, tag, dataset, arom,
         val = cpu_ref.compute_valencies(len(sym), bt, bs, bd, arom_dependent=arom)
         n_stable, mol_stable = cpu_ref.check_stability(sym, val, chg, table, explicit_aromaticity=arom)
         assert [n_stable, int(mol_stable), len(sym)] == g[f'{tag}.expect'][i].tolist()
+
+
+def _moldata_cases(golden_dir):
+    """(tag, arom, fake, per-molecule inputs and the reference's extract_moldata_from_graph outputs) of tests/golden/moldata.npz."""
+    g = _load(golden_dir, 'moldata.npz')
+    st = _load(golden_dir, 'stability.npz')
+    base = ['C', 'H', 'N', 'O', 'F', 'P', 'S', 'Cl', 'Br', 'I']
+    for tag, arom, fake in (('kek', False, True), ('arom', True, False)):
+        amap = base + (['Sn'] if fake else []) + ['Se']
+        no = po = ao = bo = 0
+        for i, n in enumerate(st[f'{tag}.n_atoms'].tolist()):
+            u = n * (n - 1) // 2
+            na, nbd = g[f'{tag}.counts'][i].tolist()
+            yield dict(tag=tag, arom=arom, fake=fake, n=n, base=base, amap=amap,
+                       x=g[f'{tag}.x'][no:no + n], a=st[f'{tag}.a'][no:no + n], c=st[f'{tag}.c'][no:no + n], e=st[f'{tag}.e'][po:po + u],
+                       pos=g[f'{tag}.pos'][ao:ao + na], sym=[amap[int(k)] for k in g[f'{tag}.sym'][ao:ao + na]], chg=g[f'{tag}.chg'][ao:ao + na],
+                       bt=g[f'{tag}.bt'][bo:bo + nbd], bs=g[f'{tag}.bs'][bo:bo + nbd], bd=g[f'{tag}.bd'][bo:bo + nbd])
+            no += n; po += u; ao += na; bo += nbd
+
+
+def test_extract_moldata_matches_reference(golden_dir):
+    """the oracle's result extraction vs the reference's own extract_moldata_from_graph
+    (molecule_builder.py:217-265, run by oracle/make_golden.py:gen_moldata) -- fake atoms dropped and bonds re-indexed,
+    masked bonds = no bond, charge = index - 2, upper-triangle bonds only."""
+    import torch.nn.functional as F
+    n_cases = 0
+    for k in _moldata_cases(golden_dir):
+        nb = 5 if k['arom'] else 4
+        pos, sym, chg, bt, bs, bd = cpu_ref.extract_moldata(k['x'], F.one_hot(k['a'], len(k['amap'])).float(), F.one_hot(k['c'], 6).float(),
+                                                            torch.cat([F.one_hot(k['e'], nb + 1).float()] * 2), k['n'], k['base'], k['fake'], nb)
+        assert torch.equal(pos, k['pos']) and sym == k['sym'] and torch.equal(chg, k['chg'])
+        assert torch.equal(bt, k['bt']) and torch.equal(bs, k['bs']) and torch.equal(bd, k['bd'])
+        n_cases += 1
+    assert n_cases == 16
+
+
+@pytest.mark.parametrize('case', [0, 1, 2, 3, 4])
+def test_ctmc_step_matches_reference_step(golden_dir, case):
+    """The oracle's step (Euler + tempering + campbell_step + purity sampling) against the reference's own
+    CTMCVectorField.step run with a fixed endpoint prediction (tests/golden/ctmc_step.npz): h = 0, m = h, m = 0 molecules,
+    a one-pair molecule, an exact-zero probability, hc = 0 branch, last step -- bit-exact tokens and coordinates."""
+    g = _load(golden_dir, 'ctmc_step.npz')
+    cfg = presets.flowmol3()
+    hc, last, eta, s_idx, T = [float(v) for v in g[f'{case}.params']]
+    last, s_idx, T = bool(last), int(s_idx), int(T)
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    dst = {k: g[f'{case}.dst.{k}'] for k in 'xace'}
+
+    class FixedDst(cpu_ref.OracleVF):
+        def forward(self, *a_, **k_):
+            return dst
+    orc = FixedDst(cfg, weights.synth_state_dict(cfg, 0))
+    import torch.nn.functional as F
+    m = batch.upper_edge_mask
+    e1h = torch.zeros(batch.E, cfg.n_bond_types + 1)
+    e1h[m] = F.one_hot(g[f'{case}.e_t'], cfg.n_bond_types + 1).float()
+    e1h[~m] = F.one_hot(g[f'{case}.e_t'], cfg.n_bond_types + 1).float()
+    state = {'x_t': g[f'{case}.x_t'], 'a_t': F.one_hot(g[f'{case}.a_t'], cfg.n_atom_types + 1).float(),
+             'c_t': F.one_hot(g[f'{case}.c_t'], cfg.n_charges + 1).float(), 'e_t': e1h}
+    t = torch.linspace(0, 1, T)
+    al, alp = cpu_ref.alpha_tables(t)
+    tape = [g[f'{case}.noise{i}'] for i in range(6 if last else 9)]
+    new, _ = orc.step(batch, state, t[s_idx], t[s_idx - 1], al[s_idx - 1], alp[s_idx - 1], prev=None, eta=eta, hc_thresh=hc,
+                      last_step=last, noise=cpu_ref.TapeNoise(tape))
+    assert torch.equal(new['x_t'], g[f'{case}.x_new'])
+    for k in 'ac':
+        assert torch.equal(new[f'{k}_t'].argmax(-1), g[f'{case}.{k}_new']) and torch.equal(new[f'{k}_1_pred'].argmax(-1), g[f'{case}.{k}_1_pred'])
+    assert torch.equal(new['e_t'][m].argmax(-1), g[f'{case}.e_new']) and torch.equal(new['e_1_pred'][m].argmax(-1), g[f'{case}.e_1_pred'])
