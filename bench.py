@@ -285,8 +285,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         mine = torch.tensor([own_elapsed * 1e3 / args.steps, gather_ms], device=dev, dtype=torch.float64)
-        every = torch.empty(world, 2, device=dev, dtype=torch.float64)
-        dist.all_gather_into_tensor(every, mine)
+        flat = torch.empty(world * 2, device=dev, dtype=torch.float64)       # concatenated form: accepted by every backend
+        dist.all_gather_into_tensor(flat, mine)
+        every = flat.view(world, 2)
         per_rank_ms = every[:, 0].tolist()
         gather_ms = float(every[:, 1].max())
     ms_per_step = elapsed * 1e3 / args.steps

@@ -59,6 +59,13 @@ __device__ unsigned long long fm_tlog[64];
 #define FM_MARKB(k) ((void)0)
 #endif
 
+// Dev-only timing ablations (-DFM_ABLATE=<bit mask>; results are garbage, only the kernel time is meaningful): which part of
+// the GVP kernels costs what.  1: no SiLU math, 2: no gate GEMM / gating, 4: no vector path ([Wh|Wcp] GEMM, cross products,
+// norms, Wu GEMM), 8: no aggregation epilogue, 16: no prologue gathers, 32: no scalar-GEMM MFMAs (tools/ablate.sh, profiles/r02a_*).
+#ifndef FM_ABLATE
+#define FM_ABLATE 0
+#endif
+
 #define FM_TM 64          // rows per workgroup tile of the non-GVP kernels (MLPs, edge update, projections)
 #define FM_THREADS 512    // threads per workgroup of the non-GVP kernels (8 waves)
 #define FM_LDX 300        // scalar tile leading dim: >= 296, (300/4)=75 odd
@@ -351,7 +358,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bias_s[j] = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
 
-    if (!FIRST) {
+    if (!FIRST && !(FM_ABLATE & 4)) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
         fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * TM / 16, V / 8, w.Wv1, (V + 16) / 16,
                             [&](int row, int col, float v) { Vh[row * T::LDVH + col] = v; });
@@ -363,6 +370,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // only its own columns) and their norms into X; (b) all threads compute the norms sh of the H plain hidden
     // channels (gvp.py:116, _norm_no_nan clamp) -> X[:, SOFF..SOFF+H) and clear the K padding of X.
     static_assert(TM * 4 <= NTH, "cross-product phase needs 4 threads per row");
+    if (!(FM_ABLATE & 4)) {
     if (tid < TM * 4) {
         const int r = tid >> 2, p = tid & 3;
         float a[3], b[3];
@@ -403,6 +411,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // Vu = Vh_full * Wu -> Vin (the input vectors are dead by now)
     fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * TM / 16, T::KU / 8, w.Wu, VOP / 16,
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
+    }
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     {
         // The accumulators start at bias (+ `pre` for the FIRST GVP of an edge tile: the hoisted W_s*s[src] term, requested
@@ -418,7 +427,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = FIRST ? pre[i][j][r] + bias : bias;
         }
         FM_MARKB(2);
-        fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
+        if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
@@ -428,7 +437,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * FM_LDX + j * 16] = fm_silu(acc[i][j][r]);
+                for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * FM_LDX + j * 16] = (FM_ABLATE & 1) ? acc[i][j][r] : fm_silu(acc[i][j][r]);
         __syncthreads();
     }
     FM_MARKB(5);
@@ -439,6 +448,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int NJ = (TM / 16) * (VOP / 16);
     constexpr int KS = (NW >= 2 * NJ) ? 2 : 1;
     float* G2 = Vh;
+    if (FM_ABLATE & 2) return;
     for (int jw = wave; jw < NJ * KS; jw += NW) {
         const int job = jw % NJ, half = jw / NJ;
         const int m0 = job / (VOP / 16), n0 = job % (VOP / 16);

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         const int left = a.b.E - e0;                         // rows of this tile that exist (ragged last tile: the range check zero-fills)
         const auto rs = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
 #pragma unroll
-        for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs, tid * 16 + k * NTH * 16, 0);
+        for (int k = 0; k < NEF; ++k) efv[k] = (FM_ABLATE & 16) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fm_buf_f32x4(rs, tid * 16 + k * NTH * 16, 0);
     }
     // (B) endpoints and geometry of the tile's edges
     if (tid < TM) {
@@ -444,7 +444,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     //     L2 latency overlaps the fill below and the first phases of the GVP (VMEM returns in order, so a request
     //     placed right before the GEMM would stall the GEMM's first weight fragments behind it)
     float pre[TM / 16][1024 / NTH][4];
-    fm_gather_pre<TM, NTH>(pre, a.Ps, a.b.N, m_src);
+    if (!(FM_ABLATE & 16)) fm_gather_pre<TM, NTH>(pre, a.Ps, a.b.N, m_src);
+    else { for (auto& p1 : pre) for (auto& p2 : p1) for (auto& p3 : p2) p3 = 0.25f; }
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):
     //     a branchy load-use-store loop serialises one L2 round trip per iteration (profiles/r01d: 37k cycles here).
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         for (int p_ = 0; p_ < NP; ++p_) {
             const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
             const int sidx = (NCH % QN == 0 || ch < NCH) ? m_src[r] : -1;
-            pv[p_] = fm_buf_f32(rs, sidx >= 0 ? sidx * (3 * (V + 16) * 4) + j * 4 : FM_BUF_OOB, (c * (V + 16) + cb * 16) * 4);
+            pv[p_] = (FM_ABLATE & 16) ? 0.5f : fm_buf_f32(rs, sidx >= 0 ? sidx * (3 * (V + 16) * 4) + j * 4 : FM_BUF_OOB, (c * (V + 16) + cb * 16) * 4);
             w0v[p_] = a.w0[cb * 16 + j];
         }
 #pragma unroll
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // the segment logic runs on scalar compares/branches; a wave holds either scalar or vector columns, so the only
     // per-lane work is the LDS reads, the adds and the (rare) stores.
     static_assert(NTH == 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
-    {
+    if (!(FM_ABLATE & 8)) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int myd = m_dst[lane % TM], mypc = m_piece[lane % TM];
         int dd[TM + 1], pc[TM];
