@@ -302,8 +302,7 @@ def main():
     torch.cuda.synchronize(dev)
     kern = {}
     for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node',
-              'edge_head', 'node_head', 'ctmc', 'ctmc_pass1', 'ctmc_pass2', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step',
-              'heads_post'):
+              'edge_head', 'node_head', 'sc', 'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step'):
         ms, cnt = eng.profile_get(k)
         if cnt:
             kern[k] = {'avg_us': ms * 1e3 / cnt, 'launches_per_step': cnt / 2}

@@ -11,8 +11,9 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FM_ABI_VERSION = 2
+FM_ABI_VERSION = 3
 FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
+FM_NOISE_TENSORS, FM_NOISE_PHILOX = 0, 1
 FM_MAX_CONVS = 16
 
 LIB_NAME = 'libflowmol_hip.so'
@@ -27,6 +28,7 @@ class fm_config(C.Structure):
         ('update_after', C.c_int32 * FM_MAX_CONVS), ('self_conditioning', C.c_int32),
         ('time_embedding_dim', C.c_int32), ('a_token_dim', C.c_int32), ('c_token_dim', C.c_int32),
         ('e_token_dim', C.c_int32), ('rbf_dmax', C.c_float), ('msg_z', C.c_float),
+        ('s_dst_feats', C.c_int32), ('v_dst_feats', C.c_int32),
     ]
 
 
@@ -50,7 +52,8 @@ class fm_step_scalars(C.Structure):
     _fields_ = [('t', C.c_float), ('dt', C.c_float), ('x_coef', C.c_float), ('unmask_prob', C.c_float * 3),
                 ('mask_prob', C.c_float * 3), ('hc_thresh', C.c_float), ('cat_temperature', C.c_float),
                 ('last_step', C.c_int32), ('x_scale', C.c_float), ('dfm_type', C.c_int32), ('gat_cf', C.c_float * 3),
-                ('gat_cb', C.c_float * 3), ('gat_fw', C.c_float), ('gat_bw', C.c_float)]
+                ('gat_cb', C.c_float * 3), ('gat_fw', C.c_float), ('gat_bw', C.c_float),
+                ('noise_mode', C.c_int32), ('step_index', C.c_int32), ('philox_seed_lo', C.c_uint32), ('philox_seed_hi', C.c_uint32)]
 
 
 class fm_sampled(C.Structure):
@@ -74,6 +77,8 @@ _EXPORTS = {
     'fm_workspace_bytes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     'fm_batch_bind': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     'fm_remove_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fm_set_molecule_ids': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fm_prior_philox': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     'fm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.c_void_p, C.POINTER(fm_dst), C.c_int, C.c_int,
                              C.POINTER(fm_dst)]),
     'fm_ctmc_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.POINTER(fm_dst), C.POINTER(fm_step_noise),

@@ -42,7 +42,8 @@ class VFConfig:
     c_token_dim: int = 64
     e_token_dim: int = 64
     self_conditioning: bool = True
-    use_dst_feats: bool = False
+    use_dst_feats: bool = False                         # GVPConv: reduced destination-node features join the message inputs (gvp.py:300-316,527-537)
+    dst_feat_msg_reduction_factor: float = 4
     n_recycles: int = 1
     # ---- CTMC integrator defaults (ctmc_vector_field.py:23-34)
     stochasticity: float = 30.0
@@ -87,6 +88,15 @@ class VFConfig:
         return a, c, e
 
     @property
+    def s_dst_feats(self) -> int:
+        """Scalars of the reduced destination-node message features (gvp.py:302)."""
+        return int(self.n_hidden_scalars / self.dst_feat_msg_reduction_factor) if self.use_dst_feats else 0
+
+    @property
+    def v_dst_feats(self) -> int:
+        return int(self.n_vec_channels / self.dst_feat_msg_reduction_factor) if self.use_dst_feats else 0
+
+    @property
     def msg_z(self) -> float:
         """Divisor applied to the aggregated messages (gvp.py:495-501)."""
         if isinstance(self.message_norm, str):
@@ -111,16 +121,20 @@ class VFConfig:
         return out
 
     def validate(self) -> "VFConfig":
-        if self.n_hidden_scalars != 256 or self.n_hidden_edge_feats != 128 or self.rbf_dim != 32:
+        # tiles are 256 scalar / 128 edge-feature columns wide; narrower models (configs/dev.yml: 64 / 64) are zero-padded at fm_create
+        if not (8 <= self.n_hidden_scalars <= 256 and 8 <= self.n_hidden_edge_feats <= 128) or self.rbf_dim != 32:
             raise NotImplementedError(
-                f"HIP kernels are built for S=256,F=128,R=32; got S={self.n_hidden_scalars} "
+                f"HIP kernels hold up to S=256 scalars and F=128 edge features (R=32); got S={self.n_hidden_scalars} "
                 f"F={self.n_hidden_edge_feats} R={self.rbf_dim}")
         if self.n_vec_channels not in (16, 32):
             raise NotImplementedError(f"n_vec_channels must be 16 or 32, got {self.n_vec_channels}")
         if self.n_cp_feats != 4 or self.n_message_gvps != 3 or self.n_update_gvps != 3:
             raise NotImplementedError("only n_cp_feats=4 and 3/3 message/update GVPs are implemented")
         if self.use_dst_feats:
-            raise NotImplementedError("use_dst_feats (configs/dev.yml) is outside the round-1 hot path")
+            if self.dst_feat_msg_reduction_factor == 1:
+                raise NotImplementedError("use_dst_feats with dst_feat_msg_reduction_factor == 1 (no projection GVP) is not implemented")
+            if not (1 <= self.v_dst_feats <= 8 and 1 <= self.s_dst_feats <= 256):
+                raise NotImplementedError(f"destination-feature widths out of range: v={self.v_dst_feats} s={self.s_dst_feats}")
         if self.n_recycles != 1:
             raise NotImplementedError("n_recycles>1 is never enabled by a shipped config")
         if not self.update_edge_w_distance:
@@ -161,7 +175,7 @@ def from_reference_hparams(hp: dict) -> VFConfig:
         n_molecule_updates=2, convs_per_update=2, n_message_gvps=3, n_update_gvps=3,
         separate_mol_updaters=False, message_norm=100, update_edge_w_distance=False,
         rbf_dmax=20, rbf_dim=16, time_embedding_dim=1, a_token_dim=0, c_token_dim=0,
-        e_token_dim=0, self_conditioning=False, use_dst_feats=False, n_recycles=1,
+        e_token_dim=0, self_conditioning=False, use_dst_feats=False, dst_feat_msg_reduction_factor=4, n_recycles=1,
         stochasticity=0.0, high_confidence_threshold=0.0, dfm_type='campbell',
     )
     for k, dflt in ref_defaults.items():

@@ -321,11 +321,17 @@ struct FmGvpW {
 // LDS tile geometry shared by every GVP-based kernel; TM = rows (edges or nodes) per workgroup tile:
 // 64 -> 154 KB of LDS, one workgroup per CU; 32 -> 77 KB, two workgroups per CU whose MFMA and
 // VALU/LDS/gather phases overlap each other.
-template <int V, int TM>
+// HX = extra hidden vector channels of the FIRST edge-message GVP: the reduced destination-node vectors of
+// use_dst_feats models (gvp.py:527-529; V/4 with configs/dev.yml), 0 otherwise.
+template <int V, int TM, int HX = 0>
 struct FmGvpTile {
+    static constexpr int H0 = V + 1 + HX;                     // hidden vectors of the first edge GVP: [x_diff | v_src | v_dst_msg]
+    static constexpr int KU0 = (H0 + 4 + 7) / 8 * 8;          // K of its Wu GEMM: hidden + 4 cross products, padded
+    static constexpr int PVW = (KU0 + 8 + 15) / 16 * 16;      // its hidden-vector row: [hidden | cp | 0 .. KU0) | Vcp sources (8) | 0]
     static constexpr int LDVI = V + 4;       // Vin  [3*TM][LDVI]   (36 | 20: /4 odd)
-    static constexpr int LDVH = V + 20;      // Vh   [3*TM][LDVH]   (52 | 36: /4 odd)
-    static constexpr int KU = V + 8;         // K of the Wu GEMM    (hidden h + 4 cp (+pad) <= V+8)
+    static constexpr int LDVH = PVW + 4;     // Vh   [3*TM][LDVH]   (HX = 0: V+20 = 52 | 36; /4 odd in every instance)
+    static constexpr int KU = V + 8;         // K of the other GVPs' Wu GEMM (hidden V + 4 cp (+pad))
+    static_assert(((PVW + 4) / 4) % 2 == 1 && PVW >= V + 16, "Vh leading dimension must keep ds_read_b64 conflict-free");
     static constexpr int X_FLOATS = TM * FM_LDX;
     static constexpr int VIN_FLOATS = 3 * TM * LDVI;
     static constexpr int VH_FLOATS = 3 * TM * LDVH;
@@ -334,24 +340,25 @@ struct FmGvpTile {
 };
 
 // State on entry
-//   FIRST : Vh[xyz*TM+r][0..V]    = hidden vectors (h = V+1), Vh[..][V+1..V+7] = 0, Vh[..][V+8..V+15] = Vcp (8),
+//   FIRST : Vh[xyz*TM+r][0..H0)   = hidden vectors (H0 = V+1+HX), Vh[..][H0..KU0) = 0, Vh[..][KU0..KU0+8) = Vcp (8)   (HX = 0: KU0 = V+8),
 //           X[r][0..159]          = [rbf(32) | ef(128)]
 //   !FIRST: Vin[xyz*TM+r][0..V-1] = input vectors,  X[r][0..255] = input scalars
 // State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
 // `pre`: per-accumulator-element addend of the scalar linear, used by FIRST only (fm_gather_pre); the bias is added here.
 // All 512 threads must call it (it contains barriers); it ends with a barrier.
-template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH>
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
-    typedef FmGvpTile<V, TM> T;
+    typedef FmGvpTile<V, TM, HX> T;
     constexpr int MT = TM / 16;                          // row tiles of the scalar GEMM
     constexpr int NW = NTH / 64;                         // waves per workgroup
     constexpr int NTW = 16 / NW;                         // column tiles of the scalar GEMM per wave (16 tiles = 256 columns)
-    constexpr int H = FIRST ? V + 1 : V;                 // hidden vector channels
+    constexpr int H = FIRST ? T::H0 : V;                 // hidden vector channels
+    constexpr int KUC = FIRST ? T::KU0 : T::KU;          // K of this GVP's Wu GEMM = width of [hidden | cp | pad] in Vh and of sh in X
     constexpr int SOFF = FIRST ? 160 : 256;              // where sh goes in X
-    constexpr int K8S = (SOFF + V + 8) / 8;
+    constexpr int K8S = (SOFF + KUC) / 8;
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
-    constexpr int CPSRC = FIRST ? V + 8 : V;             // where the 8 Vcp channels sit in Vh
+    constexpr int CPSRC = FIRST ? T::KU0 : V;            // where the 8 Vcp channels sit in Vh
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // biases of this lane's accumulator columns, requested first: their L2 latency hides behind the vector phases
     float bias_s[NTW];
@@ -394,14 +401,14 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // thread -> (row, 16-column group): no integer division by V+8 in the index math
     for (int r = tid >> 4; r < TM; r += NTH / 16) {
 #pragma unroll
-        for (int j = 0; j < (V + 8 + 15) / 16; ++j) {
+        for (int j = 0; j < (KUC + 15) / 16; ++j) {
             const int c = (tid & 15) + 16 * j;
             if (c < H) {
                 const float vx = Vh[(0 * TM + r) * T::LDVH + c];
                 const float vy = Vh[(1 * TM + r) * T::LDVH + c];
                 const float vz = Vh[(2 * TM + r) * T::LDVH + c];
                 X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
-            } else if (c >= H + 4 && c < V + 8) {
+            } else if (c >= H + 4 && c < KUC) {
                 X[r * FM_LDX + SOFF + c] = 0.f;
             }
         }
@@ -409,7 +416,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     __syncthreads();
     FM_MARKB(1);
     // Vu = Vh_full * Wu -> Vin (the input vectors are dead by now)
-    fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * TM / 16, T::KU / 8, w.Wu, VOP / 16,
+    fm_block_gemm<1, 1>(Vh, T::LDVH, 3 * TM / 16, KUC / 8, w.Wu, VOP / 16,
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
     }
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
@@ -475,7 +482,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 
 // per-element addend of the first edge GVP's scalar linear: addend[rows[row]][col] for this lane's accumulator elements
 // (rows[] < 0: no row -> 0, via the buffer range check).  `addend` is (nrows, 256) fp32.
-template <int TM, int NTH>
+template <int TM, int NTH, bool ACCUM>
 __device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, int nrows, const int* rows) {
     constexpr int NTW = 1024 / NTH;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -487,7 +494,7 @@ __device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][
             const int ar = rows[i * 16 + 4 * (lane >> 4) + r];
             const int voff = ar >= 0 ? ar * 1024 + (lane & 15) * 4 : FM_BUF_OOB;
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) pre[i][j][r] = fm_buf_f32(rs, voff, (NTW * wave + j) * 64);
+            for (int j = 0; j < NTW; ++j) { const float t = fm_buf_f32(rs, voff, (NTW * wave + j) * 64); pre[i][j][r] = ACCUM ? pre[i][j][r] + t : t; }
         }
 }
 
@@ -510,3 +517,22 @@ __device__ __forceinline__ void fm_row_stats(const float* row, int n, int sub, f
 __device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {
     fm_row_stats<8>(row, n, sub, mean, rstd);
 }
+
+// Counter-based noise for sharded sampling (SURVEY.md §8e "performance mode"): Philox4x32-10 keyed by the run's seed, counter =
+// (global molecule id, row inside the molecule, step * 4 + modality, draw block).  A molecule's draws depend on nothing else,
+// so its trajectory is the same on 1 or 8 GPUs, in any batch composition; no noise tensors exist in HBM.
+struct FmPhilox4 { unsigned v[4]; };
+__device__ __forceinline__ FmPhilox4 fm_philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    FmPhilox4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+__device__ __forceinline__ float fm_u01(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }              // [0, 1), 24 bits like torch.rand
+__device__ __forceinline__ float fm_exp1(unsigned x) { return fmaxf(-logf((float)((x >> 8) + 1u) * 5.9604644775390625e-08f), 1e-30f); }   // Exp(1): -log(u), u in (0, 1]; never -0
+

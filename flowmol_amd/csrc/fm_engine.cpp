@@ -31,6 +31,7 @@ struct MlpW { const float2* W1; const float* b1; const float2* W2; const float* 
 
 struct ConvW {
     const float2* Wps; const float2* Wpv; const float* w0;
+    FmGvpW dproj{}; const float2* Wsd = nullptr; const float2* Wpvd = nullptr;     // use_dst_feats: projection GVP + hoisted destination terms
     FmGvpW msg[3]; FmGvpW upd[3];
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
 };
@@ -45,13 +46,15 @@ struct UpdW {
 struct fm_ctx {
     fm_config cfg{};
     std::string err;
-    int V = 32, na = 0, nc = 0, ne = 0;
+    int V = 32, S = 256, F = 128, na = 0, nc = 0, ne = 0;
+    int HX = 0, SD = 0, PVW = 48;     // use_dst_feats: destination vectors / scalars per message; width of the hoisted hidden-vector rows
     // Rows per workgroup tile of the GVP kernels, chosen per bound batch (ws_layout): 32 once the chip is full, 16 while
     // the 32-row tiling would leave CUs idle (fewer tiles than CUs) - half the work per tile, i.e. lower step latency
     // for small batches.  FM_TILE_EDGE / FM_TILE_NODE (16|32|64) force a size; FM_TILE_EUPD (32|64) for EdgeUpdate.
     int tm_edge = 32, tm_node = 32, tm_eupd = 32;
     int tm_edge_forced = 0, tm_node_forced = 0;
     int n_cus = 256;
+    int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (FM_FUSE_NODE=0: separate launches)
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
@@ -69,9 +72,11 @@ struct fm_ctx {
     FmBatch b{};
     int n_tiles_e = 0, n_tiles_n = 0, n_tiles_u = 0;
     float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
-    float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *tab_in = nullptr;
+    float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *Psd = nullptr, *PVd = nullptr;
+    float *tap_s = nullptr, *tap_v = nullptr;    // scratch of the aggregated-message taps (parity runs only)
     fm_dst boot{};
     int32_t *sa1 = nullptr, *sc1 = nullptr, *se1 = nullptr;
+    int* mol_gid = nullptr;   // [B] global molecule ids of the Philox noise streams
     // ---- taps / profiling
     std::map<std::string, void*> taps;
     bool prof = false;
@@ -169,15 +174,15 @@ void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
     B.put(slot, t);
 }
 
-// one non-first GVP (vin = V, hidden = V): reference gvp.py:30-88 parameter shapes
-bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int vout, FmGvpW& g) {
+// one non-first GVP (vin = V, hidden = V, S real scalar channels in a 256-wide tile): reference gvp.py:30-88 parameter shapes
+bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g) {
     const int vop = vout < 16 ? 16 : vout;
     const float* Wh = bl.get(key + ".Wh", V, V);
     const float* Wcp = bl.get(key + ".Wcp", V, 8);
     const float* Wu = bl.get(key + ".Wu", V + 4, vout);
-    const float* Ws = bl.get(key + ".to_feats_out.0.weight", 256, V + 4 + 256);
-    const float* bs = bl.get(key + ".to_feats_out.0.bias", 256);
-    const float* Wg = bl.get(key + ".scalar_to_vector_gates.weight", vout, 256);
+    const float* Ws = bl.get(key + ".to_feats_out.0.weight", S, V + 4 + S);
+    const float* bs = bl.get(key + ".to_feats_out.0.bias", S);
+    const float* Wg = bl.get(key + ".scalar_to_vector_gates.weight", vout, S);
     const float* bg = bl.get(key + ".scalar_to_vector_gates.bias", vout);
     if (!Wh || !Wcp || !Wu || !Ws || !bs || !Wg || !bg) return false;
     B.put(g.Wv1, pack(V, V + 16, [&](int k, int n) -> float {
@@ -185,17 +190,19 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int vout, FmG
         if (n < V + 8) return Wcp[k * 8 + (n - V)];
         return 0.f; }));
     B.put(g.Wu, pack(V + 8, vop, [&](int k, int n) -> float { return (k < V + 4 && n < vout) ? Wu[k * vout + n] : 0.f; }));
-    pack_linear(B, g.Ws, Ws, 256, V + 4 + 256, 256 + V + 8, 256, [&](int k) { return k < 256 + V + 4 ? k : -1; });
-    pad_vec(B, g.bs, bs, 256, 256);
-    pack_linear(B, g.Wg, Wg, vout, 256, 256, vop, [](int k) { return k; });
+    // tile K order [s (256 columns, S real) | sh (V+4) | 0]; reference order [s (S) | sh (V+4)]
+    pack_linear(B, g.Ws, Ws, S, V + 4 + S, 256 + V + 8, 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : (k < 256 + V + 4 ? S + (k - 256) : -1); });
+    pad_vec(B, g.bs, bs, S, 256);
+    pack_linear(B, g.Wg, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
     pad_vec(B, g.bg, bg, vout, vop);
     return true;
 }
 
 template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
-size_t lds_gvp(int V, int TM, bool with_meta) {
-    size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (V + 20) + TM * FM_LDG;
+int pvw_of(int V, int HX) { return (pad8(V + 1 + HX + 4) + 8 + 15) / 16 * 16; }     // FmGvpTile::PVW
+size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
+    size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, HX) + 4) + TM * FM_LDG;
     return fl * 4 + (with_meta ? (size_t)TM * 7 * 4 : 0);
 }
 size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 5 * FM_TM * 4; }
@@ -241,16 +248,25 @@ struct Launch {
     }
 };
 
-template <int MODE>
-void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows) {
+void fill_mlp(FmMlpArgs& a, const MlpW& w, int rows) {
     a.rows = rows; a.K1p = w.K1p; a.H = w.H; a.O = w.O;
     a.W1 = w.W1; a.b1 = w.b1; a.W2 = w.W2; a.b2 = w.b2;
     a.ldx = ld_for(w.K1p > w.O ? w.K1p : w.O); a.ldh = ld_for(w.H);
+}
+template <int MODE>
+void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows) {
+    fill_mlp(a, w, rows);
     L(name, fm_k_mlp2<MODE>, dim3((rows + FM_TM - 1) / FM_TM), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
+}
+template <int MODE_A, int MODE_B>
+void launch_mlp_pair(Launch& L, const char* name, FmMlpArgs a, const MlpW& wa, int rows_a, FmMlpArgs b, const MlpW& wb, int rows_b) {
+    fill_mlp(a, wa, rows_a); fill_mlp(b, wb, rows_b);
+    const int ta = (rows_a + FM_TM - 1) / FM_TM, tb = (rows_b + FM_TM - 1) / FM_TM;
+    L(name, fm_k_mlp2_pair<MODE_A, MODE_B>, dim3(ta + tb), dim3(FM_THREADS), std::max(lds_mlp(a.ldx, a.ldh), lds_mlp(b.ldx, b.ldh)), a, b, ta);
 }
 
 // ---------------------------------------------------------------------------------------- one network evaluation
-template <int V, int TE, int TN>
+template <int V, int TE, int TN, int HX>
 int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
              bool taps_on) {
     Launch L{c, st};
@@ -268,13 +284,14 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         a.s_tab = c->s_tab; a.tok_a = state->a_t; a.tok_c = state->c_t; a.n_c1 = nc1;
         a.prev_a = prev->a; a.prev_c = prev->c; a.prev_x = prev->x; a.x_t = state->x_t;
         a.out = c->s;
-        launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N);
         FmMlpArgs e = ma;
         e.e_src = b.e_src; e.e_dst = b.e_dst; e.e_pair = b.e_pair; e.tok_e = state->e_t;
         e.prev_e = prev->e; e.prev_x = prev->x; e.x_t = state->x_t; e.T1 = c->T1; e.ef_tab = c->ef_tab;
         e.out = c->ef;
         e.p_e0 = b.p_e0; e.p_e1 = b.p_e1;
-        launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U);   // one row per unordered pair, written to both directed edges
+        // one row per unordered pair, written to both directed edges; node and pair tiles share one launch
+        if (c->fuse_node) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U);
+        else { launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N); launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U); }
         tap("sc.s", c->s, (size_t)N * 256 * 4);
         tap("sc.ef", c->ef, (size_t)E * 128 * 4);
     } else {
@@ -285,19 +302,28 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         tap("embed.s", c->s, (size_t)N * 256 * 4);
         tap("embed.ef", c->ef, (size_t)E * 128 * 4);
     }
-    L.zero(c->v, (size_t)N * 3 * V * 4);
-    L.copy(c->xw, state->x_t, (size_t)N * 3 * 4);
 
     const dim3 blk(FM_THREADS);
     const dim3 gn((N + FM_TM - 1) / FM_TM), ge((E + FM_TM - 1) / FM_TM);     // 64-row kernels
     const dim3 gnt((N + TN - 1) / TN), get((E + TE - 1) / TE);              // GVP kernels
+    // FM_FUSE_NODE=0 (read at fm_create) keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own
+    const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
     for (int i = 0; i < cf.n_convs; ++i) {
         const ConvW& cw = c->conv[i];
-        FmProjArgs pa{};
-        pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV;
-        L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
+        if (i == 0 || !fuse) {      // later convs: projected in the previous conv's node_update
+            FmProjArgs pa{};
+            pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV; pa.pv_w = c->PVW;
+            if (i == 0) { pa.v_init = c->v; pa.x_src = state->x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
+            L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
+        }
         FmMsgArgs m{};
         m.b = b; m.x = c->xw; m.ef = c->ef; m.Ps = c->Ps; m.PV = c->PV; m.w0 = cw.w0;
+        if constexpr (HX > 0) {       // use_dst_feats: projection GVP of the conv's input features + its per-node hoists
+            FmDstProjArgs dp{};
+            dp.N = N; dp.s = c->s; dp.v = c->v; dp.g = cw.dproj; dp.Wsd = cw.Wsd; dp.Psd = c->Psd; dp.Wpvd = cw.Wpvd; dp.PVd = c->PVd; dp.pv_w = c->PVW;
+            L("dst_proj", fm_k_dst_proj<V, TN, HX>, gnt, blk, lds_gvp(V, TN, false), dp);
+            m.Psd = c->Psd; m.PVd = c->PVd;
+        }
         m.g0 = cw.msg[0]; m.g1 = cw.msg[1]; m.g2 = cw.msg[2];
         m.part_s = c->part_s; m.part_v = c->part_v;
         m.rbf_mu_step = c->rbf_mu_step; m.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -306,34 +332,48 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
         dim3 gmsg = get;
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
-        L("edge_message", fm_k_edge_message<V, TE, 512>, gmsg, dim3(512), lds_gvp(V, TE, true), m);
+        L("edge_message", fm_k_edge_message<V, TE, 512, HX>, gmsg, dim3(512), lds_gvp(V, TE, true, HX), m);
+        const int u = cf.update_after[i];
         FmNodeUpdArgs nu{};
         nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
         nu.g0 = cw.upd[0]; nu.g1 = cw.upd[1]; nu.g2 = cw.upd[2];
         nu.ln1_g = cw.ln1_g; nu.ln1_b = cw.ln1_b; nu.ln2_g = cw.ln2_g; nu.ln2_b = cw.ln2_b;
         const std::string ci = "conv" + std::to_string(i);
         const bool tagg = taps_on && (c->taps.count(ci + ".agg.s") || c->taps.count(ci + ".agg.v"));
-        nu.agg_s = tagg ? c->Ps : nullptr;        // Ps / PV are dead until the next conv: reuse as tap scratch
-        nu.agg_v = tagg ? c->PV : nullptr;
+        // aggregated-message taps go through scratch of their own (Ps / PV, which served in round 1, are outputs of the fused kernel)
+        nu.agg_s = tagg ? c->tap_s : nullptr;
+        nu.agg_v = tagg ? c->tap_v : nullptr;
         nu.tile_e = TE;
-        L("node_update", fm_k_node_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), nu);
-        if (tagg) { tap(ci + ".agg.s", c->Ps, (size_t)N * 256 * 4); tap(ci + ".agg.v", c->PV, (size_t)N * 3 * V * 4); }
+        if (fuse) {
+            if (i + 1 < cf.n_convs) { const ConvW& nx = c->conv[i + 1]; nu.Wps = nx.Wps; nu.Ps = c->Ps; nu.Wpv = nx.Wpv; nu.PV = c->PV; }
+            if (u >= 0) {
+                const UpdW& uw = c->upd[u];
+                nu.Wasd = uw.Wasd; nu.Asd = c->Asd; nu.p0 = uw.pos[0]; nu.p1 = uw.pos[1]; nu.p2 = uw.pos[2]; nu.x = c->xw;
+            }
+        }
+        nu.s_real = c->S;
+        if (c->S == 256) L("node_update", fm_k_node_update<V, TN, false>, gnt, blk, lds_gvp(V, TN, false), nu);
+        else L("node_update", fm_k_node_update<V, TN, true>, gnt, blk, lds_gvp(V, TN, false), nu);
+        if (tagg) { tap(ci + ".agg.s", c->tap_s, (size_t)N * 256 * 4); tap(ci + ".agg.v", c->tap_v, (size_t)N * 3 * V * 4); }
         tap(ci + ".s", c->s, (size_t)N * 256 * 4);
         tap(ci + ".v", c->v, (size_t)N * 3 * V * 4);
-        const int u = cf.update_after[i];
         if (u >= 0) {
             const UpdW& uw = c->upd[u];
-            FmPosArgs pp{};
-            pp.N = N; pp.s = c->s; pp.v = c->v; pp.x = c->xw; pp.g0 = uw.pos[0]; pp.g1 = uw.pos[1]; pp.g2 = uw.pos[2];
-            L("pos_update", fm_k_pos_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), pp);
-            FmProjArgs pa2{};
-            pa2.N = N; pa2.s = c->s; pa2.v = c->v; pa2.Wasd = uw.Wasd; pa2.Asd = c->Asd;
-            L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
+            if (!fuse) {
+                FmPosArgs pp{};
+                pp.N = N; pp.s = c->s; pp.v = c->v; pp.x = c->xw; pp.g0 = uw.pos[0]; pp.g1 = uw.pos[1]; pp.g2 = uw.pos[2];
+                L("pos_update", fm_k_pos_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), pp);
+                FmProjArgs pa2{};
+                pa2.N = N; pa2.s = c->s; pa2.v = c->v; pa2.Wasd = uw.Wasd; pa2.Asd = c->Asd;
+                L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
+            }
             FmEdgeUpdArgs eu{};
             eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
             eu.ln_g = uw.ln_g; eu.ln_b = uw.ln_b; eu.rbf_mu_step = c->rbf_mu_step; eu.rbf_inv_sigma = c->rbf_inv_sigma;
-            if (c->tm_eupd == 32) L("edge_update", fm_k_edge_update<32>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
-            else L("edge_update", fm_k_edge_update<64>, dim3((E + 63) / 64), blk, lds_edge_upd(64), eu);
+            eu.f_real = c->F;
+            if (c->F != 128) L("edge_update", fm_k_edge_update<32, true>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
+            else if (c->tm_eupd == 32) L("edge_update", fm_k_edge_update<32, false>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
+            else L("edge_update", fm_k_edge_update<64, false>, dim3((E + 63) / 64), blk, lds_edge_upd(64), eu);
             const std::string ui = "upd" + std::to_string(i);
             tap(ui + ".x", c->xw, (size_t)N * 3 * 4);
             tap(ui + ".ef", c->ef, (size_t)E * 128 * 4);
@@ -342,34 +382,41 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     {
         FmMlpArgs a = ma;
         a.in = c->s; a.out = out->a; a.out2 = out->c;
-        launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N);
         FmMlpArgs e = ma;
         e.ef = c->ef; e.p_e0 = b.p_e0; e.p_e1 = b.p_e1; e.out = out->e;
-        launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U);
+        if (c->fuse_node) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U);
+        else { launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N); launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U); }
     }
-    L.copy(out->x, c->xw, (size_t)N * 3 * 4);
-    if (remove_com) L("remove_com", fm_k_remove_com, dim3(b.B), dim3(64), 0, out->x, (const int*)b.mol_node_off);
+    if (remove_com != 2) {       // 2: the caller's fused CTMC kernel centres the raw positions (c->xw) and writes out->x itself
+        L.copy(out->x, c->xw, (size_t)N * 3 * 4);
+        if (remove_com) L("remove_com", fm_k_remove_com, dim3(b.B), dim3(64), 0, out->x, (const int*)b.mol_node_off);
+    }
     return L.rc;
 }
 
 int evaluate_dispatch(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out, bool taps_on) {
-#define FM_EVAL(V_, TE_, TN_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_) return evaluate<V_, TE_, TN_>(c, st, state, prev, remove_com, out, taps_on);
+#define FM_EVAL_H(V_, TE_, TN_, H_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_ && c->HX == H_) return evaluate<V_, TE_, TN_, H_>(c, st, state, prev, remove_com, out, taps_on);
+#define FM_EVAL(V_, TE_, TN_) FM_EVAL_H(V_, TE_, TN_, 0)
 #define FM_EVAL_V(V_) FM_EVAL(V_, 16, 16) FM_EVAL(V_, 16, 32) FM_EVAL(V_, 16, 64) FM_EVAL(V_, 32, 16) FM_EVAL(V_, 32, 32) FM_EVAL(V_, 32, 64) \
                       FM_EVAL(V_, 64, 16) FM_EVAL(V_, 64, 32) FM_EVAL(V_, 64, 64)
     FM_EVAL_V(32) FM_EVAL_V(16)
+    // use_dst_feats models (configs/dev.yml): destination vectors = V/4; 16- and 32-row tiles only
+    FM_EVAL_H(16, 16, 16, 4) FM_EVAL_H(16, 16, 32, 4) FM_EVAL_H(16, 32, 16, 4) FM_EVAL_H(16, 32, 32, 4)
+    FM_EVAL_H(32, 16, 16, 8) FM_EVAL_H(32, 16, 32, 8) FM_EVAL_H(32, 32, 16, 8) FM_EVAL_H(32, 32, 32, 8)
 #undef FM_EVAL_V
 #undef FM_EVAL
-    return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d", c->V, c->tm_edge, c->tm_node);
+#undef FM_EVAL_H
+    return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d dst_vectors=%d", c->V, c->tm_edge, c->tm_node, c->HX);
 }
 
 int embed_table(fm_ctx* c, hipStream_t st, const float* temb) {
     Launch L{c, st};
     const fm_config& cf = c->cfg;
-    const int ta = cf.a_token_dim ? cf.a_token_dim : c->na + 1, tc = cf.c_token_dim ? cf.c_token_dim : c->nc + 1;
-    L("embed_in", fm_k_embed_in, dim3((c->tab_rows * c->tab_kp + 255) / 256), dim3(256), 0, c->tab_in, c->tab_kp, c->na + 1, c->nc + 1,
-      ta, tc, cf.time_embedding_dim, c->emb_a, c->emb_c, temb);
     FmMlpArgs a{};
-    a.in = c->tab_in; a.in_ld = c->tab_kp; a.out = c->s_tab; a.out_ld = 256; a.ln_g = c->node_ln_g; a.ln_b = c->node_ln_b;
+    a.in = nullptr; a.n_c1 = c->nc + 1;          // rows = (a,c) token pairs; the input row is built in the kernel's prologue
+    a.emb_a = c->emb_a; a.emb_c = c->emb_c; a.temb = temb;
+    a.ta = cf.a_token_dim ? cf.a_token_dim : c->na + 1; a.tc = cf.c_token_dim ? cf.c_token_dim : c->nc + 1; a.tt = cf.time_embedding_dim;
+    a.out = c->s_tab; a.out_ld = 256; a.ln_g = c->node_ln_g; a.ln_b = c->node_ln_b; a.ln_n = c->S;
     launch_mlp<FM_MLP_TABLE>(L, "embed_table", a, c->node_embed, c->tab_rows);
     return L.rc;
 }
@@ -391,15 +438,22 @@ int forward_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const float* 
 }
 
 int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* dst, const fm_step_noise* nz,
-              const fm_step_scalars* sc, const fm_sampled* smp) {
+              const fm_step_scalars* sc, const fm_sampled* smp, const float* x_raw = nullptr) {
     Launch L{c, st};
     const FmBatch& b = c->b;
     struct Mod { int rows, K; const float* p; const int* mol; int* xt; int* x1; const float *q, *u1, *u2; };
+    static const fm_step_noise no_noise{};
+    if (!nz) {                    // Philox steps draw inside the kernel
+        if (sc->noise_mode != FM_NOISE_PHILOX) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: noise tensors missing (noise_mode FM_NOISE_TENSORS)");
+        nz = &no_noise;
+    }
     Mod mods[3] = {
         {b.N, c->na, dst->a, b.node_mol, state->a_t, (smp && smp->a1) ? smp->a1 : c->sa1, nz->q_a, nz->u1_a, nz->u2_a},
         {b.N, c->nc, dst->c, b.node_mol, state->c_t, (smp && smp->c1) ? smp->c1 : c->sc1, nz->q_c, nz->u1_c, nz->u2_c},
         {b.U, c->ne, dst->e, b.pair_mol, state->e_t, (smp && smp->e1) ? smp->e1 : c->se1, nz->q_e, nz->u1_e, nz->u2_e},
     };
+    if (sc->dfm_type == FM_DFM_GAT && (sc->noise_mode == FM_NOISE_PHILOX || !nz->q_a))
+        return fail(c, FM_ERR_INVALID, "fm_ctmc_step: dfm_type 'gat' needs the caller's noise tensors");
     if (sc->dfm_type == FM_DFM_GAT) {
         L("x_step", fm_k_x_step, dim3((b.N * 3 + 255) / 256), dim3(256), 0, state->x_t, (const float*)dst->x, sc->x_coef, sc->dt, sc->x_scale, b.N * 3);
         for (int m = 0; m < 3; ++m) {
@@ -421,6 +475,9 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
     }
     f.temp = sc->cat_temperature; f.hc_thresh = sc->hc_thresh; f.last_step = sc->last_step;
     f.x_t = state->x_t; f.x1 = dst->x; f.node_off = b.mol_node_off; f.coef = sc->x_coef; f.dt = sc->dt; f.scale = sc->x_scale;
+    f.x_raw = x_raw; f.x1_out = dst->x;
+    if (sc->noise_mode == FM_NOISE_PHILOX) { f.philox = 1; f.seed_lo = sc->philox_seed_lo; f.seed_hi = sc->philox_seed_hi; f.step = sc->step_index; f.mol_gid = c->mol_gid; }
+    else if (!nz->q_a || !nz->u1_a || !nz->q_e) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: noise tensors missing (noise_mode FM_NOISE_TENSORS)");
     L("ctmc", fm_k_ctmc_fused, dim3(b.B, 4), dim3(256), 0, f);
     return L.rc;
 }
@@ -436,8 +493,11 @@ int fm_abi_version(void) { return FM_ABI_VERSION; }
 int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors, const float* host_blob, fm_ctx** out) {
     if (!cfg || !tensors || !host_blob || !out) return fail(nullptr, FM_ERR_INVALID, "fm_create: null argument");
     if (cfg->abi_version != FM_ABI_VERSION) return fail(nullptr, FM_ERR_INVALID, "fm_create: ABI version %d != %d", cfg->abi_version, FM_ABI_VERSION);
-    if (cfg->n_hidden_scalars != 256 || cfg->n_hidden_edge_feats != 128 || cfg->rbf_dim != 32)
-        return fail(nullptr, FM_ERR_INVALID, "fm_create: kernels are built for S=256,F=128,R=32");
+    // The kernels' tiles are 256 scalar / 128 edge-feature columns wide.  Narrower models (configs/dev.yml: 64 / 64) run on the
+    // same tiles: weights, biases and LayerNorm affine parameters are zero-padded when they are repacked, so the extra columns
+    // stay exactly 0 through every Linear / SiLU / residual, and LayerNorm takes its statistics over the REAL width only.
+    if (cfg->n_hidden_scalars < 8 || cfg->n_hidden_scalars > 256 || cfg->n_hidden_edge_feats < 8 || cfg->n_hidden_edge_feats > 128 || cfg->rbf_dim != 32)
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: need 8 <= n_hidden_scalars <= 256, 8 <= n_hidden_edge_feats <= 128, rbf_dim == 32");
     if (cfg->n_vec_channels != 16 && cfg->n_vec_channels != 32) return fail(nullptr, FM_ERR_INVALID, "fm_create: n_vec_channels must be 16 or 32");
     if (cfg->n_convs < 1 || cfg->n_convs > FM_MAX_CONVS) return fail(nullptr, FM_ERR_INVALID, "fm_create: bad n_convs");
     if (cfg->n_atom_types + 1 > 16 || cfg->n_charges + 1 > 16 || cfg->n_bond_types + 1 > 16 || cfg->n_atom_types + cfg->n_charges > 32)
@@ -448,6 +508,11 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     fm_ctx* c = new fm_ctx();
     c->cfg = *cfg;
     const int V = c->V = cfg->n_vec_channels;
+    const int S = c->S = cfg->n_hidden_scalars, F = c->F = cfg->n_hidden_edge_feats;
+    const int HX = c->HX = cfg->v_dst_feats, SD = c->SD = cfg->s_dst_feats;
+    if ((HX > 0) != (SD > 0) || HX < 0 || HX > 8 || SD > 256 || (HX > 0 && HX != V / 4))
+        { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: destination-feature widths must be both 0 or v = n_vec_channels/4 (<= 8), s <= 256"); }
+    const int H0 = V + 1 + HX, KU0 = pad8(H0 + 4), PVW = c->PVW = pvw_of(V, HX);
     const int na = c->na = cfg->n_atom_types, nc = c->nc = cfg->n_charges, ne = c->ne = cfg->n_bond_types;
     c->rbf_mu_step = cfg->rbf_dmax / (float)(cfg->rbf_dim - 1);
     c->rbf_inv_sigma = 1.0f / (cfg->rbf_dmax / (float)cfg->rbf_dim);
@@ -470,62 +535,62 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     }
     {
         const int kin = ta + tc + tt;
-        const float* W1 = bl.get("scalar_embedding.0.weight", 256, kin); const float* b1 = bl.get("scalar_embedding.0.bias", 256);
-        const float* W2 = bl.get("scalar_embedding.2.weight", 256, 256); const float* b2 = bl.get("scalar_embedding.2.bias", 256);
-        const float* g = bl.get("scalar_embedding.4.weight", 256); const float* be = bl.get("scalar_embedding.4.bias", 256);
+        const float* W1 = bl.get("scalar_embedding.0.weight", S, kin); const float* b1 = bl.get("scalar_embedding.0.bias", S);
+        const float* W2 = bl.get("scalar_embedding.2.weight", S, S); const float* b2 = bl.get("scalar_embedding.2.bias", S);
+        const float* g = bl.get("scalar_embedding.4.weight", S); const float* be = bl.get("scalar_embedding.4.bias", S);
         if (!W1 || !b1 || !W2 || !b2 || !g || !be) return bail(bl.err);
         c->node_embed.K1p = pad8(kin); c->node_embed.H = 256; c->node_embed.O = 256;
-        pack_linear(B, c->node_embed.W1, W1, 256, kin, pad8(kin), 256, ident);
-        pad_vec(B, c->node_embed.b1, b1, 256, 256);
-        pack_linear(B, c->node_embed.W2, W2, 256, 256, 256, 256, ident);
-        pad_vec(B, c->node_embed.b2, b2, 256, 256);
-        pad_vec(B, c->node_ln_g, g, 256, 256); pad_vec(B, c->node_ln_b, be, 256, 256);
+        pack_linear(B, c->node_embed.W1, W1, S, kin, pad8(kin), 256, ident);
+        pad_vec(B, c->node_embed.b1, b1, S, 256);
+        pack_linear(B, c->node_embed.W2, W2, S, S, 256, 256, ident);
+        pad_vec(B, c->node_embed.b2, b2, S, 256);
+        pad_vec(B, c->node_ln_g, g, S, 256); pad_vec(B, c->node_ln_b, be, S, 256);
         c->tab_rows = (na + 1) * (nc + 1); c->tab_kp = pad8(kin);
     }
     const float *ee_W1, *ee_b1, *ee_W2, *ee_b2, *ee_g, *ee_b;
     {
-        ee_W1 = bl.get("edge_embedding.0.weight", 128, te); ee_b1 = bl.get("edge_embedding.0.bias", 128);
-        ee_W2 = bl.get("edge_embedding.2.weight", 128, 128); ee_b2 = bl.get("edge_embedding.2.bias", 128);
-        ee_g = bl.get("edge_embedding.4.weight", 128); ee_b = bl.get("edge_embedding.4.bias", 128);
+        ee_W1 = bl.get("edge_embedding.0.weight", F, te); ee_b1 = bl.get("edge_embedding.0.bias", F);
+        ee_W2 = bl.get("edge_embedding.2.weight", F, F); ee_b2 = bl.get("edge_embedding.2.bias", F);
+        ee_g = bl.get("edge_embedding.4.weight", F); ee_b = bl.get("edge_embedding.4.bias", F);
         if (!ee_W1 || !ee_b1 || !ee_W2 || !ee_b2 || !ee_g || !ee_b) return bail(bl.err);
     }
     // edge-embedding table (ne+1 rows): the edge embedding has only ne+1 distinct inputs;
     // evaluated once here on the host in f32 (same op order as a row of the device MLP is not required: 1e-7 class)
     std::vector<float> ef_tab((size_t)(ne + 1) * 128), T1((size_t)(ne + 1) * 128, 0.f);
     for (int t = 0; t <= ne; ++t) {
-        std::vector<float> in(te, 0.f), h1(128), h2(128);
+        std::vector<float> in(te, 0.f), h1(F), h2(F);
         if (tok) for (int k = 0; k < te; ++k) in[k] = emb_e[t * te + k]; else in[t] = 1.f;
-        for (int n = 0; n < 128; ++n) { float acc = ee_b1[n]; for (int k = 0; k < te; ++k) acc = fmaf(ee_W1[n * te + k], in[k], acc); h1[n] = acc / (1.0f + expf(-acc)); }
-        for (int n = 0; n < 128; ++n) { float acc = ee_b2[n]; for (int k = 0; k < 128; ++k) acc = fmaf(ee_W2[n * 128 + k], h1[k], acc); h2[n] = acc / (1.0f + expf(-acc)); }
-        double mean = 0; for (float x : h2) mean += x; mean /= 128;
-        double var = 0; for (float x : h2) var += (x - mean) * (x - mean); var /= 128;
+        for (int n = 0; n < F; ++n) { float acc = ee_b1[n]; for (int k = 0; k < te; ++k) acc = fmaf(ee_W1[n * te + k], in[k], acc); h1[n] = acc / (1.0f + expf(-acc)); }
+        for (int n = 0; n < F; ++n) { float acc = ee_b2[n]; for (int k = 0; k < F; ++k) acc = fmaf(ee_W2[n * F + k], h1[k], acc); h2[n] = acc / (1.0f + expf(-acc)); }
+        double mean = 0; for (float x : h2) mean += x; mean /= F;
+        double var = 0; for (float x : h2) var += (x - mean) * (x - mean); var /= F;
         const float rstd = (float)(1.0 / std::sqrt(var + 1e-5));
-        for (int n = 0; n < 128; ++n) ef_tab[(size_t)t * 128 + n] = (h2[n] - (float)mean) * rstd * ee_g[n] + ee_b[n];
+        for (int n = 0; n < F; ++n) ef_tab[(size_t)t * 128 + n] = (h2[n] - (float)mean) * rstd * ee_g[n] + ee_b[n];      // columns F..127 stay 0
     }
     // ---- self-conditioning
     if (cfg->self_conditioning) {
         const std::string p = "self_conditioning_residual_layer.";
-        const int kin = 256 + na + nc + 32;
-        const float* W1 = bl.get(p + "node_residual_mlp.0.weight", 256, kin); const float* b1 = bl.get(p + "node_residual_mlp.0.bias", 256);
-        const float* W2 = bl.get(p + "node_residual_mlp.2.weight", 256, 256); const float* b2 = bl.get(p + "node_residual_mlp.2.bias", 256);
-        const int kie = 128 + ne + 32;
-        const float* E1 = bl.get(p + "edge_residual_mlp.0.weight", 128, kie); const float* eb1 = bl.get(p + "edge_residual_mlp.0.bias", 128);
-        const float* E2 = bl.get(p + "edge_residual_mlp.2.weight", 128, 128); const float* eb2 = bl.get(p + "edge_residual_mlp.2.bias", 128);
+        const int kin = S + na + nc + 32, kinp = 256 + na + nc + 32;       // reference / tile input widths: [s | p_a | p_c | rbf]
+        const float* W1 = bl.get(p + "node_residual_mlp.0.weight", S, kin); const float* b1 = bl.get(p + "node_residual_mlp.0.bias", S);
+        const float* W2 = bl.get(p + "node_residual_mlp.2.weight", S, S); const float* b2 = bl.get(p + "node_residual_mlp.2.bias", S);
+        const int kie = F + ne + 32;
+        const float* E1 = bl.get(p + "edge_residual_mlp.0.weight", F, kie); const float* eb1 = bl.get(p + "edge_residual_mlp.0.bias", F);
+        const float* E2 = bl.get(p + "edge_residual_mlp.2.weight", F, F); const float* eb2 = bl.get(p + "edge_residual_mlp.2.bias", F);
         if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
-        c->sc_node.K1p = pad8(kin); c->sc_node.H = 256; c->sc_node.O = 256;
-        pack_linear(B, c->sc_node.W1, W1, 256, kin, pad8(kin), 256, ident);
-        pad_vec(B, c->sc_node.b1, b1, 256, 256);
-        pack_linear(B, c->sc_node.W2, W2, 256, 256, 256, 256, ident);
-        pad_vec(B, c->sc_node.b2, b2, 256, 256);
+        c->sc_node.K1p = pad8(kinp); c->sc_node.H = 256; c->sc_node.O = 256;
+        pack_linear(B, c->sc_node.W1, W1, S, kin, pad8(kinp), 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : S + (k - 256); });
+        pad_vec(B, c->sc_node.b1, b1, S, 256);
+        pack_linear(B, c->sc_node.W2, W2, S, S, 256, 256, ident);
+        pad_vec(B, c->sc_node.b2, b2, S, 256);
         c->sc_edge.K1p = pad8(ne + 32); c->sc_edge.H = 128; c->sc_edge.O = 128;
-        pack_linear(B, c->sc_edge.W1, E1, 128, kie, pad8(ne + 32), 128, [&](int k) { return k < ne + 32 ? 128 + k : -1; });
-        pad_vec(B, c->sc_edge.b1, eb1, 128, 128);
-        pack_linear(B, c->sc_edge.W2, E2, 128, 128, 128, 128, ident);
-        pad_vec(B, c->sc_edge.b2, eb2, 128, 128);
+        pack_linear(B, c->sc_edge.W1, E1, F, kie, pad8(ne + 32), 128, [&](int k) { return k < ne + 32 ? F + k : -1; });
+        pad_vec(B, c->sc_edge.b1, eb1, F, 128);
+        pack_linear(B, c->sc_edge.W2, E2, F, F, 128, 128, ident);
+        pad_vec(B, c->sc_edge.b2, eb2, F, 128);
         for (int t = 0; t <= ne; ++t)
-            for (int n = 0; n < 128; ++n) {
+            for (int n = 0; n < F; ++n) {
                 float acc = eb1[n];
-                for (int k = 0; k < 128; ++k) acc = fmaf(E1[(size_t)n * kie + k], ef_tab[(size_t)t * 128 + k], acc);
+                for (int k = 0; k < F; ++k) acc = fmaf(E1[(size_t)n * kie + k], ef_tab[(size_t)t * 128 + k], acc);
                 T1[(size_t)t * 128 + n] = acc;
             }
     }
@@ -537,43 +602,65 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         ConvW& cw = c->conv[i];
         const std::string p = "conv_layers." + std::to_string(i) + ".";
         const std::string k0 = p + "edge_message.0";
-        const int kin0 = 256 + 32 + 128 + V + 5;
-        const float* Wh = bl.get(k0 + ".Wh", V + 1, V + 1);
-        const float* Wcp = bl.get(k0 + ".Wcp", V + 1, 8);
-        const float* Wu = bl.get(k0 + ".Wu", V + 5, V);
-        const float* Ws = bl.get(k0 + ".to_feats_out.0.weight", 256, kin0);
-        const float* bs = bl.get(k0 + ".to_feats_out.0.bias", 256);
-        const float* Wg = bl.get(k0 + ".scalar_to_vector_gates.weight", V, 256);
+        const int kin0 = S + 32 + F + SD + H0 + 4;
+        const float* Wh = bl.get(k0 + ".Wh", H0, H0);        // input vectors [x_diff | v_src (V) | v_dst_msg (HX)], hidden = max(in, out) = H0
+        const float* Wcp = bl.get(k0 + ".Wcp", H0, 8);
+        const float* Wu = bl.get(k0 + ".Wu", H0 + 4, V);
+        const float* Ws = bl.get(k0 + ".to_feats_out.0.weight", S, kin0);
+        const float* bs = bl.get(k0 + ".to_feats_out.0.bias", S);
+        const float* Wg = bl.get(k0 + ".scalar_to_vector_gates.weight", V, S);
         const float* bg = bl.get(k0 + ".scalar_to_vector_gates.bias", V);
         if (!Wh || !Wcp || !Wu || !Ws || !bs || !Wg || !bg) return bail(bl.err);
         // hoisted per-node parts (input vector 0 is the displacement; 1.. are v_src)
-        pack_linear(B, cw.Wps, Ws, 256, kin0, 256, 256, ident);
-        B.put(cw.Wpv, pack(V, V + 16, [&](int k, int n) -> float {
-            if (n < V + 1) return Wh[(1 + k) * (V + 1) + n];
-            if (n < V + 8) return 0.f;
-            return Wcp[(1 + k) * 8 + (n - V - 8)]; }));
+        pack_linear(B, cw.Wps, Ws, S, kin0, 256, 256, [&](int k) { return k < S ? k : -1; });
+        // hidden-vector row layout (FmGvpTile): [hidden (H0) | cp (4, filled by the kernel) | 0 .. KU0) | Vcp sources (8) | 0 .. PVW)
+        auto hrow = [&](int vin_row, int n) -> float {
+            if (n < H0) return Wh[(size_t)vin_row * H0 + n];
+            if (n >= KU0 && n < KU0 + 8) return Wcp[(size_t)vin_row * 8 + (n - KU0)];
+            return 0.f; };
+        B.put(cw.Wpv, pack(V, PVW, [&](int k, int n) -> float { return hrow(1 + k, n); }));
         {
-            std::vector<float> w0(V + 16, 0.f);
-            for (int n = 0; n < V + 1; ++n) w0[n] = Wh[n];
-            for (int n = 0; n < 8; ++n) w0[V + 8 + n] = Wcp[n];
+            std::vector<float> w0(PVW, 0.f);
+            for (int n = 0; n < PVW; ++n) w0[n] = hrow(0, n);
             B.put(cw.w0, w0);
         }
         FmGvpW& g0 = cw.msg[0];
         g0.Wv1 = nullptr;
-        B.put(g0.Wu, pack(V + 8, V, [&](int k, int n) -> float { return k < V + 5 ? Wu[k * V + n] : 0.f; }));
-        // K order of the first scalar linear: [rbf(32) | ef(128) | sh(V+5) | 0]; reference column order
-        // [s_src(256) | rbf(32) | ef(128) | sh(V+5)] (gvp.py:532-539,118)
-        pack_linear(B, g0.Ws, Ws, 256, kin0, 160 + V + 8, 256, [&](int k) { return k < 160 + V + 5 ? 256 + k : -1; });
-        pad_vec(B, g0.bs, bs, 256, 256);
-        pack_linear(B, g0.Wg, Wg, V, 256, 256, V, ident);
+        B.put(g0.Wu, pack(KU0, V, [&](int k, int n) -> float { return k < H0 + 4 ? Wu[k * V + n] : 0.f; }));
+        // K order of the first scalar linear: [rbf(32) | ef(128 columns, F real) | sh(V+5) | 0]; reference column order
+        // [s_src(S) | rbf(32) | ef(F) | sh(V+5)] (gvp.py:532-539,118)
+        pack_linear(B, g0.Ws, Ws, S, kin0, 160 + KU0, 256, [&](int k) {
+            if (k < 32) return S + k;
+            if (k < 160) return k - 32 < F ? S + 32 + (k - 32) : -1;
+            return k < 160 + H0 + 4 ? S + 32 + F + SD + (k - 160) : -1; });
+        pad_vec(B, g0.bs, bs, S, 256);
+        pack_linear(B, g0.Wg, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
         pad_vec(B, g0.bg, bg, V, V);
-        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, V, cw.msg[g])) return bail(bl.err);
-        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, V, cw.upd[g])) return bail(bl.err);
-        const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", 256); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", 256);
-        const float* l2g = bl.get(p + "update_layer_norm.feat_norm.weight", 256); const float* l2b = bl.get(p + "update_layer_norm.feat_norm.bias", 256);
+        if (HX > 0) {
+            // destination-node terms of the first edge GVP, hoisted per node: vectors through [Wh | Wcp] rows V+1.., scalars through Ws columns S+32+F..
+            B.put(cw.Wpvd, pack(8, PVW, [&](int k, int n) -> float { return k < HX ? hrow(V + 1 + k, n) : 0.f; }));
+            pack_linear(B, cw.Wsd, Ws, S, kin0, 256, 256, [&](int k) { return k < SD ? S + 32 + F + k : -1; });
+            // the projection GVP itself (gvp.py:304-311): V -> HX vectors, S -> SD scalars, hidden V, no cross-product features
+            const std::string kp = p + "dst_feat_msg_projection";
+            const float* pWh = bl.get(kp + ".Wh", V, V); const float* pWu = bl.get(kp + ".Wu", V, HX);
+            const float* pWs = bl.get(kp + ".to_feats_out.0.weight", SD, V + S); const float* pbs = bl.get(kp + ".to_feats_out.0.bias", SD);
+            const float* pWg = bl.get(kp + ".scalar_to_vector_gates.weight", HX, SD); const float* pbg = bl.get(kp + ".scalar_to_vector_gates.bias", HX);
+            if (!pWh || !pWu || !pWs || !pbs || !pWg || !pbg) return bail(bl.err);
+            FmGvpW& dp = cw.dproj;
+            B.put(dp.Wv1, pack(V, V + 16, [&](int k, int n) -> float { return n < V ? pWh[k * V + n] : 0.f; }));         // Wcp = 0
+            B.put(dp.Wu, pack(V + 8, 16, [&](int k, int n) -> float { return (k < V && n < HX) ? pWu[k * HX + n] : 0.f; }));
+            pack_linear(B, dp.Ws, pWs, SD, V + S, 256 + V + 8, 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : (k < 256 + V ? S + (k - 256) : -1); });
+            pad_vec(B, dp.bs, pbs, SD, 256);
+            pack_linear(B, dp.Wg, pWg, HX, SD, 256, 16, [&](int k) { return k < SD ? k : -1; });
+            pad_vec(B, dp.bg, pbg, HX, 16);
+        }
+        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g])) return bail(bl.err);
+        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g])) return bail(bl.err);
+        const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", S); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", S);
+        const float* l2g = bl.get(p + "update_layer_norm.feat_norm.weight", S); const float* l2b = bl.get(p + "update_layer_norm.feat_norm.bias", S);
         if (!l1g || !l1b || !l2g || !l2b) return bail(bl.err);
-        pad_vec(B, cw.ln1_g, l1g, 256, 256); pad_vec(B, cw.ln1_b, l1b, 256, 256);
-        pad_vec(B, cw.ln2_g, l2g, 256, 256); pad_vec(B, cw.ln2_b, l2b, 256, 256);
+        pad_vec(B, cw.ln1_g, l1g, S, 256); pad_vec(B, cw.ln1_b, l1b, S, 256);
+        pad_vec(B, cw.ln2_g, l2g, S, 256); pad_vec(B, cw.ln2_b, l2b, S, 256);
     }
     // ---- molecule updaters (only those the schedule uses; index 0 is dead when convs_per_update == 1)
     c->upd.resize(cfg->n_updaters);
@@ -583,35 +670,38 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!used) continue;
         UpdW& uw = c->upd[u];
         const std::string p = "node_position_updaters." + std::to_string(u) + ".gvps.";
-        if (!pack_gvp(B, bl, p + "0", V, V, uw.pos[0]) || !pack_gvp(B, bl, p + "1", V, V, uw.pos[1]) || !pack_gvp(B, bl, p + "2", V, 1, uw.pos[2]))
+        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0]) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1]) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2]))
             return bail(bl.err);
         const std::string q = "edge_updaters." + std::to_string(u) + ".";
-        const int kin = 2 * 256 + 128 + 32;
-        const float* W1 = bl.get(q + "edge_update_fn.0.weight", 128, kin); const float* b1 = bl.get(q + "edge_update_fn.0.bias", 128);
-        const float* W2 = bl.get(q + "edge_update_fn.2.weight", 128, 128); const float* b2 = bl.get(q + "edge_update_fn.2.bias", 128);
-        const float* g = bl.get(q + "edge_norm.weight", 128); const float* be = bl.get(q + "edge_norm.bias", 128);
+        const int kin = 2 * S + F + 32;
+        const float* W1 = bl.get(q + "edge_update_fn.0.weight", F, kin); const float* b1 = bl.get(q + "edge_update_fn.0.bias", F);
+        const float* W2 = bl.get(q + "edge_update_fn.2.weight", F, F); const float* b2 = bl.get(q + "edge_update_fn.2.bias", F);
+        const float* g = bl.get(q + "edge_norm.weight", F); const float* be = bl.get(q + "edge_norm.bias", F);
         if (!W1 || !b1 || !W2 || !b2 || !g || !be) return bail(bl.err);
-        // input order [s_src(256) | s_dst(256) | ef(128) | d(32)] (vector_field.py:870-877)
-        B.put(uw.Wasd, pack(256, 256, [&](int k, int n) -> float { return n < 128 ? W1[(size_t)n * kin + k] : W1[(size_t)(n - 128) * kin + 256 + k]; }));
-        pack_linear(B, uw.W1, W1, 128, kin, 160, 128, [&](int k) { return 512 + k; });
-        pad_vec(B, uw.b1, b1, 128, 128);
-        pack_linear(B, uw.W2, W2, 128, 128, 128, 128, ident);
-        pad_vec(B, uw.b2, b2, 128, 128);
-        pad_vec(B, uw.ln_g, g, 128, 128); pad_vec(B, uw.ln_b, be, 128, 128);
+        // input order [s_src(S) | s_dst(S) | ef(F) | d(32)] (vector_field.py:870-877); tile: Asd = [W1_src s | W1_dst s] (2 x 128 columns)
+        B.put(uw.Wasd, pack(256, 256, [&](int k, int n) -> float {
+            const int o = n < 128 ? n : n - 128;
+            if (k >= S || o >= F) return 0.f;
+            return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
+        pack_linear(B, uw.W1, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : 2 * S + F + (k - 128); });
+        pad_vec(B, uw.b1, b1, F, 128);
+        pack_linear(B, uw.W2, W2, F, F, 128, 128, ident);
+        pad_vec(B, uw.b2, b2, F, 128);
+        pad_vec(B, uw.ln_g, g, F, 128); pad_vec(B, uw.ln_b, be, F, 128);
     }
     // ---- output heads
     {
-        const float* W1 = bl.get("node_output_head.0.weight", 256, 256); const float* b1 = bl.get("node_output_head.0.bias", 256);
-        const float* W2 = bl.get("node_output_head.2.weight", na + nc, 256); const float* b2 = bl.get("node_output_head.2.bias", na + nc);
-        const float* E1 = bl.get("to_edge_logits.0.weight", 128, 128); const float* eb1 = bl.get("to_edge_logits.0.bias", 128);
-        const float* E2 = bl.get("to_edge_logits.2.weight", ne, 128); const float* eb2 = bl.get("to_edge_logits.2.bias", ne);
+        const float* W1 = bl.get("node_output_head.0.weight", S, S); const float* b1 = bl.get("node_output_head.0.bias", S);
+        const float* W2 = bl.get("node_output_head.2.weight", na + nc, S); const float* b2 = bl.get("node_output_head.2.bias", na + nc);
+        const float* E1 = bl.get("to_edge_logits.0.weight", F, F); const float* eb1 = bl.get("to_edge_logits.0.bias", F);
+        const float* E2 = bl.get("to_edge_logits.2.weight", ne, F); const float* eb2 = bl.get("to_edge_logits.2.bias", ne);
         if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
         c->node_head.K1p = 256; c->node_head.H = 256; c->node_head.O = pad16(na + nc);
-        pack_linear(B, c->node_head.W1, W1, 256, 256, 256, 256, ident); pad_vec(B, c->node_head.b1, b1, 256, 256);
-        pack_linear(B, c->node_head.W2, W2, na + nc, 256, 256, pad16(na + nc), ident); pad_vec(B, c->node_head.b2, b2, na + nc, pad16(na + nc));
+        pack_linear(B, c->node_head.W1, W1, S, S, 256, 256, ident); pad_vec(B, c->node_head.b1, b1, S, 256);
+        pack_linear(B, c->node_head.W2, W2, na + nc, S, 256, pad16(na + nc), ident); pad_vec(B, c->node_head.b2, b2, na + nc, pad16(na + nc));
         c->edge_head.K1p = 128; c->edge_head.H = 128; c->edge_head.O = 16;
-        pack_linear(B, c->edge_head.W1, E1, 128, 128, 128, 128, ident); pad_vec(B, c->edge_head.b1, eb1, 128, 128);
-        pack_linear(B, c->edge_head.W2, E2, ne, 128, 128, 16, ident); pad_vec(B, c->edge_head.b2, eb2, ne, 16);
+        pack_linear(B, c->edge_head.W1, E1, F, F, 128, 128, ident); pad_vec(B, c->edge_head.b1, eb1, F, 128);
+        pack_linear(B, c->edge_head.W2, E2, ne, F, 128, 16, ident); pad_vec(B, c->edge_head.b2, eb2, ne, 16);
     }
     // ---- upload
     c->arena_bytes = B.A.h.size() * sizeof(float);
@@ -624,6 +714,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge_forced = atoi(e1);
     if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node_forced = atoi(e2);
     if (const char* e4 = getenv("FM_XCD_SWIZZLE")) c->xcd_swizzle = atoi(e4);
+    if (const char* e5 = getenv("FM_FUSE_NODE")) c->fuse_node = atoi(e5);
     if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
     if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
@@ -635,15 +726,19 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cus = prop.multiProcessorCount;
     }
-#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_>, lds_gvp(V_, T_, false)); \
+#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true>, lds_gvp(V_, T_, false)); \
     set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
     FM_SET(32, 16) FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 16) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
+#define FM_SETH(V_, T_, H_) set_lds(fm_k_edge_message<V_, T_, 512, H_>, lds_gvp(V_, T_, true, H_)); set_lds(fm_k_dst_proj<V_, T_, H_>, lds_gvp(V_, T_, false));
+    FM_SETH(16, 16, 4) FM_SETH(16, 32, 4) FM_SETH(32, 16, 8) FM_SETH(32, 32, 8)
+#undef FM_SETH
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
-    set_lds(fm_k_edge_update<32>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64>, lds_edge_upd(64));
+    set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max);
+    set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>, mlp_max);
     *out = c;
     return FM_OK;
 }
@@ -660,8 +755,8 @@ int fm_destroy(fm_ctx* c) {
 struct WsLayout {
     int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
-        off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_stab, off_tabin, off_bx, off_ba,
-        off_bc, off_be, off_sa1, off_sc1, off_se1, total;
+        off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_Psd, off_PVd, off_stab, off_bx, off_ba,
+        off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, total;
 };
 
 static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
@@ -680,7 +775,9 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
     // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
     w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
+    if (c->HX && (w.tm_edge > 32)) w.tm_edge = 32;
     w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 31) / 32 <= c->n_cus ? 16 : 32);
+    if (c->HX && (w.tm_node > 32)) w.tm_node = 32;
     w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
@@ -691,10 +788,13 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.off_pe0 = take((size_t)w.U * 4); w.off_pe1 = take((size_t)w.U * 4); w.off_pair_mol = take((size_t)w.U * 4);
     w.off_s = take((size_t)N * 256 * 4); w.off_v = take((size_t)N * 3 * V * 4); w.off_xw = take((size_t)N * 3 * 4);
     w.off_ef = take((size_t)E * 128 * 4);
-    w.off_Ps = take((size_t)N * 256 * 4); w.off_Asd = take((size_t)N * 256 * 4); w.off_PV = take((size_t)N * 3 * (V + 16) * 4);
+    w.off_Ps = take((size_t)N * 256 * 4); w.off_Asd = take((size_t)N * 256 * 4); w.off_PV = take((size_t)N * 3 * c->PVW * 4);
+    w.off_Psd = take(c->HX ? (size_t)N * 256 * 4 : 0); w.off_PVd = take(c->HX ? (size_t)N * 3 * c->PVW * 4 : 0);
     w.off_part_s = take((size_t)N * w.P * 256 * 4); w.off_part_v = take((size_t)N * w.P * 3 * V * 4);
-    w.off_stab = take((size_t)align_up(w.tab_rows, FM_TM) * 256 * 4); w.off_tabin = take((size_t)w.tab_rows * w.tab_kp * 4);
+    w.off_stab = take((size_t)align_up(w.tab_rows, FM_TM) * 256 * 4);
     w.off_bx = take((size_t)N * 3 * 4); w.off_ba = take((size_t)N * c->na * 4); w.off_bc = take((size_t)N * c->nc * 4); w.off_be = take((size_t)w.U * c->ne * 4);
+    w.off_tap_s = take((size_t)N * 256 * 4); w.off_tap_v = take((size_t)N * 3 * V * 4);
+    w.off_gid = take((size_t)B * 4);
     w.off_sa1 = take((size_t)N * 4); w.off_sc1 = take((size_t)N * 4); w.off_se1 = take((size_t)w.U * 4);
     w.total = o;
     return FM_OK;
@@ -726,7 +826,12 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     FM_HIP(c, hipMemcpyAsync(base + w.off_mol_node, no, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
     FM_HIP(c, hipMemcpyAsync(base + w.off_mol_edge, eo, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
     FM_HIP(c, hipMemcpyAsync(base + w.off_mol_pair, po, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
-    FM_HIP(c, hipStreamSynchronize(st));
+    {
+        std::vector<int32_t> ids(B);
+        for (int i = 0; i < B; ++i) ids[i] = i;
+        FM_HIP(c, hipMemcpyAsync(base + w.off_gid, ids.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+        FM_HIP(c, hipStreamSynchronize(st));
+    }
     FmBatch& b = c->b;
     b.B = B; b.N = w.N; b.E = w.E; b.U = w.U; b.P = w.P;
     b.mol_node_off = (const int*)(base + w.off_mol_node); b.mol_edge_off = (const int*)(base + w.off_mol_edge); b.mol_pair_off = (const int*)(base + w.off_mol_pair);
@@ -736,8 +841,11 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     c->s = (float*)(base + w.off_s); c->v = (float*)(base + w.off_v); c->xw = (float*)(base + w.off_xw); c->ef = (float*)(base + w.off_ef);
     c->Ps = (float*)(base + w.off_Ps); c->Asd = (float*)(base + w.off_Asd); c->PV = (float*)(base + w.off_PV);
     c->part_s = (float*)(base + w.off_part_s); c->part_v = (float*)(base + w.off_part_v);
-    c->s_tab = (float*)(base + w.off_stab); c->tab_in = (float*)(base + w.off_tabin);
+    c->Psd = (float*)(base + w.off_Psd); c->PVd = (float*)(base + w.off_PVd);
+    c->s_tab = (float*)(base + w.off_stab);
     c->boot.x = (float*)(base + w.off_bx); c->boot.a = (float*)(base + w.off_ba); c->boot.c = (float*)(base + w.off_bc); c->boot.e = (float*)(base + w.off_be);
+    c->tap_s = (float*)(base + w.off_tap_s); c->tap_v = (float*)(base + w.off_tap_v);
+    c->mol_gid = (int*)(base + w.off_gid);
     c->sa1 = (int32_t*)(base + w.off_sa1); c->sc1 = (int32_t*)(base + w.off_sc1); c->se1 = (int32_t*)(base + w.off_se1);
     c->n_tiles_e = (w.E + FM_TM - 1) / FM_TM; c->n_tiles_n = (w.N + FM_TM - 1) / FM_TM; c->n_tiles_u = (w.U + FM_TM - 1) / FM_TM;
     Launch L{c, st};
@@ -756,16 +864,35 @@ int fm_remove_com(fm_ctx* c, void* stream, float* x) {
     return L.rc;
 }
 
+int fm_set_molecule_ids(fm_ctx* c, void* stream, const int32_t* ids_host) {
+    if (!c) return fail(c, FM_ERR_INVALID, "fm_set_molecule_ids: null context");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_set_molecule_ids: no batch bound");
+    std::vector<int32_t> ids(c->b.B);
+    for (int i = 0; i < c->b.B; ++i) ids[i] = ids_host ? ids_host[i] : i;
+    FM_HIP(c, hipMemcpyAsync(c->mol_gid, ids.data(), (size_t)c->b.B * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FM_HIP(c, hipStreamSynchronize((hipStream_t)stream));        // `ids` is pageable host memory about to go out of scope
+    return FM_OK;
+}
+
+int fm_prior_philox(fm_ctx* c, void* stream, uint64_t seed, float* x0) {
+    if (!c || !x0) return fail(c, FM_ERR_INVALID, "fm_prior_philox: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_prior_philox: no batch bound");
+    Launch L{c, (hipStream_t)stream};
+    L("prior_philox", fm_k_prior_philox, dim3(c->b.B), dim3(64), 0, x0, (const int*)c->b.mol_node_off, (const int*)c->mol_gid,
+      (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32));
+    return L.rc;
+}
+
 int fm_forward(fm_ctx* c, void* stream, const fm_state* state, const float* temb, const fm_dst* prev, int bootstrap, int remove_com,
                const fm_dst* out) {
     if (!c || !state || !temb || !out) return fail(c, FM_ERR_INVALID, "fm_forward: null argument");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_forward: no batch bound");
-    return forward_impl(c, (hipStream_t)stream, state, temb, prev, bootstrap, remove_com, out);
+    return forward_impl(c, (hipStream_t)stream, state, temb, prev, bootstrap, remove_com ? 1 : 0, out);
 }
 
 int fm_ctmc_step(fm_ctx* c, void* stream, const fm_state* state, const fm_dst* dst, const fm_step_noise* noise, const fm_step_scalars* sc,
                  const fm_sampled* sampled) {
-    if (!c || !state || !dst || !noise || !sc) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: null argument");
+    if (!c || !state || !dst || !sc) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: null argument");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_ctmc_step: no batch bound");
     return ctmc_impl(c, (hipStream_t)stream, state, dst, noise, sc, sampled);
 }
@@ -773,7 +900,7 @@ int fm_ctmc_step(fm_ctx* c, void* stream, const fm_state* state, const fm_dst* d
 int fm_integrate(fm_ctx* c, void* stream, const fm_state* state, int n_steps, const fm_step_scalars* steps, const float* temb,
                  const fm_step_noise* noise, const fm_dst* prev0, const fm_dst* dst_a, const fm_dst* dst_b, const fm_traj_sink* sink,
                  int* final_dst) {
-    if (!c || !state || !steps || !temb || !noise || !dst_a || !dst_b) return fail(c, FM_ERR_INVALID, "fm_integrate: null argument");
+    if (!c || !state || !steps || !temb || !dst_a || !dst_b) return fail(c, FM_ERR_INVALID, "fm_integrate: null argument");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_integrate: no batch bound");
     hipStream_t st = (hipStream_t)stream;
     const int tt = c->cfg.time_embedding_dim;
@@ -783,7 +910,9 @@ int fm_integrate(fm_ctx* c, void* stream, const fm_state* state, int n_steps, co
     for (int i = 0; i < n_steps; ++i) {
         const fm_dst* out = cur == 0 ? dst_a : dst_b;
         const int boot = (!prev && steps[i].t == 0.0f) ? 1 : 0;      // prev is None and (t == 0).all(), vector_field.py:269-272
-        int rc = forward_impl(c, st, state, temb + (size_t)i * tt, prev, boot, 1, out);
+        // campbell steps: the COM removal of the endpoint positions runs inside the fused CTMC kernel (one launch and one copy less)
+        const bool defer_com = steps[i].dfm_type == FM_DFM_CAMPBELL;
+        int rc = forward_impl(c, st, state, temb + (size_t)i * tt, prev, boot, defer_com ? 2 : 1, out);
         if (rc) return rc;
         fm_sampled smp{};
         if (sink) {
@@ -791,7 +920,7 @@ int fm_integrate(fm_ctx* c, void* stream, const fm_state* state, int n_steps, co
             smp.c1 = sink->c1 ? sink->c1 + (size_t)i * b.N : nullptr;
             smp.e1 = sink->e1 ? sink->e1 + (size_t)i * b.U : nullptr;
         }
-        rc = ctmc_impl(c, st, state, out, &noise[i], &steps[i], &smp);
+        rc = ctmc_impl(c, st, state, out, noise ? &noise[i] : nullptr, &steps[i], &smp, defer_com ? c->xw : nullptr);
         if (rc) return rc;
         if (sink) {
             Launch L{c, st};

@@ -74,7 +74,7 @@ struct FmMlpArgs {
     int ldx, ldh;             // LDS leading dims ((ld/4) odd, ldx >= max(K1p, O), ldh >= H)
     const float2* W1; const float* b1;
     const float2* W2; const float* b2;
-    const float* ln_g; const float* ln_b;     // TABLE
+    const float* ln_g; const float* ln_b; int ln_n;     // TABLE: LayerNorm affine + the REAL width its statistics run over (<= O)
     // generic sources / destinations
     const float* in;  int in_ld;              // TABLE: dense input
     float* out; int out_ld;                   // TABLE / SC_NODE / heads
@@ -88,22 +88,33 @@ struct FmMlpArgs {
     const float* ef; const int* p_e0; const int* p_e1;                   // EDGE_HEAD
     const int* e_src; const int* e_dst; const int* e_pair; const int* tok_e;   // SC_EDGE
     const float* prev_e; const float* T1; const float* ef_tab;
+    // TABLE with in == null: rows are the (a,c) token pairs, x = [emb_a[a] | emb_c[c] | temb] (or one-hots when emb_* are null)
+    const float* emb_a; const float* emb_c; const float* temb; int ta, tc, tt;
 };
 
 template <int MODE>
-__global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
-    HIP_DYNAMIC_SHARED(float, lds)
+__device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float* lds) {
     float* X = lds;                         // [64][ldx]
     float* Hb = lds + FM_TM * a.ldx;        // [64][ldh]
     int* meta = reinterpret_cast<int*>(Hb + FM_TM * a.ldh);   // [64] token / row ids
     const int tid = threadIdx.x;
-    const int row0 = blockIdx.x * FM_TM;
+    const int row0 = tile * FM_TM;
 
     // ---------------- prologue: fill X[:, 0..K1p)
     if (MODE == FM_MLP_TABLE) {
         for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
-            const int r = idx / a.K1p, c = idx % a.K1p;
-            X[r * a.ldx + c] = (row0 + r < a.rows) ? a.in[(size_t)(row0 + r) * a.in_ld + c] : 0.f;
+            const int r = idx / a.K1p, c = idx % a.K1p, row = row0 + r;
+            float v = 0.f;
+            if (row < a.rows) {
+                if (a.in) v = a.in[(size_t)row * a.in_ld + c];
+                else {      // input row of the (a,c) embedding table, built in place (vector_field.py:228-243)
+                    const int ia = row / a.n_c1, ic = row % a.n_c1;
+                    if (c < a.ta) v = a.emb_a ? a.emb_a[ia * a.ta + c] : (c == ia ? 1.f : 0.f);
+                    else if (c < a.ta + a.tc) v = a.emb_c ? a.emb_c[ic * a.tc + (c - a.ta)] : ((c - a.ta) == ic ? 1.f : 0.f);
+                    else if (c < a.ta + a.tc + a.tt) v = a.temb[c - a.ta - a.tc];
+                }
+            }
+            X[r * a.ldx + c] = v;
         }
     } else if (MODE == FM_MLP_SC_NODE) {
         float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64] |x_t - x1_prev| per row
@@ -240,7 +251,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
     const int grow = row0 + r;
     if (MODE == FM_MLP_TABLE) {
         float mean, rstd;
-        fm_row_stats8(X + r * a.ldx, a.O, sub, mean, rstd);
+        fm_row_stats8(X + r * a.ldx, a.ln_n, sub, mean, rstd);
         if (grow < a.rows)
             for (int c = sub; c < a.O; c += 8)
                 a.out[(size_t)grow * a.out_ld + c] = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
@@ -294,6 +305,22 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
     }
 }
 
+template <int MODE>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    fm_mlp2_tile<MODE>(a, blockIdx.x, lds);
+}
+
+// Two independent MLP passes in ONE launch (node-side tiles first, then the pair-side tiles): the self-conditioning layers
+// (SC_NODE + SC_EDGE) and the output heads (NODE_HEAD + EDGE_HEAD) each depend on the same inputs only, so one kernel
+// boundary per pair is pure latency on the per-step critical path.
+template <int MODE_A, int MODE_B>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2_pair(FmMlpArgs a, FmMlpArgs b, int tiles_a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    if ((int)blockIdx.x < tiles_a) fm_mlp2_tile<MODE_A>(a, blockIdx.x, lds);
+    else fm_mlp2_tile<MODE_B>(b, (int)blockIdx.x - tiles_a, lds);
+}
+
 // gather-only initialisation when there is no self-conditioning input (bootstrap pass / non-SC models)
 __global__ void __launch_bounds__(256) fm_k_gather_rows(float* __restrict__ out, const float* __restrict__ tab, int width,
                                                          int rows, const int* __restrict__ tok_a, const int* __restrict__ tok_c,
@@ -319,6 +346,9 @@ struct FmProjArgs {
     const float2* Wps; float* Ps;         // null -> skip
     const float2* Wasd; float* Asd;       // null -> skip
     const float2* Wpv; float* PV;         // null -> skip
+    int pv_w;                             // PV row width (FmGvpTile::PVW of the edge-message instance: V+16 without destination features)
+    float* v_init;                        // non-null: the vector features start at zero (vector_field.py:246): use zeros AND write them
+    const float* x_src; float* x_dst;     // non-null: copy the tile's positions (working copy updated by NodePositionUpdate)
 };
 
 template <int V>
@@ -336,6 +366,10 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
         float* d = X + r * LDS_ + 4 * c4;
         *reinterpret_cast<float4*>(d) = val;        // one ds_write_b128 (16-B aligned: row pitch and column offset are multiples of 16 B)
     }
+    if (a.x_dst) {
+        const int i0 = row0 * 3, i1 = (row0 + FM_TM < a.N ? row0 + FM_TM : a.N) * 3;
+        for (int i = i0 + tid; i < i1; i += FM_THREADS) a.x_dst[i] = a.x_src[i];
+    }
     if (a.PV) {
         const int rows = a.N - row0 < FM_TM ? a.N - row0 : FM_TM;
         const auto rs_v = fm_buf(a.v + (size_t)row0 * 3 * V, (unsigned)rows * (3 * V * 4));
@@ -344,7 +378,12 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int idx = tid + k * FM_THREADS;
-            qv[k] = fm_buf_f32x4(rs_v, idx < NCHK ? idx * 16 : FM_BUF_OOB, 0);
+            if (a.v_init) {
+                qv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < rows * 3 * V4) reinterpret_cast<float4*>(a.v_init + (size_t)row0 * 3 * V)[idx] = qv[k];
+            } else {
+                qv[k] = fm_buf_f32x4(rs_v, idx < NCHK ? idx * 16 : FM_BUF_OOB, 0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -365,10 +404,62 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
             if (row0 + row < a.N) a.Asd[(size_t)(row0 + row) * 256 + col] = v;
         });
     if (a.PV)
-        fm_block_gemm<1, 1>(Vt, LDV, 12, V / 8, a.Wpv, (V + 16) / 16, [&](int row, int col, float v) {
+        fm_block_gemm<1, 1>(Vt, LDV, 12, V / 8, a.Wpv, a.pv_w / 16, [&](int row, int col, float v) {
             const int c = row / FM_TM, r = row % FM_TM;
-            if (row0 + r < a.N) a.PV[((size_t)(row0 + r) * 3 + c) * (V + 16) + col] = v;
+            if (row0 + r < a.N) a.PV[((size_t)(row0 + r) * 3 + c) * a.pv_w + col] = v;
         });
+}
+
+// ------------------------------------------------------------------------------------------------
+// use_dst_feats (gvp.py:300-316, 472-473): per node, the projection GVP (V -> VD vectors, S -> S/r scalars, no cross
+// products) of the conv's input features, followed at once by the per-node hoists of the first edge GVP's destination terms:
+//   Psd = s_dst_msg * Ws[:, dst columns]   (256)        added to the scalar-linear accumulators like Ps[src]
+//   PVd = v_dst_msg * [Wh | Wcp][dst rows] (per xyz: PVW) added to the hidden vectors like PV[src]
+// The GVP is fm_gvp_core with zero Wcp: its cross products are exactly 0 and their sh entries meet zero weights.
+// ------------------------------------------------------------------------------------------------
+struct FmDstProjArgs {
+    int N;
+    const float* s; const float* v;
+    FmGvpW g;
+    const float2* Wsd; float* Psd;
+    const float2* Wpvd; float* PVd; int pv_w;
+};
+
+template <int V, int TM, int VD>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_dst_proj(FmDstProjArgs a) {
+    typedef FmGvpTile<V, TM> T;
+    HIP_DYNAMIC_SHARED(float, lds)
+    float* X = lds;
+    float* Vin = X + T::X_FLOATS;
+    float* Vh = Vin + T::VIN_FLOATS;
+    float* G = Vh + T::VH_FLOATS;
+    const int tid = threadIdx.x, row0 = blockIdx.x * TM;
+    {
+        const int rows = a.N - row0 < TM ? a.N - row0 : TM;
+        const auto rs_s = fm_buf(a.s + (size_t)row0 * 256, (unsigned)rows * 1024u);
+        const auto rs_v = fm_buf(a.v + (size_t)row0 * 3 * V, (unsigned)rows * (3 * V * 4));
+        constexpr int V4 = V / 4, NCHK = TM * 3 * V4;
+        for (int idx = tid; idx < TM * 64; idx += FM_THREADS)
+            *reinterpret_cast<float4*>(X + (idx >> 6) * FM_LDX + (idx & 63) * 4) = fm_buf_f32x4(rs_s, idx * 16, 0);
+        for (int idx = tid; idx < NCHK; idx += FM_THREADS) {
+            const int r = idx / (3 * V4), rem = idx % (3 * V4), c = rem / V4, u4 = rem % V4;
+            *reinterpret_cast<float4*>(Vin + (c * TM + r) * T::LDVI + u4 * 4) = fm_buf_f32x4(rs_v, idx * 16, 0);
+        }
+    }
+    __syncthreads();
+    {
+        FM_MARK_DECL
+        float pre[TM / 16][2][4];
+        fm_gvp_core<V, VD, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g, pre FM_MARK_PASS(50));
+    }
+    constexpr int MT = TM / 16;
+    fm_block_gemm<MT, 2>(X, FM_LDX, MT, 32, a.Wsd, 16, [&](int row, int col, float val) {
+        if (row0 + row < a.N) a.Psd[(size_t)(row0 + row) * 256 + col] = val;
+    });
+    fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * MT, 1, a.Wpvd, a.pv_w / 16, [&](int row, int col, float val) {      // K = 8 >= VD (columns VD.. of Vin are 0)
+        const int c = row / TM, r = row % TM;
+        if (row0 + r < a.N) a.PVd[((size_t)(row0 + r) * 3 + c) * a.pv_w + col] = val;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -382,8 +473,10 @@ struct FmMsgArgs {
     const float* x;           // (N,3) positions used for distances
     const float* ef;          // (E,128)
     const float* Ps;          // (N,256)
-    const float* PV;          // (N,3,V+16)
-    const float* w0;          // (V+16): [Wh[0,:] | 0.. | Wcp[0,:]]  row of the displacement vector
+    const float* PV;          // (N,3,PVW)
+    const float* w0;          // (PVW): [Wh[0,:] | 0.. | Wcp[0,:]]  row of the displacement vector
+    const float* Psd;         // (N,256)   use_dst_feats: W_s * s_dst_msg[dst], added like Ps[src]        (null otherwise)
+    const float* PVd;         // (N,3,PVW) use_dst_feats: hidden-vector contribution of v_dst_msg[dst]    (null otherwise)
     FmGvpW g0, g1, g2;
     float* part_s;            // (N, P, 256)
     float* part_v;            // (N, P, 3, V)
@@ -392,9 +485,9 @@ struct FmMsgArgs {
     int xcd_chunk;            // > 0: workgroup b handles tile (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk); 0: tile = b
 };
 
-template <int V, int TM, int NTH>
+template <int V, int TM, int NTH, int HX>
 __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
-    typedef FmGvpTile<V, TM> T;
+    typedef FmGvpTile<V, TM, HX> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
     float* Vin = X + T::X_FLOATS;
@@ -444,23 +537,29 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     //     L2 latency overlaps the fill below and the first phases of the GVP (VMEM returns in order, so a request
     //     placed right before the GEMM would stall the GEMM's first weight fragments behind it)
     float pre[TM / 16][1024 / NTH][4];
-    if (!(FM_ABLATE & 16)) fm_gather_pre<TM, NTH>(pre, a.Ps, a.b.N, m_src);
+    if (!(FM_ABLATE & 16)) fm_gather_pre<TM, NTH, false>(pre, a.Ps, a.b.N, m_src);
     else { for (auto& p1 : pre) for (auto& p2 : p1) for (auto& p3 : p2) p3 = 0.25f; }
+    if (HX > 0) fm_gather_pre<TM, NTH, true>(pre, a.Psd, a.b.N, m_dst);       // + the destination node's hoisted scalar term
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):
     //     a branchy load-use-store loop serialises one L2 round trip per iteration (profiles/r01d: 37k cycles here).
     {
         // thread -> (row chunk q, column j of a 16-wide block); chunk = (xyz c, block cb, row r).  With TM*16 == NTH the
         // chunk's (c, cb) is the unrolled loop index and r = q, so every address is one VGPR + an immediate.
-        constexpr int CB = (V + 16) / 16, NCH = 3 * CB * TM, QN = NTH / 16, NP = (NCH + QN - 1) / QN;
+        constexpr int PVW = T::PVW, CB = PVW / 16, NCH = 3 * CB * TM, QN = NTH / 16, NP = (NCH + QN - 1) / QN;
         const int q = tid >> 4, j = tid & 15;
-        const auto rs = fm_buf(a.PV, (unsigned)a.b.N * (unsigned)(3 * (V + 16) * 4));
+        const auto rs = fm_buf(a.PV, (unsigned)a.b.N * (unsigned)(3 * PVW * 4));
+        const auto rsd = fm_buf(HX > 0 ? a.PVd : a.PV, (unsigned)a.b.N * (unsigned)(3 * PVW * 4));
         float pv[NP], w0v[NP];
 #pragma unroll
         for (int p_ = 0; p_ < NP; ++p_) {
             const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
             const int sidx = (NCH % QN == 0 || ch < NCH) ? m_src[r] : -1;
-            pv[p_] = (FM_ABLATE & 16) ? 0.5f : fm_buf_f32(rs, sidx >= 0 ? sidx * (3 * (V + 16) * 4) + j * 4 : FM_BUF_OOB, (c * (V + 16) + cb * 16) * 4);
+            pv[p_] = (FM_ABLATE & 16) ? 0.5f : fm_buf_f32(rs, sidx >= 0 ? sidx * (3 * PVW * 4) + j * 4 : FM_BUF_OOB, (c * PVW + cb * 16) * 4);
+            if (HX > 0) {        // v_dst_msg[dst] * Wh / Wcp rows of the destination vectors, hoisted per node like PV
+                const int didx = (NCH % QN == 0 || ch < NCH) ? m_dst[r] : -1;
+                pv[p_] += fm_buf_f32(rsd, didx >= 0 ? didx * (3 * PVW * 4) + j * 4 : FM_BUF_OOB, (c * PVW + cb * 16) * 4);
+            }
             w0v[p_] = a.w0[cb * 16 + j];
         }
 #pragma unroll
@@ -481,9 +580,9 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     }
     __syncthreads();
     FM_MARK(1);
-    fm_gvp_core<V, V, true, true, TM, NTH>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
-    fm_gvp_core<V, V, false, true, TM, NTH>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
-    fm_gvp_core<V, V, false, true, TM, NTH>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
+    fm_gvp_core<V, V, true, true, TM, NTH, HX>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
+    fm_gvp_core<V, V, false, true, TM, NTH, HX>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
+    fm_gvp_core<V, V, false, true, TM, NTH, HX>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
 
     if (a.dbg_s) {
         for (int idx = tid; idx < TM * 256; idx += NTH) {
@@ -550,18 +649,26 @@ struct FmNodeUpdArgs {
     FmGvpW g0, g1, g2;
     const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
     float* agg_s; float* agg_v;      // optional debug taps of the aggregated messages, else null
+    // Fused tail, every part optional (null = skip).  The updated (s, v) tile is still in LDS, so everything that depends only
+    // on it runs here instead of in launches of its own that would re-read it: the hoisted per-node projections of the NEXT
+    // conv's edge messages (Ps, PV) and of this conv's EdgeUpdate (Asd), and NodePositionUpdate (vector_field.py:813-842).
+    const float2* Wps; float* Ps;
+    const float2* Wpv; float* PV;
+    const float2* Wasd; float* Asd;
+    FmGvpW p0, p1, p2; float* x;     // x != null: x += GVP3(GVP2(GVP1(s, v))).v[:, 0]
+    int s_real;                      // NARROW instances: real scalar width (< 256); the LayerNorm statistics run over it
 };
 
 // GVPLayerNorm of a tile held in X[:, 0..255] / Vin (gvp.py:169-184); result written to LDS in place and,
 // when out_s/out_v are given, to HBM.
 template <int V, int TM>
 __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, const float* g, const float* b_,
-                                                      int row0, int nrows, float* out_s, float* out_v) {
+                                                      int row0, int nrows, float* out_s, float* out_v, int s_width = 256) {
     typedef FmGvpTile<V, TM> T;
     constexpr int LPR = FM_THREADS / TM;          // lanes per row
     const int tid = threadIdx.x, r = tid / LPR, sub = tid % LPR;
     float mean, rstd;
-    fm_row_stats<LPR>(X + r * FM_LDX, 256, sub, mean, rstd);
+    fm_row_stats<LPR>(X + r * FM_LDX, s_width, sub, mean, rstd);      // zero-padded columns beyond s_width stay 0: gain and bias are padded with 0
     // vector norm: vn = sqrt(mean_c max(|v_c|^2, 1e-8) + eps) + eps
     float q = 0.f;
     for (int u = sub; u < V; u += LPR) {
@@ -588,7 +695,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     __syncthreads();
 }
 
-template <int V, int TM>
+template <int V, int TM, bool NARROW>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) {
     typedef FmGvpTile<V, TM> T;
     HIP_DYNAMIC_SHARED(float, lds)
@@ -663,7 +770,8 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         }
     }
     __syncthreads();
-    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v);     // s1, v1 -> HBM (needed for the residual)
+    const int s_width = NARROW ? a.s_real : 256;
+    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v, s_width);     // s1, v1 -> HBM (needed for the residual)
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
@@ -695,7 +803,34 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         }
     }
     __syncthreads();
-    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v);
+    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v, s_width);       // ends with a barrier: X = s, Vin = v
+    // ---- fused tail: projections first (they only read the tile), then the position GVPs (which overwrite it)
+    constexpr int MT = TM / 16;
+    if (a.Ps)
+        fm_block_gemm<MT, 2>(X, FM_LDX, MT, 32, a.Wps, 16, [&](int row, int col, float val) {
+            if (row0 + row < N) a.Ps[(size_t)(row0 + row) * 256 + col] = val;
+        });
+    if (a.Asd)
+        fm_block_gemm<MT, 2>(X, FM_LDX, MT, 32, a.Wasd, 16, [&](int row, int col, float val) {
+            if (row0 + row < N) a.Asd[(size_t)(row0 + row) * 256 + col] = val;
+        });
+    if (a.PV)
+        fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * MT, V / 8, a.Wpv, (V + 16) / 16, [&](int row, int col, float val) {
+            const int c = row / TM, r = row % TM;
+            if (row0 + r < N) a.PV[((size_t)(row0 + r) * 3 + c) * (V + 16) + col] = val;
+        });
+    if (a.x) {
+        __syncthreads();                     // every wave has read the tile for the projections
+        FM_MARK_DECL
+        float pre[TM / 16][2][4];
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, 1, false, false, TM, FM_THREADS>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
+        if (tid < TM * 3) {
+            const int r = tid / 3, c = tid % 3, n = row0 + r;
+            if (n < N) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,9 +906,10 @@ struct FmEdgeUpdArgs {
     const float2* W2; const float* b2;      // K = 128, N = 128
     const float* ln_g; const float* ln_b;
     float rbf_mu_step, rbf_inv_sigma;
+    int f_real;                // NARROW instances: real edge-feature width (< 128) of the LayerNorm statistics
 };
 
-template <int TM>
+template <int TM, bool NARROW>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int LDX = 164, LDH = 132, MT = TM / 16, LPR = FM_THREADS / TM;
@@ -854,7 +990,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     __syncthreads();
     const int r = tid / LPR, sub = tid % LPR;
     float mean, rstd;
-    fm_row_stats<LPR>(X + r * LDX, 128, sub, mean, rstd);
+    fm_row_stats<LPR>(X + r * LDX, NARROW ? a.f_real : 128, sub, mean, rstd);
 #pragma unroll
     for (int j = 0; j < 32 / LPR; ++j) {
         const int c = (j * LPR + sub) * 4;
@@ -872,22 +1008,6 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
 // ------------------------------------------------------------------------------------------------
 // small element-wise kernels
 // ------------------------------------------------------------------------------------------------
-// rows of the (a,c) embedding-table input: [emb_a[a] | emb_c[c] | temb]  or  [onehot(a) | onehot(c) | t]
-__global__ void __launch_bounds__(256) fm_k_embed_in(float* __restrict__ out, int ld, int n_a1, int n_c1, int ta, int tc, int tt,
-                                                      const float* __restrict__ emb_a, const float* __restrict__ emb_c,
-                                                      const float* __restrict__ temb) {
-    const int rows = n_a1 * n_c1;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rows * ld; idx += gridDim.x * blockDim.x) {
-        const int row = idx / ld, c = idx % ld;
-        const int ia = row / n_c1, ic = row % n_c1;
-        float v = 0.f;
-        if (c < ta) v = emb_a ? emb_a[ia * ta + c] : (c == ia ? 1.f : 0.f);
-        else if (c < ta + tc) v = emb_c ? emb_c[ic * tc + (c - ta)] : ((c - ta) == ic ? 1.f : 0.f);
-        else if (c < ta + tc + tt) v = temb[c - ta - tc];
-        out[idx] = v;
-    }
-}
-
 // x -= per-molecule mean (vector_field.py:347-350); one 64-lane workgroup per molecule
 __global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, const int* __restrict__ mol_node_off) {
     const int m = blockIdx.x, lane = threadIdx.x;
@@ -909,6 +1029,29 @@ __global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, cons
         const float vf = fm_mul_rn(coef, fm_sub_rn(x1[i], x_t[i]));
         x_t[i] = fm_add_rn(x_t[i], fm_mul_rn(fm_mul_rn(dt, vf), scale));
     }
+}
+
+// Position prior of the Philox mode: x0 ~ N(0, I) per atom from the molecule's own stream (Box-Muller on draw block
+// (atom, 0xFFFFFFFF, 0)), then minus the molecule's mean (priors.py:27-35) -- one 64-lane workgroup per molecule.
+__global__ void __launch_bounds__(64) fm_k_prior_philox(float* __restrict__ x, const int* __restrict__ mol_node_off,
+                                                         const int* __restrict__ mol_gid, unsigned seed_lo, unsigned seed_hi) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const int n0 = mol_node_off[m], n1 = mol_node_off[m + 1];
+    const unsigned gid = (unsigned)mol_gid[m];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int n = n0 + lane; n < n1; n += 64) {
+        const FmPhilox4 rn = fm_philox4x32(gid, (unsigned)(n - n0), 0xFFFFFFFFu, 0u, seed_lo, seed_hi);
+        const float r0 = sqrtf(2.0f * fm_exp1(rn.v[0])), r1 = sqrtf(2.0f * fm_exp1(rn.v[2]));
+        const float t0 = 6.283185307179586f * fm_u01(rn.v[1]), t1 = 6.283185307179586f * fm_u01(rn.v[3]);
+        const float gx = r0 * cosf(t0), gy = r0 * sinf(t0), gz = r1 * cosf(t1);
+        x[n * 3] = gx; x[n * 3 + 1] = gy; x[n * 3 + 2] = gz;
+        sx += gx; sy += gy; sz += gz;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    const float inv = 1.0f / (float)(n1 - n0);
+    sx *= inv; sy *= inv; sz *= inv;
+    for (int n = n0 + lane; n < n1; n += 64) { x[n * 3] -= sx; x[n * 3 + 1] -= sy; x[n * 3 + 2] -= sz; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -938,14 +1081,36 @@ struct FmCtmcFusedArgs {
     float temp, hc_thresh;
     int last_step;
     float* x_t; const float* x1; const int* node_off; float coef, dt, scale;     // Euler step (fm_k_x_step)
+    int philox; unsigned seed_lo, seed_hi; int step; const int* mol_gid;      // philox != 0: q / u1 / u2 come from fm_philox4x32, not from memory
+    const float* x_raw; float* x1_out;   // x_raw != null: the network's raw endpoint positions; x1_out = x_raw - per-molecule mean
+                                         // (vector_field.py:347-350, arithmetic of fm_k_remove_com) is written first and used as x1
 };
 
 __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
     __shared__ int red[2][4];
     const int mol = blockIdx.x, job = blockIdx.y, tid = threadIdx.x;
     if (job == 3) {
-        const int i0 = a.node_off[mol] * 3, i1 = a.node_off[mol + 1] * 3;
-        for (int i = i0 + tid; i < i1; i += 256) {
+        const int n0 = a.node_off[mol], n1 = a.node_off[mol + 1];
+        if (a.x_raw) {
+            __shared__ float com[3];
+            if (tid < 64) {          // the 64-lane strided sum + xor tree of fm_k_remove_com: identical rounding
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+                for (int n = n0 + tid; n < n1; n += 64) { sx += a.x_raw[n * 3]; sy += a.x_raw[n * 3 + 1]; sz += a.x_raw[n * 3 + 2]; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+                const float inv = 1.0f / (float)(n1 - n0);
+                if (tid == 0) { com[0] = sx * inv; com[1] = sy * inv; com[2] = sz * inv; }
+            }
+            __syncthreads();
+            for (int i = n0 * 3 + tid; i < n1 * 3; i += 256) {
+                const float x1 = a.x_raw[i] - com[(i - n0 * 3) % 3];
+                a.x1_out[i] = x1;
+                const float vf = fm_mul_rn(a.coef, fm_sub_rn(x1, a.x_t[i]));
+                a.x_t[i] = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
+            }
+            return;
+        }
+        for (int i = n0 * 3 + tid; i < n1 * 3; i += 256) {
             const float vf = fm_mul_rn(a.coef, fm_sub_rn(a.x1[i], a.x_t[i]));
             a.x_t[i] = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
         }
@@ -953,9 +1118,19 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
     }
     const FmCtmcMod md = a.mod[job];
     const int r0 = md.off[mol], r1 = md.off[mol + 1], K = md.K;
+    const unsigned gid = a.philox ? (unsigned)a.mol_gid[mol] : 0u, ctr2 = (unsigned)a.step * 4u + (unsigned)job;
     int cm = 0, ch = 0;
     for (int i = r0 + tid; i < r1; i += 256) {
-        float lp[16];
+        float lp[16], qv[16];
+        if (a.philox) {            // draws 0..K-1 of this row's stream: Exp(1) for the categorical sample
+            for (int blk = 0; blk * 4 < K; ++blk) {
+                const FmPhilox4 rn = fm_philox4x32(gid, (unsigned)(i - r0), ctr2, (unsigned)blk, a.seed_lo, a.seed_hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[(blk * 4 + j) & 15] = fm_exp1(rn.v[j]);
+            }
+        } else {
+            for (int k = 0; k < K; ++k) qv[k] = md.q[(size_t)i * K + k];
+        }
         float mx = -INFINITY;
         for (int k = 0; k < K; ++k) { lp[k] = fm_div_rn(logf(md.p[(size_t)i * K + k]), a.temp); mx = fmaxf(mx, lp[k]); }
         float sum = 0.f;
@@ -964,7 +1139,7 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
         for (int k = 0; k < K; ++k) { lp[k] = fm_div_rn(lp[k], sum); purity = fmaxf(purity, lp[k]); psum = fm_add_rn(psum, lp[k]); }
         int best = 0; float bestv = -1.f;
         for (int k = 0; k < K; ++k) {
-            const float v = fm_div_rn(fm_div_rn(lp[k], psum), md.q[(size_t)i * K + k]);
+            const float v = fm_div_rn(fm_div_rn(lp[k], psum), qv[k]);
             if (v > bestv) { bestv = v; best = k; }
         }
         const bool masked = md.xt[i] == K;
@@ -991,15 +1166,23 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
         const int x1 = packed & 255;
         const int tok = md.xt[i];
         const bool masked = tok == K;
+        float u1, u2 = 1.f;
+        if (a.philox) {            // draws 16, 17 of the row's stream (block 4), clear of the <= 16 categorical draws
+            const FmPhilox4 rn = fm_philox4x32(gid, (unsigned)(i - r0), ctr2, 4u, a.seed_lo, a.seed_hi);
+            u1 = fm_u01(rn.v[0]); u2 = fm_u01(rn.v[1]);
+        } else {
+            u1 = md.u1[i];
+            if (!a.last_step) u2 = md.u2[i];
+        }
         bool will_unmask;
         if (a.hc_thresh > 0.f) {
             const float prob = masked ? ((packed & 256) ? ph : pl) : 0.f;
-            will_unmask = md.u1[i] < prob;           // comparisons against NaN are false, as in torch
+            will_unmask = u1 < prob;           // comparisons against NaN are false, as in torch
         } else {
-            will_unmask = (md.u1[i] < md.unmask_prob) && masked;
+            will_unmask = (u1 < md.unmask_prob) && masked;
         }
         int nt = tok;
-        if (!a.last_step) { if ((md.u2[i] < md.mask_prob) && !masked) nt = K; }
+        if (!a.last_step) { if ((u2 < md.mask_prob) && !masked) nt = K; }
         if (will_unmask) nt = x1;
         md.xt[i] = nt;
         md.x1[i] = x1;

@@ -15,7 +15,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (FM_DFM_CAMPBELL, FM_DFM_GAT, FlowMolHipError, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
+from ._lib import (FM_DFM_CAMPBELL, FM_DFM_GAT, FM_NOISE_PHILOX, FlowMolHipError, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
                    fm_tensor_desc, fm_traj_sink)
 from .config import VFConfig
 from .weights import check_state_dict, state_dict_shapes
@@ -76,7 +76,7 @@ def _f32(v) -> float:
 
 def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperature,
                    tspan: Optional[torch.Tensor] = None, dfm_type: str = 'campbell', forward_weight_func: Optional[Callable] = None,
-                   inv_temp_func: Optional[Callable] = None) -> StepPlan:
+                   inv_temp_func: Optional[Callable] = None, philox_seed: Optional[int] = None) -> StepPlan:
     """Per-step scalars of CTMCVectorField.integrate/step (ctmc_vector_field.py:169-178, 287-340), computed with the
     reference's own float32 tensor arithmetic.  ``cat_temperature`` is a number or a callable of the 0-dim tensor t_i."""
     t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32)
@@ -110,6 +110,12 @@ def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperatu
                 sc.gat_cf[k] = float(one / (1 - a_i))
                 sc.gat_cb[k] = float(one / (a_i + 1e-8))
             sc.gat_fw, sc.gat_bw = _f32(fw), _f32(bw)
+        if philox_seed is not None:        # noise drawn inside the CTMC kernel from per-molecule counter-based streams (fm_noise_mode)
+            if dfm_type != 'campbell':
+                raise NotImplementedError("the in-kernel Philox noise covers dfm_type='campbell'")
+            sc.noise_mode = FM_NOISE_PHILOX
+            sc.step_index = s_idx - 1
+            sc.philox_seed_lo, sc.philox_seed_hi = philox_seed & 0xffffffff, (philox_seed >> 32) & 0xffffffff
         out.append(sc)
     return StepPlan(t, out)
 
@@ -210,6 +216,7 @@ class Engine:
         c.a_token_dim, c.c_token_dim, c.e_token_dim = cfg.a_token_dim, cfg.c_token_dim, cfg.e_token_dim
         c.rbf_dmax = float(cfg.rbf_dmax)
         c.msg_z = float(cfg.msg_z)
+        c.s_dst_feats, c.v_dst_feats = cfg.s_dst_feats, cfg.v_dst_feats
         self._ctx = C.c_void_p()
         with self._dev():
             rc = self.lib.fm_create(C.byref(c), descs, len(shapes), C.c_void_p(blob.data_ptr()), C.byref(self._ctx))
@@ -330,6 +337,25 @@ class Engine:
             self._check(self.lib.fm_remove_com(self._ctx, self._stream(), _ptr(x)), 'fm_remove_com')
         return x
 
+    def set_molecule_ids(self, ids: Optional[torch.Tensor]):
+        """Global ids of the bound batch's molecules for the Philox noise streams (None = 0..B-1): a molecule keeps its id, and
+        therefore its draws, however the batch is sharded."""
+        if ids is None:
+            ptr = None
+        else:
+            ids = ids.detach().to('cpu', torch.int32).contiguous()
+            assert ids.shape == (self.B,)
+            ptr = C.c_void_p(ids.data_ptr())
+        with self._dev():
+            self._check(self.lib.fm_set_molecule_ids(self._ctx, self._stream(), ptr), 'fm_set_molecule_ids')
+
+    def prior_philox(self, seed: int) -> torch.Tensor:
+        """Centred Gaussian position prior (priors.py:27-35) from the per-molecule Philox streams."""
+        x0 = torch.empty(self.N, 3, device=self.device)
+        with self._dev():
+            self._check(self.lib.fm_prior_philox(self._ctx, self._stream(), C.c_uint64(seed), _ptr(x0)), 'fm_prior_philox')
+        return x0
+
     def stability(self, state, table: torch.Tensor, fake_atom_token: int = -1, explicit_aromaticity: bool = False) -> torch.Tensor:
         """Valence stability + connectivity of the bound batch's molecules from their tokens, on the device
         (see fm_stability).  table: (n_types, n_charges) int32 bit masks.  Returns (B,4) int32:
@@ -428,8 +454,11 @@ class IntegrationRun:
             b = min(hi, a + chunk)
             k = b - a
             scal = (fm_step_scalars * k)(*self.plan.scalars[a:b])
-            noises = [self.noise_for_step(i, bool(self.plan.scalars[i].last_step)) for i in range(a, b)]
-            nzs = (fm_step_noise * k)(*[nz.c_struct() for nz in noises])
+            if self.noise_for_step is None:        # Philox plan: the kernel draws its own noise
+                noises, nzs = None, None
+            else:
+                noises = [self.noise_for_step(i, bool(self.plan.scalars[i].last_step)) for i in range(a, b)]
+                nzs = (fm_step_noise * k)(*[nz.c_struct() for nz in noises])
             sink = None
             if self.traj is not None:
                 sink = fm_traj_sink()

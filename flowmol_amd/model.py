@@ -186,13 +186,17 @@ class FlowMol:
         ``noise='per_rank'``: each rank draws only its shard's noise from its own torch RNG stream (seed it per rank);
         results depend on the world size.  ``noise='replicated'`` (parity mode): every rank, seeded identically, draws the
         full batch's prior and per-step noise and keeps its molecules' rows, so the result reproduces the single-GPU
-        ``sample(n_atoms)`` with that seed (to float summation order), at world_size times the (cheap) RNG work.  Trajectories are not gathered."""
+        ``sample(n_atoms)`` with that seed (to float summation order), at world_size times the (cheap) RNG work.
+        ``noise='philox'`` (performance mode): prior and CTMC noise are drawn INSIDE the kernels from per-molecule Philox4x32-10
+        streams keyed by (seed, original molecule index, step, modality): no noise tensors at all, and every molecule's
+        trajectory is the same for any world size or batch composition (tokens identical; coordinates to float summation order).
+        Trajectories are not gathered."""
         import torch.distributed as dist
         from . import shard
         if kwargs.get('xt_traj') or kwargs.get('ep_traj') or kwargs.get('prior') is not None:
             raise NotImplementedError('sample_distributed gathers final states only (no trajectories / caller-supplied priors)')
-        if noise not in ('per_rank', 'replicated'):
-            raise ValueError(f"noise must be 'per_rank' or 'replicated', got {noise!r}")
+        if noise not in ('per_rank', 'replicated', 'philox'):
+            raise ValueError(f"noise must be 'per_rank', 'replicated' or 'philox', got {noise!r}")
         n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         parts = shard.partition_lpt(n_atoms, world)
@@ -203,6 +207,13 @@ class FlowMol:
             node_rows = shard._ranges((torch.cumsum(n_atoms, 0) - n_atoms)[mine], n_atoms[mine]).to(dev)
             pair_rows = shard._ranges((torch.cumsum(pairs, 0) - pairs)[mine], pairs[mine]).to(dev)
             kwargs['_rows'] = (int(n_atoms.sum()), int(pairs.sum()), node_rows, pair_rows)
+        if noise == 'philox':
+            # performance mode of SURVEY.md section 8e: per-molecule counter-based streams keyed by (seed, ORIGINAL molecule index, step,
+            # modality); rank 0's seed is broadcast; nothing but the shard's own noise is generated, and it is generated in-kernel
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+            sd = seed.to(dev if dist.get_backend(group) == 'nccl' else 'cpu')
+            dist.broadcast(sd, src=0, group=group)
+            kwargs.update(rng='philox', _philox=int(sd.item()), _mol_ids=parts[rank])
         if len(parts[rank]):
             local, _ = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors='device', **kwargs)   # stays in HBM
         else:
@@ -234,7 +245,7 @@ class FlowMol:
         dfm_type = kwargs.get('dfm_type') or self.cfg.dfm_type
         if dfm_type not in ('campbell', 'gat'):
             raise ValueError(f"Invalid dfm_type: {dfm_type}")
-        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows', '_noise_for_step'}
+        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows', '_noise_for_step', 'rng', '_philox', '_mol_ids'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         visualize = bool(xt_traj or ep_traj)
@@ -244,7 +255,22 @@ class FlowMol:
         cfg = self.cfg
         # ---- prior (flowmol.py:417-448 / 534-545)
         rows = kwargs.get('_rows')     # sample_distributed(noise='replicated'): (N_full, U_full, node rows, pair rows) of this shard
-        if prior is None:
+        # rng='philox': position prior and CTMC noise come from per-molecule counter-based streams inside the kernels (no noise
+        # tensors; results independent of batch composition / sharding).  rng='torch' (default): the reference's draws from torch's generator.
+        rng = kwargs.get('rng', 'torch')
+        if rng not in ('torch', 'philox'):
+            raise ValueError(f"rng must be 'torch' or 'philox', got {rng!r}")
+        philox_seed = None
+        if rng == 'philox':
+            if dfm_type != 'campbell' or rows is not None or kwargs.get('_noise_for_step') is not None:
+                raise NotImplementedError("rng='philox' covers the default campbell integrator")
+            philox_seed = kwargs.get('_philox')
+            if philox_seed is None:                       # one 62-bit seed per call from torch's CPU generator: torch.manual_seed controls it
+                philox_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            eng.set_molecule_ids(kwargs.get('_mol_ids'))
+        if prior is None and philox_seed is not None:
+            state = eng.prior_state(eng.prior_philox(philox_seed))
+        elif prior is None:
             x0 = torch.randn(N, 3, device=dev) if rows is None else torch.randn(rows[0], 3, device=dev)[rows[2]].contiguous()
             eng.remove_com(x0)
             state = eng.prior_state(x0)
@@ -255,7 +281,7 @@ class FlowMol:
         ctf = kwargs.get('cat_temp_func') or cat_temp_schedule(cfg)
         fwf = kwargs.get('forward_weight_func') or forward_weight_schedule(cfg)
         plan = make_step_plan(n_timesteps, eta, hc, ctf, tspan=kwargs.get('tspan'), dfm_type=dfm_type,
-                              forward_weight_func=fwf, inv_temp_func=kwargs.get('inv_temp_func'))
+                              forward_weight_func=fwf, inv_temp_func=kwargs.get('inv_temp_func'), philox_seed=philox_seed)
         n_steps = len(plan.scalars)
         traj = None
         if visualize:
@@ -276,7 +302,7 @@ class FlowMol:
         t0 = time.perf_counter()
         # _noise_for_step(i, last) -> StepNoise: recorded draws instead of torch's generator (parity tests drive the public API with
         # the oracle's RNG tape); never set by the product itself
-        eng.integrate(state, plan, kwargs.get('_noise_for_step') or noise_for_step, traj=traj)          # synchronises at the end
+        eng.integrate(state, plan, None if philox_seed is not None else (kwargs.get('_noise_for_step') or noise_for_step), traj=traj)          # synchronises at the end
         t1 = time.perf_counter()
         out_dev = {k: state[f'{k}_t'] for k in 'xace'}
         if return_tensors == 'device':

@@ -43,4 +43,27 @@ def qm9() -> VFConfig:
     return cfg.validate()
 
 
-PRESETS = {'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9}
+def dev_narrow() -> VFConfig:
+    """reference configs/dev.yml:78-108 WITHOUT its destination-node message features: 64 scalars / 64 edge features / 16 vector
+    channels, 3 molecule updates -- the narrow-model path (zero-padded tiles) on its own."""
+    return VFConfig(
+        atom_type_map=list(GEOM_ATOMS), fake_atoms=True,
+        n_vec_channels=16, n_cp_feats=4, n_hidden_scalars=64, n_hidden_edge_feats=64,
+        n_molecule_updates=3, convs_per_update=1, separate_mol_updaters=True,
+        message_norm='sum', update_edge_w_distance=True, rbf_dmax=10.0, rbf_dim=32,
+        time_embedding_dim=64, a_token_dim=64, c_token_dim=64, e_token_dim=64,
+        self_conditioning=True, stochasticity=20.0, high_confidence_threshold=0.9,
+        n_atoms_hist='geom_full_kekulized',
+    ).validate()
+
+
+def dev() -> VFConfig:
+    """reference configs/dev.yml:78-108: the narrow development model WITH destination-node message features
+    (use_dst_feats: True, dst_feat_msg_reduction_factor: 4 -> 16 scalars + 4 vectors of the destination join every message)."""
+    cfg = dev_narrow()
+    cfg.use_dst_feats = True
+    cfg.dst_feat_msg_reduction_factor = 4
+    return cfg.validate()
+
+
+PRESETS = {'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}

@@ -58,9 +58,12 @@ def state_dict_shapes(cfg: VFConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     d['edge_embedding.4.bias'] = (F,)
     for i in range(cfg.n_convs):
         p = f'conv_layers.{i}'
+        sd_, vd_ = cfg.s_dst_feats, cfg.v_dst_feats
+        if cfg.use_dst_feats:        # gvp.py:300-311: GVP(V -> V/r vectors, S -> S/r scalars, no cross-product features)
+            d.update(_gvp_shapes(f'{p}.dst_feat_msg_projection', V, vd_, S, sd_, 0))
         for g in range(cfg.n_message_gvps):
             if g == 0:
-                d.update(_gvp_shapes(f'{p}.edge_message.{g}', V + 1, V, S + R + F, S, ncp))
+                d.update(_gvp_shapes(f'{p}.edge_message.{g}', V + 1 + vd_, V, S + R + F + sd_, S, ncp))
             else:
                 d.update(_gvp_shapes(f'{p}.edge_message.{g}', V, V, S, S, ncp))
         for g in range(cfg.n_update_gvps):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 2
+#define FM_ABI_VERSION 3
 #define FM_MAX_CONVS 16
 
 typedef enum fm_status {
@@ -60,8 +60,8 @@ typedef struct fm_config {
     int32_t n_charges;
     int32_t n_bond_types;
     int32_t n_vec_channels;       /* 16 or 32 */
-    int32_t n_hidden_scalars;     /* 256 */
-    int32_t n_hidden_edge_feats;  /* 128 */
+    int32_t n_hidden_scalars;     /* 8..256 (flowmol3: 256, configs/dev.yml: 64); narrower models run on zero-padded 256-column tiles */
+    int32_t n_hidden_edge_feats;  /* 8..128 (flowmol3: 128, dev.yml: 64) */
     int32_t rbf_dim;              /* 32 */
     int32_t n_convs;
     int32_t n_updaters;
@@ -71,6 +71,10 @@ typedef struct fm_config {
     int32_t a_token_dim, c_token_dim, e_token_dim;   /* 0 = one-hot input */
     float rbf_dmax;
     float msg_z;                  /* divisor of the aggregated messages (1 for 'sum') */
+    /* --- ABI 3: use_dst_feats (flowmol/models/gvp.py:300-316,472-473,527-537): widths of the projected destination-node
+     * features that join every message's inputs; 0 / 0 = off */
+    int32_t s_dst_feats;          /* int(n_hidden_scalars / dst_feat_msg_reduction_factor) */
+    int32_t v_dst_feats;          /* int(n_vec_channels / dst_feat_msg_reduction_factor), <= 8 */
 } fm_config;
 
 /* one tensor of the reference state dict inside the host weight blob */
@@ -120,7 +124,16 @@ typedef struct fm_step_scalars {  /* host-computed with the reference's float32 
     float gat_cf[3];              /* a, c, e: alpha'/(1 - alpha)        (gat_step, ctmc_vector_field.py:481) */
     float gat_cb[3];              /* a, c, e: alpha'/(alpha + 1e-8)     (:488) */
     float gat_fw, gat_bw;         /* forward_weight_func(t_i) and forward_weight - 1 (:491-492) */
+    /* --- ABI 3: noise source of this step (campbell only).  FM_NOISE_TENSORS: the caller's fm_step_noise (the reference's draws,
+     * bit-exact parity mode).  FM_NOISE_PHILOX: drawn inside the kernel from Philox4x32-10 streams keyed by (philox_seed, global
+     * molecule id, step_index, modality, row) -- no noise tensors, and a molecule's trajectory does not depend on how the
+     * batch is sharded; fm_step_noise may then be NULL */
+    int32_t noise_mode;
+    int32_t step_index;
+    uint32_t philox_seed_lo, philox_seed_hi;
 } fm_step_scalars;
+
+enum fm_noise_mode { FM_NOISE_TENSORS = 0, FM_NOISE_PHILOX = 1 };
 
 typedef struct fm_sampled {       /* sampled endpoint tokens of a step ("*_1_pred"), optional (may be NULL) */
     int32_t* a1; int32_t* c1; int32_t* e1;
@@ -146,6 +159,11 @@ int fm_batch_bind(fm_ctx* ctx, void* stream, const int32_t* n_atoms_host, int n_
 /* x -= per-molecule mean, in place, for the bound batch: the centring step of the position prior
  * (centered_normal_prior_batched_graph, flowmol/data_processing/priors.py:27-35) */
 int fm_remove_com(fm_ctx* ctx, void* stream, float* x);
+
+/* Philox mode: global ids of the bound batch's molecules (host array of n_mols; NULL = 0..n_mols-1, the default after
+ * fm_batch_bind), and the position prior x0 ~ N(0, I) - per-molecule mean (priors.py:27-35) drawn from the same streams */
+int fm_set_molecule_ids(fm_ctx* ctx, void* stream, const int32_t* ids_host);
+int fm_prior_philox(fm_ctx* ctx, void* stream, uint64_t seed, float* x0);
 
 /* one network evaluation.  temb: device (time_embedding_dim) floats (raw t when dim == 1).
  * prev: previous endpoint for self-conditioning or NULL.  bootstrap != 0 reproduces the reference's

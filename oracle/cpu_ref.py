@@ -237,7 +237,7 @@ class OracleVF:
     def gvp(self, key, feats, vectors, vec_act='sigmoid'):
         """gvp.py:90-133 (vector_gating=True always on this path)."""
         p = self.p
-        ncp = self.cfg.n_cp_feats
+        ncp = self.cfg.n_cp_feats if (key + '.Wcp') in p else 0          # the destination-feature projection GVP has none (gvp.py:309)
         Vh = einsum('b v c, v h -> b h c', vectors, p[key + '.Wh'])
         if ncp > 0:
             Vcp = einsum('b v c, v p -> b p c', vectors, p[key + '.Wcp'])
@@ -267,10 +267,17 @@ class OracleVF:
         return xd / dij, rbf(dij.squeeze(1), D_max=self.cfg.rbf_dmax, D_count=self.cfg.rbf_dim)
 
     def conv(self, i, batch: Batch, s, v, ef, x_diff, d):
-        """GVPConv.forward / message, gvp.py:435-543 (no attention / compression / dst feats)."""
+        """GVPConv.forward / message, gvp.py:435-543 (no attention / compression); with use_dst_feats the projected
+        destination-node features join the message inputs (gvp.py:300-316, 472-473, 527-537)."""
         key = f'conv_layers.{i}'
-        vec = torch.cat([x_diff.unsqueeze(1), v[batch.src]], dim=1)
-        sca = torch.cat([s[batch.src], d, ef], dim=1)
+        vec = [x_diff.unsqueeze(1), v[batch.src]]
+        sca = [s[batch.src], d, ef]
+        if self.cfg.use_dst_feats:
+            s_dm, v_dm = self.gvp(f'{key}.dst_feat_msg_projection', s, v)
+            vec.append(v_dm[batch.dst])
+            sca.append(s_dm[batch.dst])
+        vec = torch.cat(vec, dim=1)
+        sca = torch.cat(sca, dim=1)
         for g in range(self.cfg.n_message_gvps):
             sca, vec = self.gvp(f'{key}.edge_message.{g}', sca, vec)
             if i == 0:

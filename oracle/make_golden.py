@@ -98,8 +98,8 @@ def gen_modules(ns, name, cfg, sd):
         out['edge1.ef'] = vf.edge_updaters[1](g, s, ef, d=d)
         gvp0 = vf.conv_layers[0].edge_message[0]
         R = cfg.rbf_dim
-        fs = torch.randn(7, S + R + F_, generator=gen)
-        fv = torch.randn(7, V + 1, 3, generator=gen)
+        fs = torch.randn(7, S + R + F_ + cfg.s_dst_feats, generator=gen)
+        fv = torch.randn(7, V + 1 + cfg.v_dst_feats, 3, generator=gen)
         o_s, o_v = gvp0((fs, fv))
         out['gvp0.in_s'], out['gvp0.in_v'], out['gvp0.out_s'], out['gvp0.out_v'] = fs, fv, o_s, o_v
         if cfg.self_conditioning:
@@ -459,7 +459,7 @@ def main():
     gen_ctmc_step(ns)
     gen_stability()
     gen_moldata()
-    for name in ('flowmol3', 'geom_ctmc', 'qm9'):
+    for name in ('flowmol3', 'geom_ctmc', 'qm9', 'dev'):       # dev = configs/dev.yml:78-108 (64/64/16 dims, use_dst_feats)
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, seed=0)
         gen_forward(ns, name, cfg, sd)

@@ -226,6 +226,7 @@ def build_reference_vf(ns, cfg, state_dict, **overrides):
         message_norm=cfg.message_norm, rbf_dmax=cfg.rbf_dmax, rbf_dim=cfg.rbf_dim,
         time_embedding_dim=cfg.time_embedding_dim, a_token_dim=cfg.a_token_dim,
         c_token_dim=cfg.c_token_dim, e_token_dim=cfg.e_token_dim,
+        use_dst_feats=cfg.use_dst_feats, dst_feat_msg_reduction_factor=cfg.dst_feat_msg_reduction_factor,
         **{'cat_temperature_schedule': cfg.cat_temperature, **overrides},
     )
     vf.load_state_dict(state_dict, strict=True)

@@ -167,3 +167,44 @@ def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path)
         for k in 'ace':
             assert torch.equal(res[r][k], single[k].to(res[r][k].dtype))
         torch.testing.assert_close(res[r]['x'], single['x'], rtol=1e-5, atol=1e-5)    # tile alignment changes the summation order
+
+
+def _philox_worker(rank, world, port, sizes, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pathlib import Path
+    import flowmol_amd as flowmol
+    from flowmol_amd import _lib
+    emu = _lib.load(Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so')
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu).to('cpu')
+    torch.manual_seed(55 + rank)           # different per-rank RNG state on purpose: only rank 0's broadcast seed matters
+    full, n = model.sample_distributed(torch.tensor(sizes), n_timesteps=3, return_tensors=True, noise='philox')
+    q.put((rank, {k: v.numpy().copy() for k, v in full.items()}))
+    dist.destroy_process_group()
+
+
+def test_sample_distributed_philox_is_independent_of_the_world_size(emu_lib_path):
+    """SURVEY.md §8e performance mode: with per-molecule Philox streams two ranks produce what one process produces with
+    the same seed -- identical tokens, coordinates to summation order -- while each rank generates only its own shard's noise."""
+    import flowmol_amd as flowmol
+    from flowmol_amd import _lib
+    sizes = [4, 6, 3, 5]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_philox_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=300) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+    for k in 'xace':
+        assert torch.equal(res[0][k], res[1][k])
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=_lib.load(emu_lib_path)).to('cpu')
+    torch.manual_seed(55)                  # rank 0's generator state -> the same broadcast seed
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    single, _ = model.sample(torch.tensor(sizes), n_timesteps=3, return_tensors=True, rng='philox', _philox=seed)
+    for k in 'ace':
+        assert torch.equal(res[0][k], single[k].to(res[0][k].dtype))
+    torch.testing.assert_close(res[0]['x'], single['x'], rtol=1e-5, atol=1e-5)

@@ -17,7 +17,9 @@ from parity_util import forward_compare
 
 @pytest.mark.parametrize('tile', [16, 32])
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False),
-                                               ('flowmol3', [3, 1, 2, 1], 0.5, True)])       # 1-atom molecules: no edges, no messages
+                                               ('flowmol3', [3, 1, 2, 1], 0.5, True),        # 1-atom molecules: no edges, no messages
+                                               ('dev_narrow', [5, 3, 6], 0.5, True), ('dev_narrow', [4, 7], 0.0, False),    # 64/64-wide model on zero-padded tiles
+                                               ('dev', [5, 3, 6], 0.5, True), ('dev', [4, 7, 1], 0.0, False)])             # configs/dev.yml incl. use_dst_feats
 def test_emulated_forward_matches_oracle(emu_lib, monkeypatch, name, sizes, t, prev, tile):
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
@@ -201,3 +203,60 @@ def test_emulated_ctmc_step_matches_reference_step(emu_lib, golden_dir, case):
     g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'ctmc_step.npz').items()}
     res = ctmc_step_golden(eng, cfg, g, case)
     assert all(v == 0 for v in res.values()), res
+
+
+def test_philox_noise_is_sharding_independent_and_well_distributed(emu_lib):
+    """rng='philox' (SURVEY.md §8e performance mode): prior + CTMC noise from per-molecule counter-based streams inside the
+    kernels.  (1) a molecule's result does not depend on which other molecules share its batch or where it sits in it;
+    (2) same seed -> same result, other seed -> different; (3) the in-kernel draws have the right distributions
+    (Exp(1) race = categorical sample of p; U(0,1) thresholds)."""
+    import flowmol_amd as flowmol
+    from flowmol_amd.engine import Engine, make_step_plan
+    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu_lib).to('cpu')
+    sizes = torch.tensor([4, 6, 3, 5])
+    full, _ = model.sample(sizes, n_timesteps=4, return_tensors=True, rng='philox', _philox=1234)
+    again, _ = model.sample(sizes, n_timesteps=4, return_tensors=True, rng='philox', _philox=1234)
+    other, _ = model.sample(sizes, n_timesteps=4, return_tensors=True, rng='philox', _philox=99)
+    for k in 'xace':
+        assert torch.equal(full[k], again[k])
+    assert not torch.equal(full['x'], other['x'])
+    noff = torch.cumsum(sizes, 0) - sizes
+    pairs = sizes * (sizes - 1) // 2
+    poff = torch.cumsum(pairs, 0) - pairs
+    sub_ids = torch.tensor([3, 1])                       # molecules 3 and 1, in another order, as a batch of their own
+    sub, _ = model.sample(sizes[sub_ids], n_timesteps=4, return_tensors=True, rng='philox', _philox=1234, _mol_ids=sub_ids)
+    o_n = o_p = 0
+    for i in sub_ids.tolist():
+        n, u = int(sizes[i]), int(pairs[i])
+        assert torch.equal(sub['a'][o_n:o_n + n], full['a'][noff[i]:noff[i] + n]) and torch.equal(sub['c'][o_n:o_n + n], full['c'][noff[i]:noff[i] + n])
+        assert torch.equal(sub['e'][o_p:o_p + u], full['e'][poff[i]:poff[i] + u])
+        torch.testing.assert_close(sub['x'][o_n:o_n + n], full['x'][noff[i]:noff[i] + n], rtol=1e-5, atol=1e-5)
+        o_n += n; o_p += u
+    # prior: centred, unit variance
+    cfg = model.cfg
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
+    eng.bind(torch.full((40,), 50))
+    x0 = eng.prior_philox(7)
+    assert torch.allclose(x0.reshape(40, 50, 3).mean(1), torch.zeros(40, 3), atol=1e-5)
+    assert abs(float(x0.std()) - 1.0) < 0.03 and abs(float((x0 ** 3).mean())) < 0.1
+    # categorical draws: all rows masked, p fixed, last step (every row unmasks to its sampled endpoint) -> empirical frequencies = p
+    eng.bind(torch.tensor([64, 64]))                      # 2 x 2016 pairs
+    U, N = eng.U, eng.N
+    p_e = torch.tensor([0.1, 0.2, 0.3, 0.4])
+    # the kernel tempers with T: feed p^T renormalised so that softmax(log(.)/T) = p
+    T = cfg.cat_temperature
+    pt = p_e ** T / (p_e ** T).sum()
+    plan = make_step_plan(250, cfg.stochasticity, 0.0, T, philox_seed=4242)
+    sc = plan.scalars[-1]
+    state = eng.prior_state(torch.zeros(N, 3))
+    dst = {'x': torch.zeros(N, 3), 'a': torch.full((N, cfg.n_atom_types), 1.0 / cfg.n_atom_types),
+           'c': torch.full((N, cfg.n_charges), 1.0 / cfg.n_charges), 'e': pt.repeat(U, 1).contiguous()}
+    st_, d_ = eng._state_struct(state), eng._dst_struct(dst)
+    import ctypes as C
+    with eng._dev():
+        eng._check(eng.lib.fm_ctmc_step(eng._ctx, eng._stream(), C.byref(st_), C.byref(d_), None, C.byref(sc), None), 'fm_ctmc_step')
+    freq = torch.bincount(state['e_t'].long(), minlength=5).float() / U
+    assert freq[4] == 0                                    # last step: nothing stays masked
+    assert torch.allclose(freq[:4], p_e, atol=0.03), freq
+    fa = torch.bincount(state['a_t'].long(), minlength=cfg.n_atom_types + 1).float() / N
+    assert fa[-1] == 0 and float(fa.max()) < 3.0 / cfg.n_atom_types

@@ -74,6 +74,10 @@ def test_native_library_is_the_hip_build():
     ('geom_ctmc', [2, 2, 2], 0.9, False),
     ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False),
     ('qm9', [18] * 8, 0.7, True),
+    ('dev_narrow', [70, 2, 47], 0.3, True),            # 64 scalars / 64 edge features on zero-padded 256 / 128-column tiles
+    ('dev', [5, 9, 12, 3, 2], 0.5, True),              # configs/dev.yml:78-108: narrow dims + use_dst_feats (gvp.py:300-316,472-473,527-537)
+    ('dev', [5, 9, 12, 3, 2], 0.0, False),
+    ('dev', [47, 1, 30], 0.4, True),
 ])
 @pytest.mark.parametrize('tile', [16, 32])
 def test_forward_matches_oracle(name, sizes, t, prev, tile):
@@ -608,3 +612,51 @@ def test_rccl_one_rank_group_gather_and_cli(tmp_path, monkeypatch):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev'])
+def test_forward_matches_reference_fixture_directly(golden_dir, name):
+    """The HIP forward against the REFERENCE's own outputs (tests/golden/forward_<name>.npz: EndpointVectorField.forward of the
+    reference's modules, incl. configs/dev.yml with use_dst_feats) -- no oracle in between: bootstrap pass at t = 0 and a
+    self-conditioned pass at t = 0.5, element-wise."""
+    cfg, sd, eng, orc = engine_for(name)
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / f'forward_{name}.npz').items()}
+    eng.bind(g['n_atoms'])
+    worst = {}
+    for tag, tval in (('t0', 0.0), ('th', 0.5)):
+        state = eng.make_state(g[f'{tag}.x_t'], g[f'{tag}.a'], g[f'{tag}.c'], g[f'{tag}.e_upper'])
+        prev = None
+        if tag == 'th' and cfg.self_conditioning:
+            prev = {k: g[f'th.prev.{k}'].cuda().contiguous() for k in 'xace'}
+        out = eng.forward(state, tval, prev=prev, bootstrap=(tag == 't0'), remove_com=True)
+        eng.synchronize()
+        for k in 'xace':
+            want = g[f'{tag}.out.{k}']
+            torch.testing.assert_close(out[k].cpu(), want, rtol=2e-4, atol=2e-6)
+            worst[f'{tag}.{k}'] = float((out[k].cpu() - want).abs().max() / want.abs().max())
+    _report(f'forward_vs_reference_fixture[{name}]', worst)
+    assert max(worst.values()) < OUT_TOL, worst
+
+
+def test_philox_mode_on_gpu_is_batch_composition_independent():
+    """rng='philox' on the GPU at BASELINE-like sizes: 48 GEOM-sized molecules sampled together vs. two of them sampled alone
+    (as another shard would) with their global ids -- identical tokens, coordinates to float summation order; no mask tokens left."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    torch.manual_seed(3)
+    sizes = model.sample_n_atoms(48)
+    full, _ = model.sample(sizes, n_timesteps=25, return_tensors=True, rng='philox', _philox=2024)
+    assert torch.isfinite(full['x']).all() and (full['a'] != model.cfg.n_atom_types).all() and (full['e'] != model.cfg.n_bond_types).all()
+    ids = torch.tensor([31, 7])
+    part, _ = model.sample(sizes[ids], n_timesteps=25, return_tensors=True, rng='philox', _philox=2024, _mol_ids=ids)
+    pairs = sizes * (sizes - 1) // 2
+    noff, poff = torch.cumsum(sizes, 0) - sizes, torch.cumsum(pairs, 0) - pairs
+    o_n = o_p = 0
+    flips = 0
+    for i in ids.tolist():
+        n, u = int(sizes[i]), int(pairs[i])
+        flips += int((part['a'][o_n:o_n + n] != full['a'][noff[i]:noff[i] + n]).sum() + (part['e'][o_p:o_p + u] != full['e'][poff[i]:poff[i] + u]).sum())
+        torch.testing.assert_close(part['x'][o_n:o_n + n], full['x'][noff[i]:noff[i] + n], rtol=1e-4, atol=1e-4)
+        o_n += n; o_p += u
+    _report('philox_composition', {'flips': flips})
+    assert flips == 0

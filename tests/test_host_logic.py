@@ -27,10 +27,14 @@ def test_update_schedule_quirk():
 
 
 def test_unsupported_configs_fail_loudly():
+    VFConfig(use_dst_feats=True).validate()                 # configs/dev.yml features are implemented since round 2 ...
+    VFConfig(n_hidden_scalars=64, n_hidden_edge_feats=64).validate()
     with pytest.raises(NotImplementedError):
-        VFConfig(use_dst_feats=True).validate()
+        VFConfig(use_dst_feats=True, dst_feat_msg_reduction_factor=1).validate()      # ... except the projection-free variant
     with pytest.raises(NotImplementedError):
-        VFConfig(n_hidden_scalars=64).validate()
+        VFConfig(n_hidden_scalars=320).validate()            # wider than the 256-column tiles
+    with pytest.raises(NotImplementedError):
+        VFConfig(n_hidden_edge_feats=192).validate()
     with pytest.raises(NotImplementedError):
         VFConfig(message_norm='mean').validate()
 

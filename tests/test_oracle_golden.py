@@ -24,7 +24,7 @@ def _onehots(cfg, batch, a, c, eu):
     return F.one_hot(a, cfg.n_atom_types + 1).float(), F.one_hot(c, cfg.n_charges + 1).float(), e
 
 
-@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9'])
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev'])
 def test_forward_matches_reference(golden_dir, name):
     cfg = presets.PRESETS[name]()
     g = _load(golden_dir, f'forward_{name}.npz')
@@ -42,7 +42,7 @@ def test_forward_matches_reference(golden_dir, name):
                 torch.testing.assert_close(out[k], g[f'{tag}.out.{k}'], **TOL)
 
 
-@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc'])
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'dev'])
 def test_modules_match_reference(golden_dir, name):
     cfg = presets.PRESETS[name]()
     g = _load(golden_dir, f'modules_{name}.npz')

@@ -11,18 +11,19 @@ import torch                                             # noqa: E402
 from flowmol_amd import presets, weights                 # noqa: E402
 from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan   # noqa: E402
 
-sizes = [int(a) for a in sys.argv[1:]] or [1, 8, 32, 128, 512]
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 32, 128, 512]
+philox = 'philox' in sys.argv[1:]          # in-kernel noise: no torch RNG launches between the steps
 cfg = presets.flowmol3()
 eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0')
 dev = eng.device
 for B in sizes:
     eng.bind(torch.full((B,), 47, dtype=torch.int64))
     N, U = eng.N, eng.U
-    plan = make_step_plan(250, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    plan = make_step_plan(250, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature, philox_seed=11 if philox else None)
     x0 = torch.randn(N, 3, device=dev)
     eng.remove_com(x0)
     state = eng.prior_state(x0)
-    run = IntegrationRun(eng, state, plan, lambda i, last: StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev))
+    run = IntegrationRun(eng, state, plan, None if philox else (lambda i, last: StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev)))
     run.run(0, 8, chunk=8)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -35,10 +36,11 @@ for B in sizes:
     gpu_ms = 0.0
     nl = 0
     for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head',
-              'node_head', 'ctmc_pass1', 'ctmc_pass2', 'embed_table', 'embed_in', 'remove_com', 'x_step'):
+              'node_head', 'sc', 'heads', 'ctmc', 'embed_table', 'remove_com', 'x_step'):
         ms, cnt = eng.profile_get(k)
         gpu_ms += ms
         nl += cnt
     eng.profile(False)
-    print(json.dumps({'mols': B, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
+    import os
+    print(json.dumps({'mols': B, 'noise': 'philox' if philox else 'torch', 'fuse_node': os.environ.get('FM_FUSE_NODE', '1'), 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
                       'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2)}))
