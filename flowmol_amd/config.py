@@ -57,6 +57,9 @@ class VFConfig:
     fw_beta_a: float = 0.25
     fw_beta_b: float = 0.25
     fw_beta_max: float = 10.0
+    # ---- interpolant schedule per modality (interpolant_scheduler.py:9-58): 'linear' | 'cosine' (+ exponent nu per cosine modality)
+    schedule_type: dict = field(default_factory=lambda: {k: 'linear' for k in 'xace'})
+    cosine_params: dict = field(default_factory=dict)
     # ---- sampling defaults (flowmol.py:46)
     default_n_timesteps: int = 250
     # name of the size histogram shipped in flowmol_amd/data/n_atoms_hist.json
@@ -151,6 +154,12 @@ class VFConfig:
         if self.n_atom_types + 1 > 16 or self.n_charges + 1 > 8 or self.n_bond_types + 1 > 8:
             raise NotImplementedError("categorical widths exceed kernel limits (a<=16, c<=8, e<=8 incl. mask)")
         self.msg_z  # raises for 'mean'
+        for k in 'xace':
+            st = self.schedule_type.get(k)
+            if st not in ('linear', 'cosine'):
+                raise ValueError(f'unsupported schedule_type for {k!r}: {st!r}')           # interpolant_scheduler.py:21-22
+            if st == 'cosine' and k not in self.cosine_params:
+                raise ValueError(f'must specify cosine_params for feature {k}')          # interpolant_scheduler.py:45-47
         return self
 
     def to_dict(self):
@@ -202,6 +211,10 @@ def from_reference_hparams(hp: dict) -> VFConfig:
         v = vf.get(unsupported)
         if v not in (None, False, 0, 0.0):
             raise NotImplementedError(f"vector_field.{unsupported}={v!r} is not implemented")
+    isc = hp.get('interpolant_scheduler_config', {}) or {}
+    st = isc.get('schedule_type', 'cosine')                  # InterpolantScheduler's own default (interpolant_scheduler.py:9)
+    cfg.schedule_type = {k: st for k in 'xace'} if isinstance(st, str) else {k: st[k] for k in 'xace'}
+    cfg.cosine_params = {k: float(v) for k, v in (isc.get('cosine_params', {}) or {}).items()}
     nah = str(hp.get('n_atoms_hist_file', ''))
     for name in ('geom_full_kekulized', 'geom_5_kekulized', 'geom_5_aromatic', 'qm9', 'geom'):
         if f'/{name}/' in nah or nah.startswith(f'data/{name}'):

@@ -74,29 +74,54 @@ def _f32(v) -> float:
     return float(v.to(torch.float32)) if torch.is_tensor(v) else float(torch.tensor(v, dtype=torch.float32))
 
 
+def alpha_tables(t: torch.Tensor, schedule_type=None, cosine_params=None):
+    """InterpolantScheduler.alpha_t / alpha_t_prime (interpolant_scheduler.py:97-153) for the time points ``t`` (T,), columns in the
+    canonical order x, a, c, e, with the reference's float32 tensor arithmetic -- INCLUDING its side effect: the cosine
+    derivative clamps ``t`` in place to >= 1e-9 (:140-141), after alpha_t was taken from the unclamped tensor
+    (ctmc_vector_field.py:175-176), so a cosine-scheduled trajectory starts at t = 1e-9 and has no bootstrap evaluation."""
+    schedule_type = schedule_type or {}
+    cosine_params = cosine_params or {}
+    nus = {k: torch.tensor(cosine_params[k]).unsqueeze(0) for k in cosine_params}        # interpolant_scheduler.py:53-55
+    cols = []
+    for k in 'xace':
+        if schedule_type.get(k, 'linear') == 'cosine':
+            cols.append(1 - torch.cos(torch.pi * 0.5 * torch.pow(t.unsqueeze(-1), nus[k])).square())
+        else:
+            cols.append(t.unsqueeze(-1))
+    alpha = torch.cat(cols, dim=1)
+    cols = []
+    for k in 'xace':
+        if schedule_type.get(k, 'linear') == 'cosine':
+            t = torch.clamp_(t, min=1e-9)
+            tt = t.unsqueeze(-1)
+            cols.append(torch.pi * 0.5 * torch.sin(torch.pi * torch.pow(tt, nus[k])) * nus[k] * torch.pow(tt, nus[k] - 1))
+        else:
+            cols.append(torch.ones_like(t).unsqueeze(-1))
+    return alpha, torch.cat(cols, dim=1)
+
+
 def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperature,
                    tspan: Optional[torch.Tensor] = None, dfm_type: str = 'campbell', forward_weight_func: Optional[Callable] = None,
-                   inv_temp_func: Optional[Callable] = None, philox_seed: Optional[int] = None) -> StepPlan:
+                   inv_temp_func: Optional[Callable] = None, philox_seed: Optional[int] = None,
+                   schedule_type=None, cosine_params=None) -> StepPlan:
     """Per-step scalars of CTMCVectorField.integrate/step (ctmc_vector_field.py:169-178, 287-340), computed with the
     reference's own float32 tensor arithmetic.  ``cat_temperature`` is a number or a callable of the 0-dim tensor t_i."""
-    t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32)
-    alpha = t          # linear schedule: alpha_t = t, alpha_t' = 1 for x, a, c, e (interpolant_scheduler.py:148-153)
-    one = torch.ones(())
+    t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32).clone()
+    alpha, alpha_p = alpha_tables(t, schedule_type, cosine_params)      # (T,4) each; may clamp t[0] in place (cosine)
     if dfm_type not in ('campbell', 'gat'):
         raise ValueError(f"Invalid dfm_type: {dfm_type}")
     out = []
     for s_idx in range(1, t.shape[0]):
         s_i, t_i = t[s_idx], t[s_idx - 1]
-        a_i = alpha[s_idx - 1]
+        a_i, ap_i = alpha[s_idx - 1], alpha_p[s_idx - 1]      # columns x, a, c, e
         dt = s_i - t_i
         sc = fm_step_scalars()
         sc.t = float(t_i)
         sc.dt = float(dt)
-        sc.x_coef = float(one / (1 - a_i))
-        unmask = torch.clamp(dt * (one + eta * a_i) / (1 - a_i), min=0, max=1)
+        sc.x_coef = float(ap_i[0] / (1 - a_i[0]))
         mask = torch.clamp(dt * eta, min=0, max=1)
         for k in range(3):
-            sc.unmask_prob[k] = float(unmask)
+            sc.unmask_prob[k] = float(torch.clamp(dt * (ap_i[k + 1] + eta * a_i[k + 1]) / (1 - a_i[k + 1]), min=0, max=1))
             sc.mask_prob[k] = float(mask)
         sc.hc_thresh = float(torch.tensor(hc_thresh, dtype=torch.float32))
         sc.cat_temperature = _f32(cat_temperature(t_i) if callable(cat_temperature) else cat_temperature)
@@ -107,8 +132,8 @@ def make_step_plan(n_timesteps: int, eta: float, hc_thresh: float, cat_temperatu
             fw = 1.0 if forward_weight_func is None else forward_weight_func(t_i)
             bw = fw - 1                                     # python or tensor arithmetic, as in gat_step
             for k in range(3):
-                sc.gat_cf[k] = float(one / (1 - a_i))
-                sc.gat_cb[k] = float(one / (a_i + 1e-8))
+                sc.gat_cf[k] = float(ap_i[k + 1] / (1 - a_i[k + 1]))
+                sc.gat_cb[k] = float(ap_i[k + 1] / (a_i[k + 1] + 1e-8))
             sc.gat_fw, sc.gat_bw = _f32(fw), _f32(bw)
         if philox_seed is not None:        # noise drawn inside the CTMC kernel from per-molecule counter-based streams (fm_noise_mode)
             if dfm_type != 'campbell':

@@ -65,7 +65,7 @@ def read_checkpoint(path):
 
 
 SUPPORTED_PARAMETERIZATIONS = ('ctmc',)
-SUPPORTED_SCHEDULES = ('linear',)
+SUPPORTED_SCHEDULES = ('linear', 'cosine')
 
 
 def check_reference_hparams(hp: dict) -> None:
@@ -82,7 +82,7 @@ def check_reference_hparams(hp: dict) -> None:
     bad = sorted({t for t in types if t not in SUPPORTED_SCHEDULES})
     if bad:
         raise NotImplementedError(f'interpolant schedule_type {bad}: implemented: {SUPPORTED_SCHEDULES} '
-                                  '(a cosine-schedule checkpoint would otherwise be integrated with the wrong x and unmasking coefficients)')
+                                  '(any other schedule would be integrated with the wrong x and unmasking coefficients)')
     pc = hp.get('prior_config', {}) or {}
     xt = (pc.get('x', {}) or {}).get('type', 'centered-normal')
     if xt != 'centered-normal':
@@ -281,7 +281,8 @@ class FlowMol:
         ctf = kwargs.get('cat_temp_func') or cat_temp_schedule(cfg)
         fwf = kwargs.get('forward_weight_func') or forward_weight_schedule(cfg)
         plan = make_step_plan(n_timesteps, eta, hc, ctf, tspan=kwargs.get('tspan'), dfm_type=dfm_type,
-                              forward_weight_func=fwf, inv_temp_func=kwargs.get('inv_temp_func'), philox_seed=philox_seed)
+                              forward_weight_func=fwf, inv_temp_func=kwargs.get('inv_temp_func'), philox_seed=philox_seed,
+                              schedule_type=cfg.schedule_type, cosine_params=cfg.cosine_params)
         n_steps = len(plan.scalars)
         traj = None
         if visualize:

@@ -7,7 +7,7 @@ leg may use it, and only as the checker / the timed CPU baseline -- never as the
 What it restates (all citations are into /root/reference):
   graph construction      flowmol/data_processing/utils.py:4-46, flowmol/models/flowmol.py:509-529
   priors                  flowmol/data_processing/priors.py:27-35,101-107,305-316
-  alpha schedule          flowmol/models/interpolant_scheduler.py:97-128,148-153 (linear only)
+  alpha schedule          flowmol/models/interpolant_scheduler.py:97-153 (linear and cosine)
   embeddings              flowmol/utils/embedding.py:5-34
   GVP / GVPLayerNorm      flowmol/models/gvp.py:14-21,90-133,169-184
   GVPConv                 flowmol/models/gvp.py:435-543
@@ -118,11 +118,28 @@ def time_embedding(t, dim, max_positions=1000):
     return emb
 
 
-def alpha_tables(t: torch.Tensor):
-    """Linear schedule for x,a,c,e: alpha=t, alpha'=1 (interpolant_scheduler.py:97-128,148-153)."""
-    a = torch.cat([t.unsqueeze(-1)] * 4, dim=1)
-    ap = torch.cat([torch.ones_like(t).unsqueeze(-1)] * 4, dim=1)
-    return a, ap
+def alpha_tables(t: torch.Tensor, schedule_type=None, cosine_params=None):
+    """alpha_t / alpha_t_prime for x,a,c,e (interpolant_scheduler.py:97-153).  linear: alpha=t, alpha'=1; cosine:
+    alpha = 1 - cos^2(pi/2 t^nu), alpha' = pi/2 sin(pi t^nu) nu t^(nu-1) -- whose evaluation clamps ``t`` IN PLACE to >= 1e-9
+    (:140-141) after alpha was computed from the unclamped tensor (ctmc_vector_field.py:175-176)."""
+    schedule_type = schedule_type or {}
+    nus = {k: torch.tensor(v).unsqueeze(0) for k, v in (cosine_params or {}).items()}
+    a = []
+    for k in 'xace':
+        if schedule_type.get(k, 'linear') == 'cosine':
+            a.append(1 - torch.cos(torch.pi * 0.5 * torch.pow(t.unsqueeze(-1), nus[k])).square())
+        else:
+            a.append(t.unsqueeze(-1))
+    a = torch.cat(a, dim=1)                 # materialised BEFORE the derivative's in-place clamp, as in the reference (alpha_t returns a cat)
+    ap = []
+    for k in 'xace':
+        if schedule_type.get(k, 'linear') == 'cosine':
+            t = torch.clamp_(t, min=1e-9)
+            tt = t.unsqueeze(-1)
+            ap.append(torch.pi * 0.5 * torch.sin(torch.pi * torch.pow(tt, nus[k])) * nus[k] * torch.pow(tt, nus[k] - 1))
+        else:
+            ap.append(torch.ones_like(t).unsqueeze(-1))
+    return a, torch.cat(ap, dim=1)
 
 
 # --------------------------------------------------------------------------------------
@@ -535,7 +552,7 @@ class OracleVF:
         noise = noise or TorchNoise()
         dev = prior['x_0'].device
         t = torch.linspace(0, 1, n_timesteps, device=dev) if tspan is None else tspan
-        alpha_t, alpha_tp = alpha_tables(t)
+        alpha_t, alpha_tp = alpha_tables(t, getattr(cfg, 'schedule_type', None), getattr(cfg, 'cosine_params', None))
         state = {'x_t': prior['x_0'], 'a_t': prior['a_0'], 'c_t': prior['c_0'], 'e_t': prior['e_0']}
         frames = None
         if visualize:

@@ -215,6 +215,41 @@ def gen_integrate_variant(ns, name, cfg, sd, sizes, tag, dfm_type):
     np.savez_compressed(OUT / f'integrate_{name}_{tag}.npz', **_np(out))
 
 
+def gen_integrate_cosine(ns, cfg, sd, sizes):
+    """Free-running reference trajectory under the COSINE interpolant schedule (interpolant_scheduler.py:131-146; the
+    commented example of configs/flowmol3.yml:114-118): x cosine nu=1, a and c cosine nu=2, e linear -- incl. the reference's
+    in-place clamp of t[0] to 1e-9, which removes the bootstrap evaluation."""
+    import dataclasses
+    ccfg = dataclasses.replace(cfg, schedule_type={'x': 'cosine', 'a': 'cosine', 'c': 'cosine', 'e': 'linear'},
+                               cosine_params={'x': 1, 'a': 2, 'c': 2})
+    vf = ref_standin.build_reference_vf(ns, ccfg, sd)
+    n_atoms = torch.tensor(sizes)
+    g, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
+    torch.manual_seed(8)
+    x0 = ns.centered_normal_prior_batched_graph(g, nb)
+    g.ndata['x_0'] = x0
+    g.ndata['a_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_atom_types)
+    g.ndata['c_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_charges)
+    g.edata['e_0'] = ns.edge_prior(upper, {'type': 'ctmc', 'kwargs': {}}, explicit_aromaticity=False)
+    T = 12
+    torch.manual_seed(9)
+    with torch.no_grad(), _Tape() as tp:
+        gout, frames = vf.integrate(g, nb, upper_edge_mask=upper, n_timesteps=T, visualize=True,
+                                    stochasticity=None, high_confidence_threshold=None)
+    out = {'n_atoms': n_atoms, 'T': T, 'x_0': x0,
+           'x_1': gout.ndata['x_1'], 'a_1': gout.ndata['a_1'].argmax(-1), 'c_1': gout.ndata['c_1'].argmax(-1),
+           'e_1_upper': gout.edata['e_1'][upper].argmax(-1)}
+    for i, t in enumerate(tp.tape):
+        out[f'noise.{i:05d}'] = t
+    out['traj0.x'] = frames[0]['x']
+    out['traj0.a'] = frames[0]['a'].argmax(-1)
+    tt = torch.linspace(0, 1, T)
+    out['alpha.a'] = vf.interpolant_scheduler.alpha_t(tt)
+    out['alpha.ap'] = vf.interpolant_scheduler.alpha_t_prime(tt)
+    out['alpha.t_after'] = tt
+    np.savez_compressed(OUT / 'integrate_qm9_cosine.npz', **_np(out))
+
+
 def _ref_function(path, name, cls=None):
     """Source-level import of ONE function (or method of class ``cls``) of a reference module that cannot be
     imported here as a whole (rdkit at module scope): parsed with ast, compiled and executed in this container
@@ -474,6 +509,7 @@ def main():
     cfg = presets.qm9(); sd = weights.synth_state_dict(cfg, 0)
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'gat', 'gat')
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'sched', 'campbell')
+    gen_integrate_cosine(ns, cfg, sd, [6, 3, 8])
     for f in sorted(OUT.glob('*.npz')):
         print(f.name, f.stat().st_size // 1024, 'KiB')
 

@@ -211,7 +211,8 @@ def import_reference():
 def build_reference_vf(ns, cfg, state_dict, **overrides):
     """Instantiate the reference CTMCVectorField for ``cfg`` and load ``state_dict`` (strict)."""
     sched = ns.InterpolantScheduler(canonical_feat_order=['x', 'a', 'c', 'e'],
-                                    schedule_type={k: 'linear' for k in 'xace'})
+                                    schedule_type=dict(getattr(cfg, 'schedule_type', None) or {k: 'linear' for k in 'xace'}),
+                                    cosine_params=dict(getattr(cfg, 'cosine_params', None) or {}))
     vf = ns.CTMCVectorField(
         n_atom_types=cfg.n_atom_types, canonical_feat_order=['x', 'a', 'c', 'e'],
         interpolant_scheduler=sched, n_charges=cfg.n_charges, n_bond_types=cfg.n_bond_types,

@@ -113,7 +113,8 @@ def integrate_golden(eng, cfg, g, chunk=8, device=None):
     eng.bind(g['n_atoms'])
     T = int(g['T'])
     tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
-    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature,
+                          schedule_type=cfg.schedule_type, cosine_params=cfg.cosine_params)
     state = eng.prior_state(g['x_0'])
     pos = [0]
 
@@ -239,3 +240,10 @@ def ctmc_step_golden(eng, cfg, g, case, device=None):
         res[f'{k}1_flips'] = int((smp[f'{k}1'].cpu().long() != g[f'{case}.{k}_1_pred']).sum())
     res['x_abs'] = float((state['x_t'].cpu() - g[f'{case}.x_new']).abs().max())
     return res
+
+
+def cosine_cfg(cfg):
+    """The preset under the schedule of tests/golden/integrate_qm9_cosine.npz (oracle/make_golden.py:gen_integrate_cosine)."""
+    import dataclasses
+    return dataclasses.replace(cfg, schedule_type={'x': 'cosine', 'a': 'cosine', 'c': 'cosine', 'e': 'linear'},
+                               cosine_params={'x': 1, 'a': 2, 'c': 2})

@@ -260,3 +260,15 @@ def test_philox_noise_is_sharding_independent_and_well_distributed(emu_lib):
     assert torch.allclose(freq[:4], p_e, atol=0.03), freq
     fa = torch.bincount(state['a_t'].long(), minlength=cfg.n_atom_types + 1).float() / N
     assert fa[-1] == 0 and float(fa.max()) < 3.0 / cfg.n_atom_types
+
+
+def test_cosine_schedule_trajectory_on_emulation(emu_lib, golden_dir):
+    """Cosine interpolant schedule end to end through the C ABI against the reference's own integrate() (recorded noise)."""
+    from flowmol_amd.engine import Engine
+    from parity_util import cosine_cfg, integrate_golden
+    cfg = cosine_cfg(presets.qm9())
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'integrate_qm9_cosine.npz').items()}
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cpu', lib=emu_lib)
+    res, state = integrate_golden(eng, cfg, g)
+    assert res['a_flips'] == 0 and res['c_flips'] == 0 and res['e_flips'] == 0 and res['traj0_a_flips'] == 0, res
+    assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res

@@ -660,3 +660,16 @@ def test_philox_mode_on_gpu_is_batch_composition_independent():
         o_n += n; o_p += u
     _report('philox_composition', {'flips': flips})
     assert flips == 0
+
+
+def test_cosine_schedule_trajectory_matches_reference_golden(golden_dir):
+    """Cosine interpolant schedule (interpolant_scheduler.py:131-146) on the GPU against the reference's own free-running integrate()."""
+    from flowmol_amd.engine import Engine
+    from parity_util import cosine_cfg
+    cfg = cosine_cfg(presets.qm9())
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'integrate_qm9_cosine.npz').items()}
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0')
+    res, state = integrate_golden(eng, cfg, g, device='cuda:0')
+    _report('integrate[cosine]', res)
+    assert res['a_flips'] == 0 and res['c_flips'] == 0 and res['e_flips'] == 0 and res['traj0_a_flips'] == 0, res
+    assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res

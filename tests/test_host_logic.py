@@ -222,3 +222,25 @@ def test_sdf_writer_reproduces_hand_derived_blocks(golden_dir, tmp_path):
     mols = [SampledMolecule(m['x'].float(), m['a'], m['c'], m['e'], presets.GEOM_ATOMS, fake_atoms=True) for m in cli_block_token_molecules()]
     cli.write_sdf(tmp_path / 'o.sdf', [m.to_sdf_block() for m in mols])
     assert (tmp_path / 'o.sdf').read_text() == (golden_dir / 'cli_expected_blocks.sdf').read_text()
+
+
+def test_cosine_step_plan_matches_reference_tables(golden_dir):
+    """engine.alpha_tables / make_step_plan under the cosine schedule against the reference scheduler's own tables
+    (tests/golden/integrate_qm9_cosine.npz): alpha, alpha', the clamped first time point, per-modality coefficients."""
+    import numpy as np
+    from flowmol_amd.engine import alpha_tables
+    from parity_util import cosine_cfg
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'integrate_qm9_cosine.npz').items()}
+    cfg = cosine_cfg(presets.qm9())
+    T = int(g['T'])
+    t = torch.linspace(0, 1, T)
+    a, ap = alpha_tables(t, cfg.schedule_type, cfg.cosine_params)
+    assert torch.equal(a, g['alpha.a']) and torch.equal(ap, g['alpha.ap']) and torch.equal(t, g['alpha.t_after'])
+    plan = make_step_plan(T, 30.0, 0.9, 0.05, schedule_type=cfg.schedule_type, cosine_params=cfg.cosine_params)
+    assert plan.scalars[0].t == float(torch.tensor(1e-9))                 # no bootstrap: t_0 != 0 (SURVEY.md Appendix C.6)
+    i = 4
+    dt = t[i + 1] - t[i]
+    sc = plan.scalars[i]
+    assert sc.x_coef == float(ap[i, 0] / (1 - a[i, 0]))
+    assert sc.unmask_prob[0] == float(torch.clamp(dt * (ap[i, 1] + 30.0 * a[i, 1]) / (1 - a[i, 1]), min=0, max=1))
+    assert sc.unmask_prob[2] == float(torch.clamp(dt * (ap[i, 3] + 30.0 * a[i, 3]) / (1 - a[i, 3]), min=0, max=1))

@@ -246,3 +246,25 @@ def test_ctmc_step_matches_reference_step(golden_dir, case):
     for k in 'ac':
         assert torch.equal(new[f'{k}_t'].argmax(-1), g[f'{case}.{k}_new']) and torch.equal(new[f'{k}_1_pred'].argmax(-1), g[f'{case}.{k}_1_pred'])
     assert torch.equal(new['e_t'][m].argmax(-1), g[f'{case}.e_new']) and torch.equal(new['e_1_pred'][m].argmax(-1), g[f'{case}.e_1_pred'])
+
+
+def test_cosine_schedule_integrate_matches_reference(golden_dir):
+    """Cosine interpolant schedule (interpolant_scheduler.py:131-146) through the oracle: alpha tables incl. the in-place clamp of
+    t[0] to 1e-9, and the free-running trajectory (no bootstrap evaluation) against the reference's own integrate()."""
+    from parity_util import cosine_cfg
+    g = _load(golden_dir, 'integrate_qm9_cosine.npz')
+    cfg = cosine_cfg(presets.qm9())
+    T = int(g['T'])
+    t = torch.linspace(0, 1, T)
+    a, ap = cpu_ref.alpha_tables(t, cfg.schedule_type, cfg.cosine_params)
+    assert torch.equal(a, g['alpha.a']) and torch.equal(ap, g['alpha.ap']) and torch.equal(t, g['alpha.t_after'])
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
+    prior = {'x_0': g['x_0'], 'a_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_atom_types), 'c_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_charges),
+             'e_0': cpu_ref.edge_prior(batch.upper_edge_mask, cfg.n_bond_types)}
+    with torch.no_grad():
+        out = orc.integrate(batch, prior, T, noise=cpu_ref.TapeNoise(tape))
+    assert torch.equal(out['a_1'].argmax(-1), g['a_1']) and torch.equal(out['c_1'].argmax(-1), g['c_1'])
+    assert torch.equal(out['e_1'][batch.upper_edge_mask].argmax(-1), g['e_1_upper'])
+    torch.testing.assert_close(out['x_1'], g['x_1'], **TOL)
