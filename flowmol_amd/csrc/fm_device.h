@@ -480,10 +480,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     FM_MARKB(7);
 }
 
-// per-element addend of the first edge GVP's scalar linear: addend[rows[row]][col] for this lane's accumulator elements
-// (rows[] < 0: no row -> 0, via the buffer range check).  `addend` is (nrows, 256) fp32.
+// per-element addend of the first edge GVP's scalar linear: addend[row of rowoff[..]][col] for this lane's accumulator elements.
+// rowoff[] holds ready BYTE offsets of the (nrows, 256) fp32 table rows (row * 1024), FM_BUF_OOB for "no row" (reads 0 through the
+// buffer range check; adding the lane's column offset keeps it out of range): one v_add per row instead of compare + scale + select.
 template <int TM, int NTH, bool ACCUM>
-__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, int nrows, const int* rows) {
+__device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][4], const float* __restrict__ addend, int nrows, const int* rowoff) {
     constexpr int NTW = 1024 / NTH;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const auto rs = fm_buf(addend, (unsigned)nrows * 1024u);
@@ -491,8 +492,7 @@ __device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][
     for (int i = 0; i < TM / 16; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ar = rows[i * 16 + 4 * (lane >> 4) + r];
-            const int voff = ar >= 0 ? ar * 1024 + (lane & 15) * 4 : FM_BUF_OOB;
+            const int voff = rowoff[i * 16 + 4 * (lane >> 4) + r] + (lane & 15) * 4;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) { const float t = fm_buf_f32(rs, voff, (NTW * wave + j) * 64); pre[i][j][r] = ACCUM ? pre[i][j][r] + t : t; }
         }

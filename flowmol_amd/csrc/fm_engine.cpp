@@ -203,7 +203,7 @@ template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(r
 int pvw_of(int V, int HX) { return (pad8(V + 1 + HX + 4) + 8 + 15) / 16 * 16; }     // FmGvpTile::PVW
 size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
     size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, HX) + 4) + TM * FM_LDG;
-    return fl * 4 + (with_meta ? (size_t)TM * 7 * 4 : 0);
+    return fl * 4 + (with_meta ? (size_t)TM * 9 * 4 : 0);
 }
 size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 5 * FM_TM * 4; }
 size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }

@@ -2,6 +2,8 @@
 // kernel -> reference function and the HBM data layout.  All kernels use 512-thread workgroups
 // over 64-row tiles unless noted; weights come pre-packed (fm_device.h).
 #pragma once
+#include <type_traits>
+
 #include "fm_device.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -497,6 +499,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     int* m_dst = m_src + TM;                              // [64]
     float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [TM][4]: xhat(3), dist
     int* m_piece = reinterpret_cast<int*>(m_geo + 4 * TM); // [TM] which partial-sum slot of its destination the row adds to
+    int* m_soff = m_piece + TM;                            // [TM] byte offset of the source's row in the (N,256) tables, FM_BUF_OOB if none
+    int* m_doff = m_soff + TM;                             // [TM] same for the destination (use_dst_feats)
     const int tid = threadIdx.x;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  With the chunked mapping every XCD walks
     // one contiguous range of tiles, so a molecule's Ps / PV rows (shared by its ~n^2/TM consecutive tiles) are filled
@@ -529,6 +533,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
             gx = dx * inv_d; gy = dy * inv_d; gz = dz * inv_d;
         }
         m_src[tid] = s; m_dst[tid] = d; m_piece[tid] = piece;
+        m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB; m_doff[tid] = d >= 0 ? d * 1024 : FM_BUF_OOB;
         m_geo[4 * tid] = gx; m_geo[4 * tid + 1] = gy; m_geo[4 * tid + 2] = gz; m_geo[4 * tid + 3] = dist;
     }
     __syncthreads();
@@ -537,9 +542,9 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     //     L2 latency overlaps the fill below and the first phases of the GVP (VMEM returns in order, so a request
     //     placed right before the GEMM would stall the GEMM's first weight fragments behind it)
     float pre[TM / 16][1024 / NTH][4];
-    if (!(FM_ABLATE & 16)) fm_gather_pre<TM, NTH, false>(pre, a.Ps, a.b.N, m_src);
+    if (!(FM_ABLATE & 16)) fm_gather_pre<TM, NTH, false>(pre, a.Ps, a.b.N, m_soff);
     else { for (auto& p1 : pre) for (auto& p2 : p1) for (auto& p3 : p2) p3 = 0.25f; }
-    if (HX > 0) fm_gather_pre<TM, NTH, true>(pre, a.Psd, a.b.N, m_dst);       // + the destination node's hoisted scalar term
+    if (HX > 0) fm_gather_pre<TM, NTH, true>(pre, a.Psd, a.b.N, m_doff);      // + the destination node's hoisted scalar term
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):
     //     a branchy load-use-store loop serialises one L2 round trip per iteration (profiles/r01d: 37k cycles here).
@@ -566,12 +571,12 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         for (int p_ = 0; p_ < NP; ++p_) {
             const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
             if (NCH % QN == 0 || ch < NCH)
-                Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = (m_src[r] >= 0) ? pv[p_] + m_geo[4 * r + c] * w0v[p_] : 0.f;
+                Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = pv[p_] + m_geo[4 * r + c] * w0v[p_];      // rows without an edge: 0 + 0 * w0 (range-checked gather, zero geometry)
         }
     }
     for (int idx = tid; idx < TM * 32; idx += NTH) {
         const int r = idx >> 5, k = idx & 31;
-        X[r * FM_LDX + k] = (m_src[r] >= 0) ? fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
+        X[r * FM_LDX + k] = fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma);      // rows without an edge hold finite junk that is never aggregated
     }
 #pragma unroll
     for (int k = 0; k < NEF; ++k) {
@@ -595,43 +600,43 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         }
     }
     FM_MARK(40);
-    // segmented sum over the rows of each destination (rows are dst-sorted).  One thread per output column; the
-    // destination ids and the column's TM values are first pulled into registers with independent LDS reads, the
-    // running sums are then register-only (the first version walked the rows with dependent LDS reads: 15k cycles).
-    // The destination ids are made wave-uniform (one LDS read per lane, then v_readlane with constant lane ids), so
-    // the segment logic runs on scalar compares/branches; a wave holds either scalar or vector columns, so the only
-    // per-lane work is the LDS reads, the adds and the (rare) stores.
+    // segmented sum over the rows of each destination (rows are dst-sorted).  One thread per output column; the column's TM
+    // values are pulled into registers with independent LDS reads and summed there (the first version walked the rows with
+    // dependent LDS reads: 15k cycles).  Where a destination's rows end inside the tile is ONE wave-uniform bit mask (a ballot of
+    // dst[r] != dst[r+1]), so the segment logic is a scalar bit test per row; destination id and piece are fetched (LDS
+    // broadcast + v_readfirstlane) only at the 1-2 segment ends of a tile.  Round 1 made all 2*TM ids wave-uniform with
+    // v_readlane: 64 VALU per wave and tile, each of which costs matrix-pipe time (profiles/r02a ablation).  Rows past the end
+    // of the edge list (ragged last tile) come after the last set bit, so whatever they add to `run` is never stored.
     static_assert(NTH == 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
     if (!(FM_ABLATE & 8)) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-        const int myd = m_dst[lane % TM], mypc = m_piece[lane % TM];
-        int dd[TM + 1], pc[TM];
-#pragma unroll
-        for (int r = 0; r < TM; ++r) { dd[r] = __builtin_amdgcn_readlane(myd, r); pc[r] = __builtin_amdgcn_readlane(mypc, r); }
-        dd[TM] = -1;
+        const int lr = lane < TM ? lane : TM - 1;
+        const int myd = m_dst[lr];
+        const int nxd = m_dst[lr + 1 < TM ? lr + 1 : TM - 1];
+        const unsigned long long ends = __ballot(lane < TM && myd >= 0 && (lr + 1 == TM || nxd != myd));
         const bool is_s = wave < 4;                                       // columns 0..255: scalars
         const int cv = tid - 256;                                         // vector column = xyz*V + channel
-        if (is_s || cv < 3 * V) {
-            const float* vp = is_s ? X + tid : Vin + (cv / V) * TM * T::LDVI + (cv % V);
-            const int vstride = is_s ? FM_LDX : T::LDVI;
+        // one instance per tile kind, so that the row stride is a compile-time constant and the TM LDS reads of a column are
+        // one base register + immediates (a run-time stride costs one VALU address computation per row)
+        auto column_sums = [&](const float* vp, auto stride_c, float* out_base, unsigned row_bytes, int col) {
+            constexpr int STRIDE = decltype(stride_c)::value;
             float val[TM];
 #pragma unroll
-            for (int r = 0; r < TM; ++r) val[r] = vp[r * vstride];
+            for (int r = 0; r < TM; ++r) val[r] = vp[r * STRIDE];
             float run = 0.f;
 #pragma unroll
             for (int r = 0; r < TM; ++r) {
-                const int d = dd[r];
-                if (d >= 0) {
-                    run += val[r];
-                    if (dd[r + 1] != d) {
-                        const size_t slot = (size_t)d * a.b.P + pc[r];
-                        if (is_s) fm_buf_store_f32(fm_buf(a.part_s + slot * 256, 1024u), tid * 4, 0, run);
-                        else fm_buf_store_f32(fm_buf(a.part_v + slot * 3 * V, 3 * V * 4u), cv * 4, 0, run);
-                        run = 0.f;
-                    }
+                run += val[r];
+                if ((ends >> r) & 1ull) {
+                    const int d = __builtin_amdgcn_readfirstlane(m_dst[r]), pcr = __builtin_amdgcn_readfirstlane(m_piece[r]);
+                    const size_t slot = (size_t)d * a.b.P + pcr;
+                    fm_buf_store_f32(fm_buf(reinterpret_cast<const char*>(out_base) + slot * row_bytes, row_bytes), col * 4, 0, run);
+                    run = 0.f;
                 }
             }
-        }
+        };
+        if (is_s) column_sums(X + tid, std::integral_constant<int, FM_LDX>{}, a.part_s, 1024u, tid);
+        else if (cv < 3 * V) column_sums(Vin + (cv / V) * TM * T::LDVI + (cv % V), std::integral_constant<int, T::LDVI>{}, a.part_v, 3 * V * 4u, cv);
     }
     FM_MARK(41);
 }
