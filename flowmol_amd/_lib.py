@@ -28,7 +28,7 @@ class fm_config(C.Structure):
         ('update_after', C.c_int32 * FM_MAX_CONVS), ('self_conditioning', C.c_int32),
         ('time_embedding_dim', C.c_int32), ('a_token_dim', C.c_int32), ('c_token_dim', C.c_int32),
         ('e_token_dim', C.c_int32), ('rbf_dmax', C.c_float), ('msg_z', C.c_float),
-        ('s_dst_feats', C.c_int32), ('v_dst_feats', C.c_int32),
+        ('s_dst_feats', C.c_int32), ('v_dst_feats', C.c_int32), ('has_mask', C.c_int32),
     ]
 
 
@@ -42,6 +42,14 @@ class fm_dst(C.Structure):
 
 class fm_state(C.Structure):
     _fields_ = [('x_t', C.c_void_p), ('a_t', C.c_void_p), ('c_t', C.c_void_p), ('e_t', C.c_void_p)]
+
+
+class fm_dense_state(C.Structure):
+    _fields_ = [('x_t', C.c_void_p), ('a_t', C.c_void_p), ('c_t', C.c_void_p), ('e_t', C.c_void_p)]
+
+
+class fm_endpoint_scalars(C.Structure):
+    _fields_ = [('dt', C.c_float), ('coef', C.c_float * 4), ('scale', C.c_float)]
 
 
 class fm_step_noise(C.Structure):
@@ -81,6 +89,8 @@ _EXPORTS = {
     'fm_prior_philox': (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     'fm_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.c_void_p, C.POINTER(fm_dst), C.c_int, C.c_int,
                              C.POINTER(fm_dst)]),
+    'fm_forward_dense': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_dense_state), C.c_void_p, C.c_int, C.POINTER(fm_dst)]),
+    'fm_endpoint_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_dense_state), C.POINTER(fm_dst), C.POINTER(fm_endpoint_scalars)]),
     'fm_ctmc_step': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.POINTER(fm_dst), C.POINTER(fm_step_noise),
                                C.POINTER(fm_step_scalars), C.POINTER(fm_sampled)]),
     'fm_integrate': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(fm_state), C.c_int, C.POINTER(fm_step_scalars), C.c_void_p,

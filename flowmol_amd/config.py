@@ -45,6 +45,13 @@ class VFConfig:
     use_dst_feats: bool = False                         # GVPConv: reduced destination-node features join the message inputs (gvp.py:300-316,527-537)
     dst_feat_msg_reduction_factor: float = 4
     n_recycles: int = 1
+    # ---- flow-matching parameterization (flowmol.py:40,137-153): 'ctmc' = CTMCVectorField (categorical tokens with a mask state),
+    # 'endpoint' = EndpointVectorField (categoricals as continuous simplex-like vectors, Euler step for all four modalities)
+    parameterization: str = 'ctmc'
+    prior_types: dict = field(default_factory=lambda: {'a': 'ctmc', 'c': 'ctmc', 'e': 'ctmc'})     # prior_config[feat]['type'] (flowmol.py:189-193,417-448)
+    prior_kwargs: dict = field(default_factory=lambda: {'a': {}, 'c': {}, 'e': {}})
+    continuous_inv_temp_schedule: Optional[str] = None     # EndpointVectorField.step scaling of the vector field: None | 'linear' (vector_field.py:199-209)
+    continuous_inv_temp_max: float = 10.0
     # ---- CTMC integrator defaults (ctmc_vector_field.py:23-34)
     stochasticity: float = 30.0
     high_confidence_threshold: float = 0.9
@@ -85,10 +92,16 @@ class VFConfig:
         """Width of the token features fed to the embedding MLPs.
 
         token_dim == 0 -> raw one-hot incl. mask column (vector_field.py:102-119)."""
-        a = self.a_token_dim if self.a_token_dim else self.n_atom_types + 1
-        c = self.c_token_dim if self.c_token_dim else self.n_charges + 1
-        e = self.e_token_dim if self.e_token_dim else self.n_bond_types + 1
+        m = 1 if self.has_mask else 0
+        a = self.a_token_dim if self.a_token_dim else self.n_atom_types + m
+        c = self.c_token_dim if self.c_token_dim else self.n_charges + m
+        e = self.e_token_dim if self.e_token_dim else self.n_bond_types + m
         return a, c, e
+
+    @property
+    def has_mask(self) -> bool:
+        """CTMC models carry a mask category in their categorical inputs (vector_field.py:100, ctmc_vector_field.py:36)."""
+        return self.parameterization == 'ctmc'
 
     @property
     def s_dst_feats(self) -> int:
@@ -154,6 +167,19 @@ class VFConfig:
         if self.n_atom_types + 1 > 16 or self.n_charges + 1 > 8 or self.n_bond_types + 1 > 8:
             raise NotImplementedError("categorical widths exceed kernel limits (a<=16, c<=8, e<=8 incl. mask)")
         self.msg_z  # raises for 'mean'
+        if self.parameterization not in ('ctmc', 'endpoint'):
+            raise NotImplementedError(f"parameterization {self.parameterization!r}: 'ctmc' and 'endpoint' are implemented "
+                                      "(the deprecated 'vector-field' / 'dirichlet' families are out of scope)")
+        if self.parameterization == 'endpoint':
+            if self.a_token_dim or self.c_token_dim or self.e_token_dim:
+                raise ValueError('token dims must be 0 for a non-CTMC parameterization (configs/dev.yml:105)')
+            if self.self_conditioning:
+                raise NotImplementedError('self-conditioning with the endpoint parameterization is not implemented (no such model ships)')
+            for k in 'ace':
+                if self.prior_types.get(k) not in ('gaussian', 'uniform-simplex', 'barycenter'):
+                    raise NotImplementedError(f"prior type {self.prior_types.get(k)!r} for {k!r}: implemented for endpoint models: gaussian, uniform-simplex, barycenter")
+            if self.continuous_inv_temp_schedule not in (None, 'linear'):
+                raise ValueError(f'Invalid continuous_inv_temp_schedule: {self.continuous_inv_temp_schedule}')
         for k in 'xace':
             st = self.schedule_type.get(k)
             if st not in ('linear', 'cosine'):
@@ -211,6 +237,13 @@ def from_reference_hparams(hp: dict) -> VFConfig:
         v = vf.get(unsupported)
         if v not in (None, False, 0, 0.0):
             raise NotImplementedError(f"vector_field.{unsupported}={v!r} is not implemented")
+    cfg.parameterization = hp.get('parameterization', 'endpoint')           # flowmol.py:40 default
+    pc = hp.get('prior_config', {}) or {}
+    if cfg.parameterization != 'ctmc':
+        cfg.prior_types = {k: (pc.get(k, {}) or {}).get('type') for k in 'ace'}
+        cfg.prior_kwargs = {k: dict((pc.get(k, {}) or {}).get('kwargs', {}) or {}) for k in 'ace'}
+        cfg.continuous_inv_temp_schedule = vf.get('continuous_inv_temp_schedule')
+        cfg.continuous_inv_temp_max = float(vf.get('continuous_inv_temp_max', 10.0))
     isc = hp.get('interpolant_scheduler_config', {}) or {}
     st = isc.get('schedule_type', 'cosine')                  # InterpolantScheduler's own default (interpolant_scheduler.py:9)
     cfg.schedule_type = {k: st for k in 'xace'} if isinstance(st, str) else {k: st[k] for k in 'xace'}

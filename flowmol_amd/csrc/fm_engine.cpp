@@ -61,7 +61,7 @@ struct fm_ctx {
     char* arena = nullptr; size_t arena_bytes = 0;
     const float *emb_a = nullptr, *emb_c = nullptr;
     MlpW node_embed{}, edge_embed{}, sc_node{}, sc_edge{}, node_head{}, edge_head{};
-    const float *node_ln_g = nullptr, *node_ln_b = nullptr;
+    const float *node_ln_g = nullptr, *node_ln_b = nullptr, *edge_ln_g = nullptr, *edge_ln_b = nullptr;
     const float *ef_tab = nullptr, *T1 = nullptr;          // (ne+1,128) each
     std::vector<ConvW> conv;
     std::vector<UpdW> upd;
@@ -268,7 +268,7 @@ void launch_mlp_pair(Launch& L, const char* name, FmMlpArgs a, const MlpW& wa, i
 // ---------------------------------------------------------------------------------------- one network evaluation
 template <int V, int TE, int TN, int HX>
 int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
-             bool taps_on) {
+             bool taps_on, const fm_dense_state* dense = nullptr, const float* temb = nullptr) {
     Launch L{c, st};
     const FmBatch& b = c->b;
     const int N = b.N, E = b.E, U = b.U;
@@ -279,7 +279,24 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
-    if (prev) {
+    const float* x_t = dense ? dense->x_t : state->x_t;
+    if (dense) {
+        // endpoint-parameterised model: the categorical inputs are continuous vectors, so the embeddings are real MLPs over the N
+        // node rows [a_t | c_t | temb] and the U pair rows e_t (vector_field.py:226-261) -- the same two-layer kernel the token
+        // tables use, fed with dense rows; pair rows are written to both directed edges.  Ps is free scratch until the first node_proj.
+        const int kp = c->node_embed.K1p;
+        L("dense_in", fm_k_dense_node_in, dim3(std::min(2048, (int)(((size_t)N * kp + 255) / 256))), dim3(256), 0, c->Ps, kp, N,
+          (const float*)dense->a_t, c->na, (const float*)dense->c_t, c->nc, temb, cf.time_embedding_dim);
+        FmMlpArgs a{};
+        a.in = c->Ps; a.in_ld = kp; a.out = c->s; a.out_ld = 256; a.ln_g = c->node_ln_g; a.ln_b = c->node_ln_b; a.ln_n = c->S;
+        launch_mlp<FM_MLP_TABLE>(L, "embed_nodes", a, c->node_embed, N);
+        FmMlpArgs e{};
+        e.in = dense->e_t; e.in_ld = c->ne; e.in_w = c->ne; e.out = c->ef; e.out_ld = 128; e.ln_g = c->edge_ln_g; e.ln_b = c->edge_ln_b; e.ln_n = c->F;
+        e.p_e0 = b.p_e0; e.p_e1 = b.p_e1;
+        launch_mlp<FM_MLP_TABLE>(L, "embed_pairs", e, c->edge_embed, U);
+        tap("embed.s", c->s, (size_t)N * 256 * 4);
+        tap("embed.ef", c->ef, (size_t)E * 128 * 4);
+    } else if (prev) {
         FmMlpArgs a = ma;
         a.s_tab = c->s_tab; a.tok_a = state->a_t; a.tok_c = state->c_t; a.n_c1 = nc1;
         a.prev_a = prev->a; a.prev_c = prev->c; a.prev_x = prev->x; a.x_t = state->x_t;
@@ -313,7 +330,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         if (i == 0 || !fuse) {      // later convs: projected in the previous conv's node_update
             FmProjArgs pa{};
             pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV; pa.pv_w = c->PVW;
-            if (i == 0) { pa.v_init = c->v; pa.x_src = state->x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
+            if (i == 0) { pa.v_init = c->v; pa.x_src = x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
             L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
         }
         FmMsgArgs m{};
@@ -503,6 +520,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (cfg->n_atom_types + 1 > 16 || cfg->n_charges + 1 > 16 || cfg->n_bond_types + 1 > 16 || cfg->n_atom_types + cfg->n_charges > 32)
         return fail(nullptr, FM_ERR_INVALID, "fm_create: categorical widths exceed kernel limits");
     const bool tok = cfg->a_token_dim > 0;
+    const int mk = cfg->has_mask ? 1 : 0;       // CTMC models: one mask category per categorical input
+    if (!mk && (tok || cfg->self_conditioning)) return fail(nullptr, FM_ERR_INVALID, "fm_create: endpoint-parameterised models (has_mask = 0) take raw categorical vectors (token dims 0) and no self-conditioning");
     if ((cfg->c_token_dim > 0) != tok || (cfg->e_token_dim > 0) != tok) return fail(nullptr, FM_ERR_INVALID, "fm_create: token dims must be all zero or all non-zero");
 
     fm_ctx* c = new fm_ctx();
@@ -522,7 +541,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     auto ident = [](int k) { return k; };
 
     // ---- input embeddings
-    const int ta = tok ? cfg->a_token_dim : na + 1, tc = tok ? cfg->c_token_dim : nc + 1, te = tok ? cfg->e_token_dim : ne + 1;
+    const int ta = tok ? cfg->a_token_dim : na + mk, tc = tok ? cfg->c_token_dim : nc + mk, te = tok ? cfg->e_token_dim : ne + mk;
     const int tt = cfg->time_embedding_dim;
     const float* emb_e = nullptr;
     if (tok) {
@@ -559,13 +578,19 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     std::vector<float> ef_tab((size_t)(ne + 1) * 128), T1((size_t)(ne + 1) * 128, 0.f);
     for (int t = 0; t <= ne; ++t) {
         std::vector<float> in(te, 0.f), h1(F), h2(F);
-        if (tok) for (int k = 0; k < te; ++k) in[k] = emb_e[t * te + k]; else in[t] = 1.f;
+        if (tok) for (int k = 0; k < te; ++k) in[k] = emb_e[t * te + k]; else if (t < te) in[t] = 1.f;
         for (int n = 0; n < F; ++n) { float acc = ee_b1[n]; for (int k = 0; k < te; ++k) acc = fmaf(ee_W1[n * te + k], in[k], acc); h1[n] = acc / (1.0f + expf(-acc)); }
         for (int n = 0; n < F; ++n) { float acc = ee_b2[n]; for (int k = 0; k < F; ++k) acc = fmaf(ee_W2[n * F + k], h1[k], acc); h2[n] = acc / (1.0f + expf(-acc)); }
         double mean = 0; for (float x : h2) mean += x; mean /= F;
         double var = 0; for (float x : h2) var += (x - mean) * (x - mean); var /= F;
         const float rstd = (float)(1.0 / std::sqrt(var + 1e-5));
         for (int n = 0; n < F; ++n) ef_tab[(size_t)t * 128 + n] = (h2[n] - (float)mean) * rstd * ee_g[n] + ee_b[n];      // columns F..127 stay 0
+    }
+    if (!mk) {      // dense edge embedding of endpoint models: the same MLP as a device kernel over the pair rows
+        c->edge_embed.K1p = pad8(te); c->edge_embed.H = 128; c->edge_embed.O = 128;
+        pack_linear(B, c->edge_embed.W1, ee_W1, F, te, pad8(te), 128, ident); pad_vec(B, c->edge_embed.b1, ee_b1, F, 128);
+        pack_linear(B, c->edge_embed.W2, ee_W2, F, F, 128, 128, ident); pad_vec(B, c->edge_embed.b2, ee_b2, F, 128);
+        pad_vec(B, c->edge_ln_g, ee_g, F, 128); pad_vec(B, c->edge_ln_b, ee_b, F, 128);
     }
     // ---- self-conditioning
     if (cfg->self_conditioning) {
@@ -775,9 +800,9 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
     // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
     w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
-    if (c->HX && (w.tm_edge > 32)) w.tm_edge = 32;
+    if ((c->HX || !c->cfg.has_mask) && (w.tm_edge > 32)) w.tm_edge = 32;
     w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 31) / 32 <= c->n_cus ? 16 : 32);
-    if (c->HX && (w.tm_node > 32)) w.tm_node = 32;
+    if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
     w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
@@ -887,7 +912,35 @@ int fm_forward(fm_ctx* c, void* stream, const fm_state* state, const float* temb
                const fm_dst* out) {
     if (!c || !state || !temb || !out) return fail(c, FM_ERR_INVALID, "fm_forward: null argument");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_forward: no batch bound");
+    if (!c->cfg.has_mask) return fail(c, FM_ERR_INVALID, "fm_forward: endpoint-parameterised model (continuous inputs): use fm_forward_dense");
     return forward_impl(c, (hipStream_t)stream, state, temb, prev, bootstrap, remove_com ? 1 : 0, out);
+}
+
+int fm_forward_dense(fm_ctx* c, void* stream, const fm_dense_state* state, const float* temb, int remove_com, const fm_dst* out) {
+    if (!c || !state || !temb || !out) return fail(c, FM_ERR_INVALID, "fm_forward_dense: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_forward_dense: no batch bound");
+    if (c->cfg.has_mask) return fail(c, FM_ERR_INVALID, "fm_forward_dense: this is a CTMC model (token inputs): use fm_forward");
+#define FM_EVAL_D(V_, TE_, TN_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_ && c->HX == 0) \
+        return evaluate<V_, TE_, TN_, 0>(c, (hipStream_t)stream, nullptr, nullptr, remove_com ? 1 : 0, out, true, state, temb);
+    FM_EVAL_D(32, 16, 16) FM_EVAL_D(32, 16, 32) FM_EVAL_D(32, 32, 16) FM_EVAL_D(32, 32, 32) FM_EVAL_D(16, 16, 16) FM_EVAL_D(16, 16, 32) FM_EVAL_D(16, 32, 16) FM_EVAL_D(16, 32, 32)
+#undef FM_EVAL_D
+    return fail(c, FM_ERR_INVALID, "fm_forward_dense: no kernel instantiation for V=%d tile_edge=%d tile_node=%d dst_vectors=%d", c->V, c->tm_edge, c->tm_node, c->HX);
+}
+
+int fm_endpoint_step(fm_ctx* c, void* stream, const fm_dense_state* state, const fm_dst* dst, const fm_endpoint_scalars* sc) {
+    if (!c || !state || !dst || !sc) return fail(c, FM_ERR_INVALID, "fm_endpoint_step: null argument");
+    if (!c->bound) return fail(c, FM_ERR_STATE, "fm_endpoint_step: no batch bound");
+    const FmBatch& b = c->b;
+    FmEndpointStepArgs a{};
+    float* xt[4] = {state->x_t, state->a_t, state->c_t, state->e_t};
+    const float* x1[4] = {dst->x, dst->a, dst->c, dst->e};
+    const int n[4] = {b.N * 3, b.N * c->na, b.N * c->nc, b.U * c->ne};
+    int nmax = 0;
+    for (int f = 0; f < 4; ++f) { a.xt[f] = xt[f]; a.x1[f] = x1[f]; a.n[f] = n[f]; a.coef[f] = sc->coef[f]; nmax = std::max(nmax, n[f]); }
+    a.scale = sc->scale; a.dt = sc->dt;
+    Launch L{c, (hipStream_t)stream};
+    L("endpoint_step", fm_k_endpoint_step, dim3(std::min(4096, (nmax + 255) / 256), 4), dim3(256), 0, a);
+    return L.rc;
 }
 
 int fm_ctmc_step(fm_ctx* c, void* stream, const fm_state* state, const fm_dst* dst, const fm_step_noise* noise, const fm_step_scalars* sc,

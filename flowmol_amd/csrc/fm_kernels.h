@@ -79,6 +79,7 @@ struct FmMlpArgs {
     const float* ln_g; const float* ln_b; int ln_n;     // TABLE: LayerNorm affine + the REAL width its statistics run over (<= O)
     // generic sources / destinations
     const float* in;  int in_ld;              // TABLE: dense input
+    int in_w;                                 // TABLE: valid input columns (0 = K1p); columns beyond read 0
     float* out; int out_ld;                   // TABLE / SC_NODE / heads
     // node-side
     const float* s_tab; const int* tok_a; const int* tok_c; int n_c1;   // s_tab row = tok_a*(n_c1)+tok_c
@@ -108,7 +109,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             const int r = idx / a.K1p, c = idx % a.K1p, row = row0 + r;
             float v = 0.f;
             if (row < a.rows) {
-                if (a.in) v = a.in[(size_t)row * a.in_ld + c];
+                if (a.in) v = (a.in_w == 0 || c < a.in_w) ? a.in[(size_t)row * a.in_ld + c] : 0.f;
                 else {      // input row of the (a,c) embedding table, built in place (vector_field.py:228-243)
                     const int ia = row / a.n_c1, ic = row % a.n_c1;
                     if (c < a.ta) v = a.emb_a ? a.emb_a[ia * a.ta + c] : (c == ia ? 1.f : 0.f);
@@ -254,9 +255,16 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
     if (MODE == FM_MLP_TABLE) {
         float mean, rstd;
         fm_row_stats8(X + r * a.ldx, a.ln_n, sub, mean, rstd);
-        if (grow < a.rows)
-            for (int c = sub; c < a.O; c += 8)
-                a.out[(size_t)grow * a.out_ld + c] = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
+        if (grow < a.rows) {
+            // rows of a per-pair table (dense edge embedding of endpoint models) go to both directed edges of the pair
+            float* o0 = a.out + (size_t)(a.p_e0 ? a.p_e0[grow] : grow) * a.out_ld;
+            float* o1 = a.p_e1 ? a.out + (size_t)a.p_e1[grow] * a.out_ld : nullptr;
+            for (int c = sub; c < a.O; c += 8) {
+                const float y = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
+                o0[c] = y;
+                if (o1) o1[c] = y;
+            }
+        }
     } else if (MODE == FM_MLP_SC_NODE) {
         if (grow < a.rows) {
             const float* trow = a.s_tab + (size_t)meta[r] * 256;
@@ -1013,6 +1021,31 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
 // ------------------------------------------------------------------------------------------------
 // small element-wise kernels
 // ------------------------------------------------------------------------------------------------
+// endpoint-parameterised models: node rows of the scalar embedding's input [a_t | c_t | temb | 0] (vector_field.py:228-243)
+__global__ void __launch_bounds__(256) fm_k_dense_node_in(float* __restrict__ out, int ld, int N, const float* __restrict__ a, int na,
+                                                           const float* __restrict__ c, int nc, const float* __restrict__ temb, int tt) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)N * ld; idx += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / ld), k = (int)(idx % ld);
+        float v = 0.f;
+        if (k < na) v = a[(size_t)n * na + k];
+        else if (k < na + nc) v = c[(size_t)n * nc + (k - na)];
+        else if (k < na + nc + tt) v = temb[k - na - nc];
+        out[idx] = v;
+    }
+}
+
+// EndpointVectorField.step (vector_field.py:528-543) for one flat feature array per blockIdx.y:
+//   vf = coef * (x_1 - x_t);  vf = vf * scale;  x_s = x_t + vf * dt      (never-contracted, as torch's separately rounded ops)
+struct FmEndpointStepArgs { float* xt[4]; const float* x1[4]; int n[4]; float coef[4]; float scale, dt; };
+__global__ void __launch_bounds__(256) fm_k_endpoint_step(FmEndpointStepArgs a) {
+    const int f = blockIdx.y;
+    float* xt = a.xt[f]; const float* x1 = a.x1[f];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[f]; i += gridDim.x * blockDim.x) {
+        const float vf = fm_mul_rn(fm_mul_rn(a.coef[f], fm_sub_rn(x1[i], xt[i])), a.scale);
+        xt[i] = fm_add_rn(xt[i], fm_mul_rn(vf, a.dt));
+    }
+}
+
 // x -= per-molecule mean (vector_field.py:347-350); one 64-lane workgroup per molecule
 __global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, const int* __restrict__ mol_node_off) {
     const int m = blockIdx.x, lane = threadIdx.x;

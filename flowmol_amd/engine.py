@@ -15,7 +15,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (FM_DFM_CAMPBELL, FM_DFM_GAT, FM_NOISE_PHILOX, FlowMolHipError, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
+from ._lib import (FM_DFM_CAMPBELL, FM_DFM_GAT, FM_NOISE_PHILOX, FlowMolHipError, fm_dense_state, fm_endpoint_scalars, fm_config, fm_dst, fm_sampled, fm_state, fm_step_noise, fm_step_scalars,
                    fm_tensor_desc, fm_traj_sink)
 from .config import VFConfig
 from .weights import check_state_dict, state_dict_shapes
@@ -242,6 +242,7 @@ class Engine:
         c.rbf_dmax = float(cfg.rbf_dmax)
         c.msg_z = float(cfg.msg_z)
         c.s_dst_feats, c.v_dst_feats = cfg.s_dst_feats, cfg.v_dst_feats
+        c.has_mask = int(cfg.has_mask)
         self._ctx = C.c_void_p()
         with self._dev():
             rc = self.lib.fm_create(C.byref(c), descs, len(shapes), C.c_void_p(blob.data_ptr()), C.byref(self._ctx))
@@ -415,6 +416,72 @@ class Engine:
             self.lib.fm_clear_taps(self._ctx)
         self._keep = [temb, state, out, prev]
         return out
+
+    # ------------------------------------------------------------------ endpoint parameterization (EndpointVectorField)
+    @staticmethod
+    def _dense_struct(st) -> fm_dense_state:
+        s = fm_dense_state()
+        s.x_t, s.a_t, s.c_t, s.e_t = _ptr(st['x_t']), _ptr(st['a_t']), _ptr(st['c_t']), _ptr(st['e_t'])
+        return s
+
+    def make_dense_state(self, x_t, a_t, c_t, e_t) -> Dict[str, torch.Tensor]:
+        """x_t (N,3), a_t (N,na), c_t (N,nc), e_t (U,ne): continuous features of an endpoint-parameterised model (copies)."""
+        d = self.device
+        st = {k: v.detach().to(d, torch.float32).contiguous().clone() for k, v in (('x_t', x_t), ('a_t', a_t), ('c_t', c_t), ('e_t', e_t))}
+        assert st['x_t'].shape == (self.N, 3) and st['a_t'].shape == (self.N, self.cfg.n_atom_types)
+        assert st['c_t'].shape == (self.N, self.cfg.n_charges) and st['e_t'].shape == (self.U, self.cfg.n_bond_types)
+        return st
+
+    def forward_dense(self, state, t: float, remove_com=True, out=None, taps: Optional[Dict[str, torch.Tensor]] = None):
+        """EndpointVectorField.forward on continuous categorical features (vector_field.py:212-293, no self-conditioning)."""
+        out = out if out is not None else self.new_dst()
+        temb = time_embedding_host(float(t), self.cfg.time_embedding_dim).to(self.device)
+        st, o = self._dense_struct(state), self._dst_struct(out)
+        self.lib.fm_clear_taps(self._ctx)
+        if taps:
+            for k, v in taps.items():
+                self._check(self.lib.fm_set_tap(self._ctx, k.encode(), _ptr(v)), 'fm_set_tap')
+        with self._dev():
+            rc = self.lib.fm_forward_dense(self._ctx, self._stream(), C.byref(st), _ptr(temb), int(bool(remove_com)), C.byref(o))
+        self._check(rc, 'fm_forward_dense')
+        if taps:
+            self.lib.fm_clear_taps(self._ctx)
+        self._keep = [temb, state, out]
+        return out
+
+    def endpoint_step(self, state, dst, dt: float, coef, scale: float = 1.0):
+        """x_s = x_t + ((coef (x_1 - x_t)) scale) dt for x, a, c, e in place (EndpointVectorField.step, vector_field.py:528-543)."""
+        sc = fm_endpoint_scalars()
+        sc.dt, sc.scale = float(dt), float(scale)
+        for k in range(4):
+            sc.coef[k] = float(coef[k])
+        st, d = self._dense_struct(state), self._dst_struct(dst)
+        with self._dev():
+            rc = self.lib.fm_endpoint_step(self._ctx, self._stream(), C.byref(st), C.byref(d), C.byref(sc))
+        self._check(rc, 'fm_endpoint_step')
+        return state
+
+    def integrate_endpoint(self, state, n_timesteps: int, inv_temp_func=None, tspan=None):
+        """EndpointVectorField.integrate (vector_field.py:388-499): Euler steps of all four modalities; the per-step scalars are computed
+        with the reference's float32 tensor arithmetic on the host, the steps are enqueued back to back (no host synchronisation)."""
+        cfg = self.cfg
+        t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32).clone()
+        alpha, alpha_p = alpha_tables(t, cfg.schedule_type, cfg.cosine_params)
+        if inv_temp_func is None:
+            if cfg.continuous_inv_temp_schedule == 'linear':
+                mx = cfg.continuous_inv_temp_max
+                inv_temp_func = lambda tt: mx * (1 - tt)                     # vector_field.py:203-204
+            else:
+                inv_temp_func = lambda tt: 1.0
+        dst = [self.new_dst(), self.new_dst()]
+        for s_idx in range(1, t.shape[0]):
+            s_i, t_i = t[s_idx], t[s_idx - 1]
+            a_i, ap_i = alpha[s_idx - 1], alpha_p[s_idx - 1]
+            out = dst[s_idx & 1]
+            self.forward_dense(state, float(t_i), remove_com=True, out=out)
+            self.endpoint_step(state, out, float(s_i - t_i), [float(ap_i[k] / (1 - a_i[k])) for k in range(4)], _f32(inv_temp_func(t_i)))
+        self.synchronize()
+        return dst[(t.shape[0] - 1) & 1] if t.shape[0] > 1 else None
 
     def ctmc_step(self, state, dst, noise: StepNoise, sc: fm_step_scalars, sampled: Optional[Dict[str, torch.Tensor]] = None):
         st = self._state_struct(state)

@@ -64,7 +64,7 @@ def read_checkpoint(path):
     return dict(ck['hyper_parameters']), ck['state_dict']
 
 
-SUPPORTED_PARAMETERIZATIONS = ('ctmc',)
+SUPPORTED_PARAMETERIZATIONS = ('ctmc', 'endpoint')
 SUPPORTED_SCHEDULES = ('linear', 'cosine')
 
 
@@ -88,8 +88,12 @@ def check_reference_hparams(hp: dict) -> None:
     if xt != 'centered-normal':
         raise NotImplementedError(f"position prior {xt!r}: only 'centered-normal' is implemented (a 'gaussian' prior would be centred silently)")
     for mod in ('a', 'c', 'e'):
-        if (pc.get(mod, {}) or {}).get('type', 'ctmc') != 'ctmc':
+        mt = (pc.get(mod, {}) or {}).get('type')
+        if par == 'ctmc' and (mt or 'ctmc') != 'ctmc':
             raise NotImplementedError('only ctmc masked priors are supported for CTMC models (as in the reference, flowmol.py:189-193)')
+        if par == 'endpoint' and mt not in ('gaussian', 'uniform-simplex', 'barycenter'):
+            raise NotImplementedError(f"categorical prior {mt!r} of an endpoint model: implemented: gaussian, uniform-simplex, barycenter "
+                                      "('marginal' / 'c-given-a' need the dataset's marginal files)")
     if hp.get('exclude_charges', False):
         raise NotImplementedError('exclude_charges=True is not implemented (no shipped v3 model uses it)')
 
@@ -110,7 +114,7 @@ class FlowMol:
         self.fake_atoms = cfg.fake_atoms
         self.explicit_aromaticity = cfg.explicit_aromaticity
         self.default_n_timesteps = cfg.default_n_timesteps
-        self.parameterization = 'ctmc'
+        self.parameterization = cfg.parameterization
         self.device = torch.device('cpu')
         self._engine: Optional[Engine] = None
         self.build_n_atoms_dist(n_atoms_hist or cfg.n_atoms_hist)
@@ -241,6 +245,8 @@ class FlowMol:
         eng = self.engine
         dev = eng.device
         n_timesteps = self.default_n_timesteps if n_timesteps is None else n_timesteps
+        if self.cfg.parameterization == 'endpoint':
+            return self._sample_endpoint(n_atoms, n_timesteps, xt_traj, ep_traj, prior, return_tensors, kwargs)
         # integrator variants of CTMCVectorField.integrate/step (ctmc_vector_field.py:145-156,287-315): all optional
         dfm_type = kwargs.get('dfm_type') or self.cfg.dfm_type
         if dfm_type not in ('campbell', 'gat'):
@@ -322,6 +328,68 @@ class FlowMol:
         self.last_timing['package'] = time.perf_counter() - t2
         return mols
 
+    # ------------------------------------------------------------------ endpoint-parameterised models
+    @staticmethod
+    def _categorical_prior(kind: str, n: int, d: int, kw: dict) -> torch.Tensor:
+        """The reference's prior functions on the CPU generator, as FlowMol.sample_prior calls them (priors.py:8-68; flowmol.py:426-441)."""
+        if kind == 'gaussian':
+            p = torch.randn(n, d) * kw.get('std', 1.0)
+            return p + 1 / d if kw.get('simplex_center', False) else p
+        if kind == 'uniform-simplex':
+            sample = torch.distributions.Exponential(torch.tensor(1.0)).sample((n, d))
+            return sample / sample.sum(dim=1, keepdim=True)
+        if kind == 'barycenter':
+            if kw.get('blur', 0.0) != 0.0:
+                raise NotImplementedError('barycenter prior with blur needs the simplex projection of flowmol/utils/dirflow.py')
+            return torch.ones(n, d) / d
+        raise NotImplementedError(f'prior type {kind!r}')
+
+    def _sample_endpoint(self, n_atoms, n_timesteps, xt_traj, ep_traj, prior, return_tensors, kwargs):
+        """FlowMol.sample for parameterization='endpoint' (flowmol.py:489-589 with EndpointVectorField.integrate, vector_field.py:388-499):
+        the categorical modalities are continuous vectors integrated with the same Euler step as the positions; the sampled
+        molecule takes their argmax.  RNG order = the reference's: randn(N,3) on the device, then a, c, e priors on the CPU generator."""
+        if xt_traj or ep_traj:
+            raise NotImplementedError('trajectory frames are implemented for CTMC models')
+        unknown = set(kwargs) - {'inv_temp_func', 'tspan'}
+        if unknown:
+            raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
+        eng, cfg = self.engine, self.cfg
+        dev = eng.device
+        n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
+        eng.bind(n_atoms)
+        N, U = eng.N, eng.U
+        if prior is None:
+            x0 = torch.randn(N, 3, device=dev)
+            eng.remove_com(x0)
+            pk = cfg.prior_kwargs
+            a0 = self._categorical_prior(cfg.prior_types['a'], N, cfg.n_atom_types, pk.get('a', {}))
+            c0 = self._categorical_prior(cfg.prior_types['c'], N, cfg.n_charges, pk.get('c', {}))
+            e0 = self._categorical_prior(cfg.prior_types['e'], U, cfg.n_bond_types, pk.get('e', {}))
+        else:
+            x0, a0, c0 = prior['x_0'], prior['a_0'], prior['c_0']
+            e0 = prior['e_0']
+            if e0.shape[0] == eng.E:          # directed edges, upper block first per molecule -> keep the upper halves
+                idx, off = [], 0
+                for k in n_atoms.tolist():
+                    u = k * (k - 1) // 2
+                    idx.append(torch.arange(off, off + u))
+                    off += 2 * u
+                e0 = e0[torch.cat(idx)]
+        state = eng.make_dense_state(x0, a0, c0, e0)
+        import time
+        t0 = time.perf_counter()
+        eng.integrate_endpoint(state, n_timesteps, inv_temp_func=kwargs.get('inv_temp_func'), tspan=kwargs.get('tspan'))
+        self.last_timing = {'integrate': time.perf_counter() - t0}
+        if return_tensors == 'dense':
+            return {k: state[f'{k}_t'] for k in 'xace'}, n_atoms
+        out_dev = {'x': state['x_t'], 'a': state['a_t'].argmax(-1).int(), 'c': state['c_t'].argmax(-1).int(), 'e': state['e_t'].argmax(-1).int()}
+        if return_tensors == 'device':
+            return out_dev, n_atoms
+        out = _to_host(out_dev)
+        if return_tensors:
+            return out, n_atoms
+        return self._package(out, n_atoms, None, False, False)
+
     # ------------------------------------------------------------------ helpers
     def _state_from_prior(self, prior):
         """Reference-format prior dict: x_0 (N,3), a_0/c_0 one-hot (N,*), e_0 one-hot (E,*) in reference edge order."""
@@ -355,7 +423,7 @@ class FlowMol:
         for i in range(len(sizes)):
             tf = {k: v[i] for k, v in fr.items()} if fr is not None else None
             mols.append(SampledMolecule(xs[i], as_[i], cs[i], es[i], self.atom_type_map, fake_atoms=self.fake_atoms,
-                                        ctmc_mol=True, explicit_aromaticity=self.explicit_aromaticity, traj_frames=tf,
+                                        ctmc_mol=self.cfg.has_mask, explicit_aromaticity=self.explicit_aromaticity, traj_frames=tf,
                                         build_xt_traj=xt_traj, build_ep_traj=ep_traj))
         return mols
 

@@ -66,4 +66,20 @@ def dev() -> VFConfig:
     return cfg.validate()
 
 
-PRESETS = {'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}
+def endpoint_small() -> VFConfig:
+    """An endpoint-parameterised model (EndpointVectorField, vector_field.py:15-564: the FlowMol v1 family -- no YAML of it ships in
+    the tree): continuous categorical features without a mask state, token dims 0, Gaussian / simplex priors, no self-conditioning."""
+    return VFConfig(
+        atom_type_map=list(QM9_ATOMS), fake_atoms=False, parameterization='endpoint',
+        n_vec_channels=16, n_cp_feats=4, n_hidden_scalars=256, n_hidden_edge_feats=128,
+        n_molecule_updates=3, convs_per_update=1, separate_mol_updaters=True,
+        message_norm=100, update_edge_w_distance=True, rbf_dmax=12.0, rbf_dim=32,
+        time_embedding_dim=1, a_token_dim=0, c_token_dim=0, e_token_dim=0,
+        self_conditioning=False, stochasticity=0.0, high_confidence_threshold=0.0,
+        prior_types={'a': 'gaussian', 'c': 'uniform-simplex', 'e': 'barycenter'},
+        prior_kwargs={'a': {'std': 1.0, 'simplex_center': True}, 'c': {}, 'e': {}},
+        n_atoms_hist='qm9',
+    ).validate()
+
+
+PRESETS = {'endpoint_small': endpoint_small, 'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}

@@ -75,6 +75,9 @@ typedef struct fm_config {
      * features that join every message's inputs; 0 / 0 = off */
     int32_t s_dst_feats;          /* int(n_hidden_scalars / dst_feat_msg_reduction_factor) */
     int32_t v_dst_feats;          /* int(n_vec_channels / dst_feat_msg_reduction_factor), <= 8 */
+    /* --- ABI 3: 1 = CTMC model (categorical inputs are tokens with a mask state, CTMCVectorField); 0 = endpoint-parameterised model
+     * (EndpointVectorField, flowmol/models/vector_field.py:15-211: categorical inputs are continuous (rows, n) vectors, token dims 0) */
+    int32_t has_mask;
 } fm_config;
 
 /* one tensor of the reference state dict inside the host weight blob */
@@ -98,6 +101,19 @@ typedef struct fm_state {         /* g.ndata['x_t','a_t','c_t'], g.edata['e_t'] 
     int32_t* c_t;                 /* (N) */
     int32_t* e_t;                 /* (U) */
 } fm_state;
+
+typedef struct fm_dense_state {   /* endpoint-parameterised models: g.ndata['x_t','a_t','c_t'], g.edata['e_t'][upper] as float features */
+    float* x_t;                   /* (N,3) */
+    float* a_t;                   /* (N,n_atom_types) */
+    float* c_t;                   /* (N,n_charges) */
+    float* e_t;                   /* (U,n_bond_types), per unordered pair */
+} fm_dense_state;
+
+typedef struct fm_endpoint_scalars {   /* EndpointVectorField.step, vector_field.py:501-564, host-computed in float32 */
+    float dt;                     /* s_i - t_i */
+    float coef[4];                /* x, a, c, e: alpha'/(1 - alpha) */
+    float scale;                  /* inv_temp_func(t_i): 1, or continuous_inv_temp_max * (1 - t_i) */
+} fm_endpoint_scalars;
 
 typedef struct fm_step_noise {    /* draws of one CTMC step, in the reference's order and shapes */
     const float* q_a;  const float* u1_a;  const float* u2_a;    /* (N,na) Exp(1), (N) U, (N) U */
@@ -171,6 +187,12 @@ int fm_prior_philox(fm_ctx* ctx, void* stream, uint64_t seed, float* x0);
  * result is used as `prev`.  out.a/c/e receive softmax probabilities, out.x is COM-free iff remove_com. */
 int fm_forward(fm_ctx* ctx, void* stream, const fm_state* state, const float* temb, const fm_dst* prev,
                int bootstrap, int remove_com, const fm_dst* out);
+
+/* Endpoint-parameterised models (has_mask == 0): one network evaluation on continuous categorical features (no self-conditioning),
+ * and the Euler step of all four modalities  x_s = x_t + ((coef * (x_1 - x_t)) * scale) * dt  given the endpoint prediction `dst`
+ * (EndpointVectorField.forward / .step, flowmol/models/vector_field.py:212-293, 501-564). */
+int fm_forward_dense(fm_ctx* ctx, void* stream, const fm_dense_state* state, const float* temb, int remove_com, const fm_dst* out);
+int fm_endpoint_step(fm_ctx* ctx, void* stream, const fm_dense_state* state, const fm_dst* dst, const fm_endpoint_scalars* sc);
 
 /* Euler step for x and the CTMC update of a, c, e given the endpoint prediction `dst` */
 int fm_ctmc_step(fm_ctx* ctx, void* stream, const fm_state* state, const fm_dst* dst,

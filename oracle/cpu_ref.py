@@ -579,6 +579,52 @@ class OracleVF:
             return out, frames
         return out
 
+    # ---------------- endpoint parameterization (EndpointVectorField.step / integrate, vector_field.py:388-569)
+    def step_endpoint(self, batch: Batch, state, s_i, t_i, alpha_t_i, alpha_tp_i, prev=None, inv_temp=1.0):
+        """One Euler step of all four modalities: x_s = x_t + (alpha'/(1-alpha) (x_1 - x_t)) * inv_temp * (s - t); the categorical
+        features are continuous vectors (no mask state); edge state lives on the upper triangle and is mirrored."""
+        dst = self.forward(batch, state['x_t'], state['a_t'], state['c_t'], state['e_t'], torch.full((batch.B,), float(t_i)), prev=prev,
+                           apply_softmax=True, remove_com=True)
+        m = batch.upper_edge_mask
+        new = {}
+        for idx, k in enumerate('xace'):
+            x_t = state[f'{k}_t']
+            x_1 = dst[k]
+            if k == 'e':
+                x_t = x_t[m]
+            vf = alpha_tp_i[idx] / (1 - alpha_t_i[idx]) * (x_1 - x_t)
+            vf = vf * inv_temp
+            x_s = x_t + vf * (s_i - t_i)
+            if k == 'e':
+                full = torch.zeros_like(state['e_t'])
+                full[m] = x_s
+                full[~m] = x_s
+                x_s = full
+                one = torch.zeros_like(state['e_t'])
+                one[m] = x_1
+                one[~m] = x_1
+                x_1 = one
+            new[f'{k}_t'] = x_s
+            new[f'{k}_1_pred'] = x_1.detach().clone()
+        return new, dst
+
+    def integrate_endpoint(self, batch: Batch, prior, n_timesteps: int, inv_temp_func=None):
+        cfg = self.cfg
+        t = torch.linspace(0, 1, n_timesteps)
+        alpha_t, alpha_tp = alpha_tables(t, getattr(cfg, 'schedule_type', None), getattr(cfg, 'cosine_params', None))
+        if inv_temp_func is None:
+            if cfg.continuous_inv_temp_schedule == 'linear':
+                inv_temp_func = lambda tt: cfg.continuous_inv_temp_max * (1 - tt)           # vector_field.py:203-204
+            else:
+                inv_temp_func = lambda tt: 1.0
+        state = {'x_t': prior['x_0'], 'a_t': prior['a_0'], 'c_t': prior['c_0'], 'e_t': prior['e_0']}
+        dst = None
+        for s_idx in range(1, t.shape[0]):
+            new, dst = self.step_endpoint(batch, state, t[s_idx], t[s_idx - 1], alpha_t[s_idx - 1], alpha_tp[s_idx - 1], prev=dst,
+                                          inv_temp=inv_temp_func(t[s_idx - 1]))
+            state = {k: new[k] for k in ('x_t', 'a_t', 'c_t', 'e_t')}
+        return {'x_1': state['x_t'], 'a_1': state['a_t'], 'c_1': state['c_t'], 'e_1': state['e_t']}
+
     def sample_prior(self, batch: Batch, device='cpu'):
         """FlowMol.sample_prior, flowmol.py:417-448 (RNG use: one randn(N,3))."""
         return {

@@ -250,6 +250,49 @@ def gen_integrate_cosine(ns, cfg, sd, sizes):
     np.savez_compressed(OUT / 'integrate_qm9_cosine.npz', **_np(out))
 
 
+def endpoint_prior(cfg, n_atoms, seed):
+    """Priors of an endpoint-parameterised model drawn with the reference's own prior functions (priors.py:8-68,305-316)."""
+    import importlib
+    pr = importlib.import_module('flowmol.data_processing.priors')
+    N = int(n_atoms.sum())
+    U = int((n_atoms * (n_atoms - 1) // 2).sum())
+    torch.manual_seed(seed)
+    out = {}
+    for k, rows, d in (('a', N, cfg.n_atom_types), ('c', N, cfg.n_charges), ('e', U, cfg.n_bond_types)):
+        out[k] = pr.train_prior_register[cfg.prior_types[k]](rows, d, **cfg.prior_kwargs.get(k, {}))
+    return out
+
+
+def gen_integrate_endpoint(ns):
+    """Free-running trajectory of the reference's EndpointVectorField (vector_field.py:388-569): Euler steps of x, a, c, e as
+    continuous features, 'linear' inverse-temperature schedule of the vector field, priors from the reference's prior functions."""
+    import dataclasses
+    cfg = dataclasses.replace(presets.endpoint_small(), continuous_inv_temp_schedule='linear', continuous_inv_temp_max=1.5)
+    sd = weights.synth_state_dict(cfg, 0)
+    vf = ref_standin.build_reference_vf(ns, cfg, sd)
+    n_atoms = torch.tensor([6, 3, 9, 2])
+    g, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
+    torch.manual_seed(21)
+    x0 = ns.centered_normal_prior_batched_graph(g, nb)
+    pri = endpoint_prior(cfg, n_atoms, 22)
+    e0 = torch.zeros(g.num_edges(), cfg.n_bond_types)
+    e0[upper] = pri['e']; e0[~upper] = pri['e']
+    g.ndata['x_0'], g.ndata['a_0'], g.ndata['c_0'], g.edata['e_0'] = x0, pri['a'], pri['c'], e0
+    T = 9
+    with torch.no_grad():
+        gout, frames = vf.integrate(g, nb, upper_edge_mask=upper, n_timesteps=T, visualize=True)
+        # one forward pass of the prior state on its own (the dense-embedding path of the network)
+        g2, _, _, _ = ref_standin.build_reference_graph(ns, n_atoms)
+        g2.ndata['x_t'], g2.ndata['a_t'], g2.ndata['c_t'], g2.edata['e_t'] = x0, pri['a'], pri['c'], e0
+        d0 = vf(g2, t=torch.full((4,), 0.25), node_batch_idx=nb, upper_edge_mask=upper, apply_softmax=True, remove_com=True, prev_dst_dict=None)
+    out = {'n_atoms': n_atoms, 'T': T, 'x_0': x0, 'a_0': pri['a'], 'c_0': pri['c'], 'e_0_upper': pri['e'],
+           'x_1': gout.ndata['x_1'], 'a_1': gout.ndata['a_1'], 'c_1': gout.ndata['c_1'], 'e_1_upper': gout.edata['e_1'][upper],
+           'e_1_sym': torch.equal(gout.edata['e_1'][upper], gout.edata['e_1'][~upper]),
+           'traj0.x': frames[0]['x'], 'traj0.a': frames[0]['a'], 'traj0.x_1_pred': frames[0]['x_1_pred']}
+    out.update({f'fwd.{k}': v for k, v in d0.items()})
+    np.savez_compressed(OUT / 'integrate_endpoint.npz', **_np(out))
+
+
 def _ref_function(path, name, cls=None):
     """Source-level import of ONE function (or method of class ``cls``) of a reference module that cannot be
     imported here as a whole (rdkit at module scope): parsed with ast, compiled and executed in this container
@@ -510,6 +553,7 @@ def main():
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'gat', 'gat')
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'sched', 'campbell')
     gen_integrate_cosine(ns, cfg, sd, [6, 3, 8])
+    gen_integrate_endpoint(ns)
     for f in sorted(OUT.glob('*.npz')):
         print(f.name, f.stat().st_size // 1024, 'KiB')
 

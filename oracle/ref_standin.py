@@ -196,6 +196,7 @@ def import_reference():
     ns.GVP, ns.GVPConv, ns.GVPLayerNorm = gvp.GVP, gvp.GVPConv, gvp.GVPLayerNorm
     vf = importlib.import_module('flowmol.models.vector_field')
     ns.NodePositionUpdate, ns.EdgeUpdate = vf.NodePositionUpdate, vf.EdgeUpdate
+    ns.EndpointVectorField = vf.EndpointVectorField
     ns.purity_sampling = importlib.import_module('flowmol.utils.ctmc_utils').purity_sampling
     emb = importlib.import_module('flowmol.utils.embedding')
     ns.get_time_embedding, ns._rbf = emb.get_time_embedding, emb._rbf
@@ -213,6 +214,9 @@ def build_reference_vf(ns, cfg, state_dict, **overrides):
     sched = ns.InterpolantScheduler(canonical_feat_order=['x', 'a', 'c', 'e'],
                                     schedule_type=dict(getattr(cfg, 'schedule_type', None) or {k: 'linear' for k in 'xace'}),
                                     cosine_params=dict(getattr(cfg, 'cosine_params', None) or {}))
+    common = {}
+    if getattr(cfg, 'parameterization', 'ctmc') == 'endpoint':
+        return _build_endpoint_vf(ns, cfg, state_dict, sched, overrides)
     vf = ns.CTMCVectorField(
         n_atom_types=cfg.n_atom_types, canonical_feat_order=['x', 'a', 'c', 'e'],
         interpolant_scheduler=sched, n_charges=cfg.n_charges, n_bond_types=cfg.n_bond_types,
@@ -246,3 +250,21 @@ def build_reference_graph(ns, n_atoms: torch.Tensor, device='cpu'):
     upper = ns.get_upper_edge_mask(g)
     nb, eb = ns.get_batch_idxs(g)
     return g, upper, nb, eb
+
+
+def _build_endpoint_vf(ns, cfg, state_dict, sched, overrides):
+    """The reference's EndpointVectorField (vector_field.py:15-211) for an endpoint-parameterised config, as FlowMol.__init__
+    builds it (flowmol.py:137-153: n_atom_types incl. the fake atom, has_mask left False)."""
+    vf = ns.EndpointVectorField(
+        n_atom_types=cfg.n_atom_types, canonical_feat_order=['x', 'a', 'c', 'e'], interpolant_scheduler=sched,
+        n_charges=cfg.n_charges, n_bond_types=cfg.n_bond_types, exclude_charges=False,
+        self_conditioning=cfg.self_conditioning, n_vec_channels=cfg.n_vec_channels, update_edge_w_distance=cfg.update_edge_w_distance,
+        n_hidden_scalars=cfg.n_hidden_scalars, n_hidden_edge_feats=cfg.n_hidden_edge_feats, n_recycles=cfg.n_recycles,
+        separate_mol_updaters=cfg.separate_mol_updaters, n_molecule_updates=cfg.n_molecule_updates, convs_per_update=cfg.convs_per_update,
+        n_cp_feats=cfg.n_cp_feats, n_message_gvps=cfg.n_message_gvps, n_update_gvps=cfg.n_update_gvps, message_norm=cfg.message_norm,
+        rbf_dmax=cfg.rbf_dmax, rbf_dim=cfg.rbf_dim, time_embedding_dim=cfg.time_embedding_dim, a_token_dim=0, c_token_dim=0, e_token_dim=0,
+        use_dst_feats=cfg.use_dst_feats, dst_feat_msg_reduction_factor=cfg.dst_feat_msg_reduction_factor,
+        continuous_inv_temp_schedule=cfg.continuous_inv_temp_schedule, continuous_inv_temp_max=cfg.continuous_inv_temp_max, **overrides)
+    vf.load_state_dict(state_dict, strict=True)
+    vf.eval()
+    return vf

@@ -247,3 +247,31 @@ def cosine_cfg(cfg):
     import dataclasses
     return dataclasses.replace(cfg, schedule_type={'x': 'cosine', 'a': 'cosine', 'c': 'cosine', 'e': 'linear'},
                                cosine_params={'x': 1, 'a': 2, 'c': 2})
+
+
+def endpoint_cfg():
+    """Config of tests/golden/integrate_endpoint.npz (oracle/make_golden.py:gen_integrate_endpoint)."""
+    import dataclasses
+    from flowmol_amd import presets
+    return dataclasses.replace(presets.endpoint_small(), continuous_inv_temp_schedule='linear', continuous_inv_temp_max=1.5)
+
+
+def endpoint_golden(eng, g, device=None):
+    """Engine vs the reference's EndpointVectorField on the fixture: one network evaluation of the prior state at t = 0.25
+    (dense-embedding path) and the free-running Euler integration of x, a, c, e.  Returns relative errors (max abs / max abs)."""
+    device = device or eng.device
+    eng.bind(g['n_atoms'])
+    res = {}
+
+    def rel(got, want):
+        return float((got.detach().cpu() - want).abs().max() / want.abs().max())
+    st = eng.make_dense_state(g['x_0'], g['a_0'], g['c_0'], g['e_0_upper'])
+    out = eng.forward_dense(st, 0.25, remove_com=True)
+    eng.synchronize()
+    for k in 'xace':
+        res[f'fwd.{k}'] = rel(out[k], g[f'fwd.{k}'])
+    st = eng.make_dense_state(g['x_0'], g['a_0'], g['c_0'], g['e_0_upper'])
+    eng.integrate_endpoint(st, int(g['T']))
+    for k, ref in (('x', 'x_1'), ('a', 'a_1'), ('c', 'c_1'), ('e', 'e_1_upper')):
+        res[f'int.{k}'] = rel(st[f'{k}_t'], g[ref])
+    return res

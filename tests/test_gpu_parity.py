@@ -673,3 +673,16 @@ def test_cosine_schedule_trajectory_matches_reference_golden(golden_dir):
     _report('integrate[cosine]', res)
     assert res['a_flips'] == 0 and res['c_flips'] == 0 and res['e_flips'] == 0 and res['traj0_a_flips'] == 0, res
     assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res
+
+
+def test_endpoint_parameterization_matches_reference_golden(golden_dir):
+    """EndpointVectorField on the GPU (fm_forward_dense + fm_endpoint_step) against the reference's own module: network evaluation on
+    continuous categorical features and the free-running Euler integration of x, a, c, e (vector_field.py:212-293, 388-569)."""
+    from flowmol_amd.engine import Engine
+    from parity_util import endpoint_cfg, endpoint_golden
+    cfg = endpoint_cfg()
+    g = {k: torch.from_numpy(v) for k, v in np.load(golden_dir / 'integrate_endpoint.npz').items()}
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0')
+    res = endpoint_golden(eng, g, device='cuda:0')
+    _report('endpoint_golden', res)
+    assert all(v < 1e-5 for v in res.values()), res

@@ -244,3 +244,24 @@ def test_cosine_step_plan_matches_reference_tables(golden_dir):
     assert sc.x_coef == float(ap[i, 0] / (1 - a[i, 0]))
     assert sc.unmask_prob[0] == float(torch.clamp(dt * (ap[i, 1] + 30.0 * a[i, 1]) / (1 - a[i, 1]), min=0, max=1))
     assert sc.unmask_prob[2] == float(torch.clamp(dt * (ap[i, 3] + 30.0 * a[i, 3]) / (1 - a[i, 3]), min=0, max=1))
+
+
+def test_endpoint_hparams_are_read_like_the_reference():
+    """from_reference_hparams for a non-CTMC checkpoint: parameterization default 'endpoint', prior types / kwargs, token dims 0,
+    the vector field's inverse-temperature schedule; the CTMC-only / unimplemented variants stay rejected."""
+    from flowmol_amd.model import check_reference_hparams
+    hp = {'atom_type_map': ['C', 'H', 'N', 'O', 'F'], 'n_atom_charges': 6, 'fake_atom_p': 0.0,
+          'prior_config': {'x': {'type': 'centered-normal', 'kwargs': {'std': 1.0}}, 'a': {'type': 'gaussian', 'kwargs': {'std': 1.0}},
+                           'c': {'type': 'uniform-simplex', 'kwargs': {}}, 'e': {'type': 'barycenter', 'kwargs': {}}},
+          'interpolant_scheduler_config': {'schedule_type': 'linear'},
+          'vector_field_config': dict(n_vec_channels=16, n_hidden_scalars=256, n_hidden_edge_feats=128, n_cp_feats=4, n_molecule_updates=3,
+                                      convs_per_update=1, separate_mol_updaters=True, message_norm=100, update_edge_w_distance=True,
+                                      rbf_dmax=12, rbf_dim=32, continuous_inv_temp_schedule='linear', continuous_inv_temp_max=4.0)}
+    check_reference_hparams(hp)                       # no 'parameterization' key -> the reference's default 'endpoint'
+    cfg = from_reference_hparams(hp)
+    assert cfg.parameterization == 'endpoint' and not cfg.has_mask and cfg.token_dims == (5, 6, 4)
+    assert cfg.prior_types == {'a': 'gaussian', 'c': 'uniform-simplex', 'e': 'barycenter'} and cfg.continuous_inv_temp_max == 4.0
+    with pytest.raises(NotImplementedError):
+        check_reference_hparams({**hp, 'prior_config': {**hp['prior_config'], 'a': {'type': 'marginal', 'kwargs': {}}}})
+    with pytest.raises(NotImplementedError):
+        from_reference_hparams({**hp, 'vector_field_config': {**hp['vector_field_config'], 'self_conditioning': True}})

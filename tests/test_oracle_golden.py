@@ -268,3 +268,24 @@ def test_cosine_schedule_integrate_matches_reference(golden_dir):
     assert torch.equal(out['a_1'].argmax(-1), g['a_1']) and torch.equal(out['c_1'].argmax(-1), g['c_1'])
     assert torch.equal(out['e_1'][batch.upper_edge_mask].argmax(-1), g['e_1_upper'])
     torch.testing.assert_close(out['x_1'], g['x_1'], **TOL)
+
+
+def test_endpoint_parameterization_matches_reference(golden_dir):
+    """Oracle restatement of EndpointVectorField.forward / step / integrate (vector_field.py:212-293, 388-569) against the reference's
+    own module (tests/golden/integrate_endpoint.npz): continuous categorical features, Euler steps of x, a, c, e."""
+    from parity_util import endpoint_cfg
+    g = _load(golden_dir, 'integrate_endpoint.npz')
+    cfg = endpoint_cfg()
+    orc = cpu_ref.OracleVF(cfg, weights.synth_state_dict(cfg, 0))
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    m = batch.upper_edge_mask
+    e0 = torch.zeros(batch.E, cfg.n_bond_types)
+    e0[m] = g['e_0_upper']; e0[~m] = g['e_0_upper']
+    with torch.no_grad():
+        d0 = orc.forward(batch, g['x_0'], g['a_0'], g['c_0'], e0, torch.full((batch.B,), 0.25), prev=None, apply_softmax=True, remove_com=True)
+        out = orc.integrate_endpoint(batch, {'x_0': g['x_0'], 'a_0': g['a_0'], 'c_0': g['c_0'], 'e_0': e0}, int(g['T']))
+    for k in 'xace':
+        torch.testing.assert_close(d0[k], g[f'fwd.{k}'], **TOL)
+    for k in 'xac':
+        torch.testing.assert_close(out[f'{k}_1'], g[f'{k}_1'], **TOL)
+    torch.testing.assert_close(out['e_1'][m], g['e_1_upper'], **TOL)
