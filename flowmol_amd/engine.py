@@ -539,9 +539,18 @@ class IntegrationRun:
     def last_dst(self):
         return None if self.prev_idx is None else self.dst[self.prev_idx]
 
+    NOISE_BYTES_PER_CHUNK = 256 << 20     # torch-generated noise kept alive per fm_integrate call (up to 3 chunks are in flight)
+
     def run(self, lo: int, hi: int, chunk: int = 32):
         eng = self.eng
         final = C.c_int(0)
+        if self.noise_for_step is not None:
+            # the reference's draws are tensors: (N, na) + (N, nc) + (U, ne) Exp(1) and two uniforms per row and step.  Bound the
+            # transient footprint (30 MB per step at 1024 x 47 atoms) instead of letting it grow with the batch; the in-kernel
+            # Philox mode has no noise tensors at all.
+            cfg = eng.cfg
+            per_step = 4 * (eng.N * (cfg.n_atom_types + cfg.n_charges + 4) + eng.U * (cfg.n_bond_types + 2))
+            chunk = max(1, min(chunk, self.NOISE_BYTES_PER_CHUNK // max(per_step, 1)))
         for a in range(lo, hi, chunk):
             b = min(hi, a + chunk)
             k = b - a
