@@ -1,7 +1,8 @@
-"""Turn the outputs of tools/gpu_final_round1.sh (merged into gpurun_out/) into the committed profiles/<tag>_* files:
-kernel stats, the three PMC summaries, the bench line and the HBM-traffic JSON bench.py reports.
+"""Turn the outputs of tools/gpu_final_round<N>.sh (merged into gpurun_out/) into the committed profiles/<tag>_* files: kernel stats, the
+three PMC summaries, the bench lines, the HBM-traffic JSON, and profiles/current_pmc.json (the committed counters bench.py quotes,
+labelled with the commit of the library they were measured on).
 
-    python tools/collect_final.py r01m
+    python tools/collect_final.py r02f
 """
 import json
 import re
@@ -40,12 +41,12 @@ def counter(txt, kernel, name):
     return float(re.search(rf'{name}\s+([0-9.]+)', blk).group(1))
 
 
-k = 'fm_k_edge_message<32, 32, 512>'
+k = 'fm_k_edge_message<32, 32, 512, 0>'
 f, w = counter(fetch, k, 'FETCH_SIZE'), counter(write, k, 'WRITE_SIZE')
 E = bench['config']['directed_edges_per_gpu']
 N = bench['config']['nodes_per_gpu']
 traffic = {
-    'kernel': 'fm_k_edge_message<32,32,512>',
+    'kernel': 'fm_k_edge_message<32,32,512,0>',
     'workload': bench['config']['workload'],
     'source': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`, '
               f'per-dispatch averages: profiles/{tag}_pmc_fetch.txt, profiles/{tag}_pmc_write_tcc.txt',
@@ -56,5 +57,16 @@ traffic = {
     'mols_per_gpu': bench['config']['global_molecules'] // bench['n_gpus'], 'n_atoms': N // (bench['config']['global_molecules'] // bench['n_gpus']),
 }
 (P / f'{tag}_traffic.json').write_text(json.dumps(traffic, indent=1) + '\n')
+sq = (P / f'{tag}_pmc_sq.txt').read_text()
+busy, gui = counter(sq, k, 'SQ_VALU_MFMA_BUSY_CYCLES'), counter(sq, k, 'GRBM_GUI_ACTIVE')
+commit = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+cur = {'preset': 'flowmol3', 'mols_per_gpu': traffic['mols_per_gpu'], 'n_atoms': traffic['n_atoms'], 'commit': commit,
+       'kernel': traffic['kernel'], 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'], 'source': f'profiles/{tag}_traffic.json',
+       'mfma_busy_frac': busy / (gui / 8 * 1024), 'source_sq': f'profiles/{tag}_pmc_sq.txt',
+       'note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs = 256 CUs x 4'}
+(P / 'current_pmc.json').write_text(json.dumps(cur, indent=1) + '\n')
+for extra in ('final_bench_sizedist.json',):
+    if (G / extra).exists():
+        (P / f'{tag}_bench_sizedist_geom.json').write_text((G / extra).read_text().strip().splitlines()[-1] + '\n')
 print(json.dumps({'value': bench['value'], 'ms_per_step': bench['ms_per_step'], 'roofline': bench.get('roofline'), 'traffic': traffic['hbm_bytes_per_launch']}, indent=1)[:1500])
 print((G / 'final_pytest.log').read_text())
