@@ -14,6 +14,7 @@ from pathlib import Path
 FM_ABI_VERSION = 3
 FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
 FM_NOISE_TENSORS, FM_NOISE_PHILOX = 0, 1
+FM_PREC_F32, FM_PREC_BF16X3 = 0, 1
 FM_MAX_CONVS = 16
 
 LIB_NAME = 'libflowmol_hip.so'
@@ -28,7 +29,7 @@ class fm_config(C.Structure):
         ('update_after', C.c_int32 * FM_MAX_CONVS), ('self_conditioning', C.c_int32),
         ('time_embedding_dim', C.c_int32), ('a_token_dim', C.c_int32), ('c_token_dim', C.c_int32),
         ('e_token_dim', C.c_int32), ('rbf_dmax', C.c_float), ('msg_z', C.c_float),
-        ('s_dst_feats', C.c_int32), ('v_dst_feats', C.c_int32), ('has_mask', C.c_int32),
+        ('s_dst_feats', C.c_int32), ('v_dst_feats', C.c_int32), ('has_mask', C.c_int32), ('precision', C.c_int32),
     ]
 
 

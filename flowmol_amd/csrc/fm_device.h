@@ -307,6 +307,97 @@ __device__ __forceinline__ void fm_block_gemm(const float* X, int ldx, int mtile
 }
 
 // ---------------------------------------------------------------------------------------------
+// Opt-in split precision ("bf16x3", never the default): the two big GEMMs of an edge GVP (scalar linear, gates) on the bf16 matrix
+// cores, every f32 value v carried as hi + lo with hi = bf16(v), lo = bf16(v - hi) (both round-to-nearest-even, residual <= 2^-18 |v|)
+// and every product as hi*hi + hi*lo + lo*hi in f32 accumulators (dropped lo*lo <= 2^-18 |ab|).  This is NOT f32 arithmetic -- per-stage
+// errors are ~10x the f32 path's (tests quote them) -- so it is reported separately and never used for the headline number.
+//   * activations are split ONCE, when they are written to LDS, into two bf16 planes XH / XL [TM][FM_LDP] (4 bytes per element together,
+//     like f32); splitting fragments at read time would cost ~24 VALU per MFMA triple;
+//   * an A fragment of v_mfma_f32_16x16x32_bf16 is 8 consecutive k of one row = one ds_read_b128 per plane; FM_LDP * 2 bytes = 32 * odd
+//     keeps the b128 lane groups on distinct banks (MI355X_MICROARCH.md LDS table);
+//   * weights are split on the host and packed per (k32-block, column tile, plane, lane) as 16-byte entries: one coalesced 1-KB
+//     buffer_load_dwordx4 per fragment, as many bytes per weight as f32.
+// ---------------------------------------------------------------------------------------------
+typedef short fm_h8 __attribute__((ext_vector_type(8)));          // eight bf16 bit patterns = one A / B fragment
+typedef __bf16 fm_bf16x8 __attribute__((ext_vector_type(8)));
+#define FM_LDP 336        // bf16 elements per row of a plane: >= 320 (ten k32 blocks), 336 * 2 B = 32 B * 21
+
+__device__ __forceinline__ f32x4 fm_mfma_bf16(fm_h8 a, fm_h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fm_bf16x8, a), __builtin_bit_cast(fm_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void fm_split(float v, unsigned short& hi, unsigned short& lo) {
+    const __bf16 h = (__bf16)v;                    // round-to-nearest-even
+    const __bf16 l = (__bf16)(v - (float)h);       // v - hi is exact in f32
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ void fm_split_store(unsigned short* XH, unsigned short* XL, int row, int col, float v) {
+    unsigned short hi, lo;
+    fm_split(v, hi, lo);
+    XH[row * FM_LDP + col] = hi;
+    XL[row * FM_LDP + col] = lo;
+}
+template <class R>
+__device__ __forceinline__ fm_h8 fm_buf_h8(R rs, int voff, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return __builtin_bit_cast(fm_h8, r);
+}
+
+// acc[MT][NT] += A(planes, rows m0.., KB k32-blocks) * W(column tiles nt0..nt0+NT-1); Wsp: packed planes, wave-uniform base.
+template <int MT, int NT>
+__device__ __forceinline__ void fm_sp_frag_load(fm_h8 (&ah)[MT], fm_h8 (&al)[MT], fm_h8 (&bh)[NT], fm_h8 (&bl)[NT], const unsigned short* aph, const unsigned short* apl,
+                                                const void* wsp, int ntiles, int nt0, int kb, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        ah[mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(aph + mt * 16 * FM_LDP + kb * 32);      // one ds_read_b128
+        al[mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(apl + mt * 16 * FM_LDP + kb * 32);
+    }
+    const auto rs = fm_buf(wsp);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int e = ((kb * ntiles + nt0 + nt) * 2) * 64 * 16;          // bytes: entry (kb, tile, plane 0)
+        bh[nt] = fm_buf_h8(rs, lane * 16, e);
+        bl[nt] = fm_buf_h8(rs, lane * 16, e + 64 * 16);
+    }
+}
+template <int MT, int NT>
+__device__ __forceinline__ void fm_sp_frag_mma(f32x4 (&acc)[MT][NT], const fm_h8 (&ah)[MT], const fm_h8 (&al)[MT], const fm_h8 (&bh)[NT], const fm_h8 (&bl)[NT]) {
+    // the two small products first, the big one last; three passes over the accumulators keep dependent MFMAs apart
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(al[mt], bh[nt], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(ah[mt], bl[nt], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
+}
+template <int MT, int NT>
+__device__ __forceinline__ void fm_wave_gemm_sp(f32x4 (&acc)[MT][NT], const unsigned short* XH, const unsigned short* XL, int row0, int KB,
+                                                const void* wsp, int ntiles, int nt0, int lane) {
+    const unsigned short* aph = XH + (row0 + (lane & 15)) * FM_LDP + 8 * (lane >> 4);
+    const unsigned short* apl = XL + (row0 + (lane & 15)) * FM_LDP + 8 * (lane >> 4);
+    fm_h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+    fm_sp_frag_load<MT, NT>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, 0, lane);
+    int kb = 0;
+    for (; kb + 2 <= KB; kb += 2) {          // double-buffered: the fragments of block kb+1 are requested before the MFMAs of block kb issue
+        fm_sp_frag_load<MT, NT>(ah1, al1, bh1, bl1, aph, apl, wsp, ntiles, nt0, kb + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        fm_sp_frag_mma<MT, NT>(acc, ah0, al0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < KB) fm_sp_frag_load<MT, NT>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, kb + 2, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        fm_sp_frag_mma<MT, NT>(acc, ah1, al1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kb < KB) fm_sp_frag_mma<MT, NT>(acc, ah0, al0, bh0, bl0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // One Geometric Vector Perceptron on a 64-row tile (reference flowmol/models/gvp.py:90-133)
 // ---------------------------------------------------------------------------------------------
 struct FmGvpW {
@@ -316,6 +407,8 @@ struct FmGvpW {
     const float* bs;     // (256)
     const float2* Wg;    // gates packed, K = 256, N = VOUT padded to 16
     const float* bg;     // (VOUT padded)
+    const void* Ws_sp;   // split-precision builds only: Ws / Wg as hi/lo bf16 planes in v_mfma_f32_16x16x32_bf16 B-fragment order
+    const void* Wg_sp;
 };
 
 // LDS tile geometry shared by every GVP-based kernel; TM = rows (edges or nodes) per workgroup tile:
@@ -346,10 +439,15 @@ struct FmGvpTile {
 // State on exit: X[r][0..255] = scalar output (SiLU), Vin[xyz*TM+r][0..VOUT-1] = gated vector output.
 // `pre`: per-accumulator-element addend of the scalar linear, used by FIRST only (fm_gather_pre); the bias is added here.
 // All 512 threads must call it (it contains barriers); it ends with a barrier.
-template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0>
+// SP = 1 (split precision, edge message only): X is NOT an f32 tile but the two bf16 planes XH = (u16*)X, XL = XH + TM*FM_LDP; the
+// scalar GEMM and the gate GEMM run on v_mfma_f32_16x16x32_bf16 with hi/lo operands; with LAST the f32 scalar output is kept in
+// registers and written as a plain f32 [TM][FM_LDX] tile over the (then dead) planes for the aggregation.  G must then alias Vh + TM*FM_LDG.
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
     typedef FmGvpTile<V, TM, HX> T;
+    unsigned short* const XH = reinterpret_cast<unsigned short*>(X);
+    unsigned short* const XL = XH + TM * FM_LDP;
     constexpr int MT = TM / 16;                          // row tiles of the scalar GEMM
     constexpr int NW = NTH / 64;                         // waves per workgroup
     constexpr int NTW = 16 / NW;                         // column tiles of the scalar GEMM per wave (16 tiles = 256 columns)
@@ -396,7 +494,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(0 * TM + r) * T::LDVH + H + p] = cx;
         Vh[(1 * TM + r) * T::LDVH + H + p] = cy;
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
-        X[r * FM_LDX + SOFF + H + p] = fm_norm3(cx, cy, cz);
+        if (SP) fm_split_store(XH, XL, r, SOFF + H + p, fm_norm3(cx, cy, cz));
+        else X[r * FM_LDX + SOFF + H + p] = fm_norm3(cx, cy, cz);
     }
     // thread -> (row, 16-column group): no integer division by V+8 in the index math
     for (int r = tid >> 4; r < TM; r += NTH / 16) {
@@ -407,9 +506,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 const float vx = Vh[(0 * TM + r) * T::LDVH + c];
                 const float vy = Vh[(1 * TM + r) * T::LDVH + c];
                 const float vz = Vh[(2 * TM + r) * T::LDVH + c];
-                X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
+                if (SP) fm_split_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
+                else X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
             } else if (c >= H + 4 && c < KUC) {
-                X[r * FM_LDX + SOFF + c] = 0.f;
+                if (SP) { XH[r * FM_LDP + SOFF + c] = 0; XL[r * FM_LDP + SOFF + c] = 0; }
+                else X[r * FM_LDX + SOFF + c] = 0.f;
             }
         }
     }
@@ -420,6 +521,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                         [&](int row, int col, float v) { Vin[row * T::LDVI + col] = v; });
     }
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
+    float keep[(SP && LAST) ? MT : 1][(SP && LAST) ? NTW : 1][4];     // split precision, last GVP: the f32 scalar output for the aggregation
     {
         // The accumulators start at bias (+ `pre` for the FIRST GVP of an edge tile: the hoisted W_s*s[src] term, requested
         // long before so its latency is hidden) instead of zero: no separate add in the epilogue (VALU instructions cost
@@ -434,17 +536,31 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = FIRST ? pre[i][j][r] + bias : bias;
         }
         FM_MARKB(2);
-        if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
+        if (SP) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane);
+        else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
-        float* xo = X + (4 * (lane >> 4)) * FM_LDX + NTW * wave * 16 + (lane & 15);
+        if (SP) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j)
+                for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * FM_LDX + j * 16] = (FM_ABLATE & 1) ? acc[i][j][r] : fm_silu(acc[i][j][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = fm_silu(acc[i][j][r]);
+                        if constexpr (SP && LAST) keep[i][j][r] = y;
+                        fm_split_store(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
+                    }
+        } else {
+            float* xo = X + (4 * (lane >> 4)) * FM_LDX + NTW * wave * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * FM_LDX + j * 16] = (FM_ABLATE & 1) ? acc[i][j][r] : fm_silu(acc[i][j][r]);
+        }
         __syncthreads();
     }
     FM_MARKB(5);
@@ -459,8 +575,16 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     for (int jw = wave; jw < NJ * KS; jw += NW) {
         const int job = jw % NJ, half = jw / NJ;
         const int m0 = job / (VOP / 16), n0 = job % (VOP / 16);
-        const f32x4 g = fm_wave_gemm_1x1<32 / KS, 8>(X + (size_t)m0 * 16 * FM_LDX + half * (256 / KS), FM_LDX,
-                                                     w.Wg + (size_t)half * (32 / KS) * (VOP / 16) * 64, VOP / 16, n0, lane);
+        f32x4 g;
+        if (SP) {
+            f32x4 ga[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+            fm_wave_gemm_sp<1, 1>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
+                                  static_cast<const char*>(w.Wg_sp) + (size_t)half * (8 / KS) * (VOP / 16) * 2 * 64 * 16, VOP / 16, n0, lane);
+            g = ga[0][0];
+        } else {
+            g = fm_wave_gemm_1x1<32 / KS, 8>(X + (size_t)m0 * 16 * FM_LDX + half * (256 / KS), FM_LDX,
+                                             w.Wg + (size_t)half * (32 / KS) * (VOP / 16) * 64, VOP / 16, n0, lane);
+        }
         float* go = (half ? G2 : G) + (m0 * 16 + 4 * (lane >> 4)) * FM_LDG + n0 * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) go[r * FM_LDG] = g[r];
@@ -475,6 +599,15 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         if (SIGMOID) gv = fm_sigmoid(gv);
 #pragma unroll
         for (int c = 0; c < 3; ++c) Vin[(c * TM + r) * T::LDVI + u] *= gv;
+    }
+    if constexpr (SP && LAST) {      // every gate GEMM has read the planes (barrier above): the region now receives the plain f32 scalar messages
+        float* xo = X + (4 * (lane >> 4)) * FM_LDX + NTW * wave * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * FM_LDX + j * 16] = keep[i][j][r];
     }
     __syncthreads();
     FM_MARKB(7);

@@ -152,11 +152,39 @@ std::vector<float> pack(int K, int N, const std::function<float(int, int)>& w) {
     return out;
 }
 
+// split-precision packing (fm_device.h "bf16x3"): W_logical[k][n] (K x N, K%32==0, N%16==0) as hi/lo bf16 planes in
+// v_mfma_f32_16x16x32_bf16 B-fragment order: entry (kb, nt, plane, lane) = 8 bf16 = W[32kb + 8(lane>>4) + q][16nt + (lane&15)], q = 0..7
+inline uint16_t bf16_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);       // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+std::vector<float> pack_sp(int K, int N, const std::function<float(int, int)>& w) {
+    const int KB = K / 32, NT = N / 16;
+    std::vector<uint16_t> out((size_t)KB * NT * 2 * 64 * 8);
+    for (int kb = 0; kb < KB; ++kb)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 8; ++q) {
+                    const float v = w(32 * kb + 8 * (lane >> 4) + q, 16 * nt + (lane & 15));
+                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_f32(hi));
+                    const size_t e = (((size_t)kb * NT + nt) * 2) * 64 * 8;
+                    out[e + (size_t)lane * 8 + q] = hi;
+                    out[e + 64 * 8 + (size_t)lane * 8 + q] = lo;
+                }
+    std::vector<float> f(out.size() / 2);
+    memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
+}
+
 struct Fix { const void** slot; size_t off; };
 
 struct Builder {
     Arena A; std::vector<Fix> fix;
     template <class T> void put(const T*& slot, const std::vector<float>& v) { fix.push_back({(const void**)&slot, A.add(v)}); }
+    void putv(const void*& slot, const std::vector<float>& v) { fix.push_back({&slot, A.add(v)}); }
 };
 
 // Linear weight W (out,in) row-major -> packed with K = Kp (logical input index remapped by kmap), N = Np
@@ -168,6 +196,15 @@ void pack_linear(Builder& B, const float2*& slot, const float* W, int out, int i
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
     }));
 }
+// the same logical matrix as pack_linear, K padded to a multiple of 32, as split-precision planes
+void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, int Np, const std::function<int(int)>& kmap) {
+    const int K32 = (Kp + 31) / 32 * 32;
+    B.putv(slot, pack_sp(K32, Np, [&](int k, int n) -> float {
+        if (n >= out || k >= Kp) return 0.f;
+        const int kk = kmap(k);
+        return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
+    }));
+}
 void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
     std::vector<float> t(np, 0.f);
     for (int i = 0; i < n; ++i) t[i] = v[i];
@@ -175,7 +212,7 @@ void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
 }
 
 // one non-first GVP (vin = V, hidden = V, S real scalar channels in a 256-wide tile): reference gvp.py:30-88 parameter shapes
-bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g) {
+bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g, bool sp = false) {
     const int vop = vout < 16 ? 16 : vout;
     const float* Wh = bl.get(key + ".Wh", V, V);
     const float* Wcp = bl.get(key + ".Wcp", V, 8);
@@ -195,12 +232,20 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vo
     pad_vec(B, g.bs, bs, S, 256);
     pack_linear(B, g.Wg, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
     pad_vec(B, g.bg, bg, vout, vop);
+    if (sp) {
+        pack_linear_sp(B, g.Ws_sp, Ws, S, V + 4 + S, 256 + V + 8, 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : (k < 256 + V + 4 ? S + (k - 256) : -1); });
+        pack_linear_sp(B, g.Wg_sp, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
+    }
     return true;
 }
 
 template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
 int pvw_of(int V, int HX) { return (pad8(V + 1 + HX + 4) + 8 + 15) / 16 * 16; }     // FmGvpTile::PVW
+size_t lds_gvp_sp(int V, int TM) {       // split-precision edge message: bf16 planes instead of the f32 scalar tile, gates inside Vh
+    size_t fl = (size_t)TM * FM_LDP + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, 0) + 4);
+    return fl * 4 + (size_t)TM * 9 * 4;
+}
 size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
     size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, HX) + 4) + TM * FM_LDG;
     return fl * 4 + (with_meta ? (size_t)TM * 9 * 4 : 0);
@@ -349,7 +394,12 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
         dim3 gmsg = get;
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
-        L("edge_message", fm_k_edge_message<V, TE, 512, HX>, gmsg, dim3(512), lds_gvp(V, TE, true, HX), m);
+        if constexpr (HX == 0 && TE <= 32) {
+            if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
+            else L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
+        } else {
+            L("edge_message", fm_k_edge_message<V, TE, 512, HX, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, HX), m);
+        }
         const int u = cf.update_after[i];
         FmNodeUpdArgs nu{};
         nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
@@ -532,6 +582,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if ((HX > 0) != (SD > 0) || HX < 0 || HX > 8 || SD > 256 || (HX > 0 && HX != V / 4))
         { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: destination-feature widths must be both 0 or v = n_vec_channels/4 (<= 8), s <= 256"); }
     const int H0 = V + 1 + HX, KU0 = pad8(H0 + 4), PVW = c->PVW = pvw_of(V, HX);
+    if (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_BF16X3) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: unknown precision %d", cfg->precision); }
+    if (cfg->precision == FM_PREC_BF16X3 && HX > 0) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: split precision is built for models without destination features"); }
     const int na = c->na = cfg->n_atom_types, nc = c->nc = cfg->n_charges, ne = c->ne = cfg->n_bond_types;
     c->rbf_mu_step = cfg->rbf_dmax / (float)(cfg->rbf_dim - 1);
     c->rbf_inv_sigma = 1.0f / (cfg->rbf_dmax / (float)cfg->rbf_dim);
@@ -661,6 +713,14 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         pad_vec(B, g0.bs, bs, S, 256);
         pack_linear(B, g0.Wg, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
         pad_vec(B, g0.bg, bg, V, V);
+        const bool sp = cfg->precision == FM_PREC_BF16X3;
+        if (sp) {
+            pack_linear_sp(B, g0.Ws_sp, Ws, S, kin0, 160 + KU0, 256, [&](int k) {
+                if (k < 32) return S + k;
+                if (k < 160) return k - 32 < F ? S + 32 + (k - 32) : -1;
+                return k < 160 + H0 + 4 ? S + 32 + F + SD + (k - 160) : -1; });
+            pack_linear_sp(B, g0.Wg_sp, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
+        }
         if (HX > 0) {
             // destination-node terms of the first edge GVP, hoisted per node: vectors through [Wh | Wcp] rows V+1.., scalars through Ws columns S+32+F..
             B.put(cw.Wpvd, pack(8, PVW, [&](int k, int n) -> float { return k < HX ? hrow(V + 1 + k, n) : 0.f; }));
@@ -679,7 +739,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             pack_linear(B, dp.Wg, pWg, HX, SD, 256, 16, [&](int k) { return k < SD ? k : -1; });
             pad_vec(B, dp.bg, pbg, HX, 16);
         }
-        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g])) return bail(bl.err);
+        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g], sp)) return bail(bl.err);
         for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g])) return bail(bl.err);
         const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", S); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", S);
         const float* l2g = bl.get(p + "update_layer_norm.feat_norm.weight", S); const float* l2b = bl.get(p + "update_layer_norm.feat_norm.bias", S);
@@ -751,13 +811,15 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cus = prop.multiProcessorCount;
     }
-#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true>, lds_gvp(V_, T_, false)); \
+#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true>, lds_gvp(V_, T_, false)); \
     set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
     FM_SET(32, 16) FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 16) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
-#define FM_SETH(V_, T_, H_) set_lds(fm_k_edge_message<V_, T_, 512, H_>, lds_gvp(V_, T_, true, H_)); set_lds(fm_k_dst_proj<V_, T_, H_>, lds_gvp(V_, T_, false));
+#define FM_SETH(V_, T_, H_) set_lds(fm_k_edge_message<V_, T_, 512, H_, 0>, lds_gvp(V_, T_, true, H_)); set_lds(fm_k_dst_proj<V_, T_, H_>, lds_gvp(V_, T_, false));
     FM_SETH(16, 16, 4) FM_SETH(16, 32, 4) FM_SETH(32, 16, 8) FM_SETH(32, 32, 8)
 #undef FM_SETH
+    set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
+    set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
@@ -800,7 +862,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
     // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
     w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
-    if ((c->HX || !c->cfg.has_mask) && (w.tm_edge > 32)) w.tm_edge = 32;
+    if ((c->HX || !c->cfg.has_mask || c->cfg.precision != FM_PREC_F32) && (w.tm_edge > 32)) w.tm_edge = 32;
     w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 31) / 32 <= c->n_cus ? 16 : 32);
     if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
     w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;

@@ -495,15 +495,17 @@ struct FmMsgArgs {
     int xcd_chunk;            // > 0: workgroup b handles tile (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk); 0: tile = b
 };
 
-template <int V, int TM, int NTH, int HX>
+// SP = 1: opt-in split-precision instance (fm_device.h "bf16x3"): the scalar tile is two bf16 planes (TM * FM_LDP * 4 bytes, 4.6 KB more
+// than the f32 tile) and the gate buffer lives inside Vh (dead whenever gates exist), so that two workgroups still share a CU.
+template <int V, int TM, int NTH, int HX, int SP>
 __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     typedef FmGvpTile<V, TM, HX> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
-    float* Vin = X + T::X_FLOATS;
+    float* Vin = X + (SP ? TM * FM_LDP : T::X_FLOATS);
     float* Vh = Vin + T::VIN_FLOATS;
-    float* G = Vh + T::VH_FLOATS;
-    int* m_src = reinterpret_cast<int*>(G + T::G_FLOATS);   // [64]
+    float* G = SP ? Vh + TM * FM_LDG : Vh + T::VH_FLOATS;
+    int* m_src = reinterpret_cast<int*>(SP ? Vh + T::VH_FLOATS : G + T::G_FLOATS);   // [64]
     int* m_dst = m_src + TM;                              // [64]
     float* m_geo = reinterpret_cast<float*>(m_dst + TM);  // [TM][4]: xhat(3), dist
     int* m_piece = reinterpret_cast<int*>(m_geo + 4 * TM); // [TM] which partial-sum slot of its destination the row adds to
@@ -582,6 +584,27 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
                 Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = pv[p_] + m_geo[4 * r + c] * w0v[p_];      // rows without an edge: 0 + 0 * w0 (range-checked gather, zero geometry)
         }
     }
+    if (SP) {
+        unsigned short* XH = reinterpret_cast<unsigned short*>(X);
+        unsigned short* XL = XH + TM * FM_LDP;
+        // K padding of the two scalar-GEMM layouts ([rbf | ef | sh] -> 7 k32 blocks, [s | sh] -> 10): written once, never touched again
+        constexpr int Z0 = 160 + T::KU0, Z1 = 256 + T::KU;
+        for (int idx = tid; idx < TM * 24; idx += NTH) {
+            const int r = idx / 24, c = idx % 24;
+            if (Z0 + c < (Z0 + 31) / 32 * 32) { XH[r * FM_LDP + Z0 + c] = 0; XL[r * FM_LDP + Z0 + c] = 0; }
+            if (Z1 + c < 320) { XH[r * FM_LDP + Z1 + c] = 0; XL[r * FM_LDP + Z1 + c] = 0; }
+        }
+        for (int idx = tid; idx < TM * 32; idx += NTH) {
+            const int r = idx >> 5, k = idx & 31;
+            fm_split_store(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
+        }
+#pragma unroll
+        for (int k = 0; k < NEF; ++k) {
+            const int idx = tid + k * NTH, r = idx >> 5, c4 = idx & 31;
+            fm_split_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
+            fm_split_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
+        }
+    } else {
     for (int idx = tid; idx < TM * 32; idx += NTH) {
         const int r = idx >> 5, k = idx & 31;
         X[r * FM_LDX + k] = fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma);      // rows without an edge hold finite junk that is never aggregated
@@ -591,11 +614,12 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         const int idx = tid + k * NTH, r = idx >> 5, c4 = idx & 31;
         *reinterpret_cast<float4*>(X + r * FM_LDX + 32 + 4 * c4) = efv[k];   // ds_write_b128 (16-B aligned)
     }
+    }
     __syncthreads();
     FM_MARK(1);
-    fm_gvp_core<V, V, true, true, TM, NTH, HX>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
-    fm_gvp_core<V, V, false, true, TM, NTH, HX>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
-    fm_gvp_core<V, V, false, true, TM, NTH, HX>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
+    fm_gvp_core<V, V, true, true, TM, NTH, HX, SP, false>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
+    fm_gvp_core<V, V, false, true, TM, NTH, HX, SP, false>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
+    fm_gvp_core<V, V, false, true, TM, NTH, HX, SP, true>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
 
     if (a.dbg_s) {
         for (int idx = tid; idx < TM * 256; idx += NTH) {

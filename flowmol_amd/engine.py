@@ -203,7 +203,14 @@ class StepNoise:
 class Engine:
     """One ``fm_ctx`` on one device."""
 
-    def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], device='cuda:0', prefix: str = '', lib=None):
+    def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], device='cuda:0', prefix: str = '', lib=None, precision: Optional[str] = None):
+        """``precision``: 'f32' (default; the reference's arithmetic) or 'bf16x3' (OPT-IN split precision of the edge-message GEMMs on the
+        bf16 matrix cores: faster, ~10x larger per-stage error, never used for parity claims); None reads $FM_PRECISION."""
+        import os
+        precision = precision or os.environ.get('FM_PRECISION', 'f32')
+        if precision not in ('f32', 'bf16x3'):
+            raise ValueError(f"precision must be 'f32' or 'bf16x3', got {precision!r}")
+        self.precision = precision
         cfg.validate()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -243,6 +250,7 @@ class Engine:
         c.msg_z = float(cfg.msg_z)
         c.s_dst_feats, c.v_dst_feats = cfg.s_dst_feats, cfg.v_dst_feats
         c.has_mask = int(cfg.has_mask)
+        c.precision = _lib.FM_PREC_BF16X3 if precision == 'bf16x3' else _lib.FM_PREC_F32
         self._ctx = C.c_void_p()
         with self._dev():
             rc = self.lib.fm_create(C.byref(c), descs, len(shapes), C.c_void_p(blob.data_ptr()), C.byref(self._ctx))

@@ -102,8 +102,9 @@ class FlowMol:
     canonical_feat_order = ['x', 'a', 'c', 'e']
 
     def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], prefix: str = 'vector_field.',
-                 n_atoms_hist: Optional[str] = None, _engine_lib=None):
+                 n_atoms_hist: Optional[str] = None, _engine_lib=None, precision: Optional[str] = None):
         self.cfg = cfg.validate()
+        self.precision = precision          # None = $FM_PRECISION or 'f32'; 'bf16x3' = opt-in split-precision edge messages (Engine)
         self._sd = state_dict
         self._prefix = prefix
         self._lib = _engine_lib
@@ -155,7 +156,7 @@ class FlowMol:
             if self.device.type != 'cuda' and self._lib is None:
                 raise RuntimeError('flowmol_amd runs on MI355X only: move the model to a GPU with .cuda() '
                                    '(there is no CPU implementation of the sampling path)')
-            self._engine = Engine(self.cfg, self._sd, device=self.device, prefix=self._prefix, lib=self._lib)
+            self._engine = Engine(self.cfg, self._sd, device=self.device, prefix=self._prefix, lib=self._lib, precision=self.precision)
         return self._engine
 
     # ------------------------------------------------------------------ sizes

@@ -78,7 +78,14 @@ typedef struct fm_config {
     /* --- ABI 3: 1 = CTMC model (categorical inputs are tokens with a mask state, CTMCVectorField); 0 = endpoint-parameterised model
      * (EndpointVectorField, flowmol/models/vector_field.py:15-211: categorical inputs are continuous (rows, n) vectors, token dims 0) */
     int32_t has_mask;
+    /* --- ABI 3: arithmetic of the edge-message GEMMs.  FM_PREC_F32 (default): exact f32 MFMAs, the reference's arithmetic.
+     * FM_PREC_BF16X3: OPT-IN split precision -- the scalar and gate GEMMs of GVPConv.message run on the bf16 matrix cores with every
+     * f32 operand carried as hi + lo bf16 and three products per term (~2^-17 relative per product instead of 2^-24).  Not f32
+     * arithmetic: per-stage errors are ~10x larger; meant for throughput runs, never for parity claims. */
+    int32_t precision;
 } fm_config;
+
+enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1 };
 
 /* one tensor of the reference state dict inside the host weight blob */
 typedef struct fm_tensor_desc {

@@ -55,6 +55,7 @@ emu_switch:
 struct WaveScratch {
     float a[2][64];
     float b[2][64];
+    unsigned short ha[2][64][8], hb[2][64][8];      // bf16 fragments (v_mfma_f32_16x16x32_bf16)
     int ia[2][64];
     int arrived = 0;
     unsigned gen = 0;
@@ -164,6 +165,23 @@ void mfma16(float a, float b, float* c4) {
         int row = (l->lane >> 4) * 4 + r;
         float acc = c4[r];
         for (int k = 0; k < 4; ++k) acc = fmaf(ws.a[p][k * 16 + row], ws.b[p][k * 16 + col], acc);
+        c4[r] = acc;
+    }
+}
+// v_mfma_f32_16x16x32_bf16 (layout verified on gfx950 by tools/ubench/mfma_bf16_layout.cpp): lane l holds A[i=l&15][k=8(l>>4)..+7],
+// B[k=8(l>>4)..+7][j=l&15]; D as the 16x16x4 form.  Products of bf16 values are exact in f32; the accumulation order over k is the
+// hardware's business -- emulated as one f32 sum in ascending k (the kernels' tolerance covers either).
+void mfma16_bf16(const unsigned short* a8, const unsigned short* b8, float* c4) {
+    Worker* w = tw; Lane* l = w->cur; WaveScratch& ws = w->waves[l->wave];
+    int p = ws.gen & 1;
+    for (int q = 0; q < 8; ++q) { ws.ha[p][l->lane][q] = a8[q]; ws.hb[p][l->lane][q] = b8[q]; }
+    wave_rendezvous(ws);
+    auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float x; memcpy(&x, &u, 4); return x; };
+    int col = l->lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l->lane >> 4) * 4 + r;
+        float acc = c4[r];
+        for (int k = 0; k < 32; ++k) acc += f(ws.ha[p][(k >> 3) * 16 + row][k & 7]) * f(ws.hb[p][(k >> 3) * 16 + col][k & 7]);
         c4[r] = acc;
     }
 }
