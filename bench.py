@@ -34,6 +34,7 @@ import torch                                     # noqa: E402
 import torch.distributed as dist                 # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+BF16_PEAK_TFLOPS = 2500.0                        # dense bf16 MFMA (the split-precision mode's matrix instructions)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -101,7 +102,7 @@ def api_end_to_end(args, B, n, T, dev):
     """Secondary figure: ONE full `model.sample(B x n atoms, n_timesteps=T)` through the drop-in API -- bind, prior, all T-1 steps
     with torch-generated noise, device->host copy and the per-molecule SampledMolecule packaging -- as wall time."""
     import flowmol_amd as flowmol
-    model = flowmol.FlowMol.from_preset(args.preset).to(dev).eval()
+    model = flowmol.FlowMol.from_preset(args.preset, precision=args.precision).to(dev).eval()
     sizes = torch.full((B,), n, dtype=torch.int64)
     model.sample(sizes[:8], n_timesteps=3)                   # engine creation + first-use costs are not part of the figure
     torch.manual_seed(7)
@@ -170,6 +171,9 @@ def main():
     ap.add_argument('--timesteps', type=int, default=250)
     ap.add_argument('--preset', default='flowmol3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=('f32', 'bf16x3'), default='f32',
+                    help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
+                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) -- a separately reported mode")
     ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
     ap.add_argument('--cpu-mols', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -205,7 +209,7 @@ def main():
 
     cfg = presets.PRESETS[args.preset]()
     sd = weights.synth_state_dict(cfg, 0)
-    eng = Engine(cfg, sd, device=dev)
+    eng = Engine(cfg, sd, device=dev, precision=args.precision)
     B, n, T = args.mols_per_gpu, args.n_atoms, args.timesteps
     def sizes_of(r):
         """Molecule sizes of rank r's shard (fixed size, or a seeded draw from the shipped size histogram)."""
@@ -318,7 +322,22 @@ def main():
         pass
     ex = executed_macs(cfg)
     roofline = None
-    if 'edge_message' in kern:
+    if 'edge_message' in kern and args.precision == 'bf16x3':
+        # opt-in mode: the scalar and gate GEMMs issue 3 bf16 products per term on padded K (7 / 10 / 10 k32 blocks); the vector path stays f32
+        us = kern['edge_message']['avg_us']
+        V = cfg.n_vec_channels
+        ku0 = (V + 1 + 4 + 7) // 8 * 8
+        kb = [(160 + ku0 + 31) // 32, (256 + V + 8 + 31) // 32, (256 + V + 8 + 31) // 32]
+        bf16_mac = 3 * (sum(k * 32 * 256 for k in kb) + 3 * 256 * V)
+        f32_mac = 3 * (V + 8) * V * 3 + 2 * 3 * V * (V + 16)
+        roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message (split precision)', 'unit': 'TFLOP/s', 'peak': BF16_PEAK_TFLOPS,
+                    'achieved': 2 * bf16_mac * E / (us * 1e-6) / 1e12, 'frac': 2 * bf16_mac * E / (us * 1e-6) / 1e12 / BF16_PEAK_TFLOPS,
+                    'traffic': None, 'avg_launch_us': us, 'executed_bf16_flop_per_launch': 2 * bf16_mac * E, 'executed_f32_flop_per_launch': 2 * f32_mac * E,
+                    'f32_equivalent_tflops': conv_message_flops_per_edge(V) * E / (us * 1e-6) / 1e12,
+                    'note': 'OPT-IN split precision, not the headline: achieved = bf16 MFMA FLOPs actually issued (3 products per term) against the dense bf16 peak; the '
+                            'kernel is bound by the L1/L2 weight stream, the f32 vector-path GEMMs and VALU, not by the bf16 pipe. f32_equivalent_tflops = the reference '
+                            'FLOP count of the op / launch time (exceeds the f32 peak because the work is not done in f32).'}
+    elif 'edge_message' in kern:
         us = kern['edge_message']['avg_us']
         flops = conv_message_flops_per_edge(cfg.n_vec_channels) * E
         ex_flops = 2 * ex['edge_message_per_edge'] * E
@@ -348,9 +367,9 @@ def main():
     alg_tf = sum(network_flops(int(k)) for k in n_list) * evals_per_s / 1e12
     exe_tf = 2 * (ex['per_edge'] * E + ex['per_node'] * N) * evals_per_s / 1e12
     out = {
-        'metric': 'molecules/sec at 250 timesteps (GEOM-drugs-sized graphs)', 'value': mols_per_s, 'unit': 'molecules/s',
+        'metric': 'molecules/sec at 250 timesteps (GEOM-drugs-sized graphs)' + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)', 'data': 'synthetic',
         'config': {'workload': f'{args.preset} GEOM-drugs model, {B} molecules/GPU x ' + (f'{n} atoms' if args.size_dist is None else f'sizes ~ {args.size_dist} histogram (mean {float(n_atoms.double().mean()):.1f}, max {int(n_atoms.max())})') + f', n_timesteps={T} '
                                f'(BASELINE.json configs[2]; configs[3] at 8 GPUs)',
                    'global_molecules': B * world, 'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'parallelism': f'molecule-shard x{world}',
@@ -359,7 +378,7 @@ def main():
                    'finite': finite},
         'network_eval_ms': ms_per_step, 'per_rank_ms_per_step': per_rank_ms, 'final_gather_ms': gather_ms,
         'launches_per_step': launches_per_step,
-        'whole_path': {'algorithmic_tflops_per_gpu': alg_tf, 'executed_tflops_per_gpu': exe_tf,
+        'whole_path': None if args.precision != 'f32' else {'algorithmic_tflops_per_gpu': alg_tf, 'executed_tflops_per_gpu': exe_tf,
                        'executed_frac': exe_tf / FP32_PEAK_TFLOPS,
                        'algorithmic_over_executed': alg_tf / exe_tf,
                        'note': 'algorithmic = the reference-executed FLOP count of a network evaluation (BASELINE.md section 2) per second; executed = MFMA FLOPs '

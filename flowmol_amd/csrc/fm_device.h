@@ -331,11 +331,12 @@ __device__ __forceinline__ void fm_split(float v, unsigned short& hi, unsigned s
     hi = __builtin_bit_cast(unsigned short, h);
     lo = __builtin_bit_cast(unsigned short, l);
 }
+template <int LDP = FM_LDP>
 __device__ __forceinline__ void fm_split_store(unsigned short* XH, unsigned short* XL, int row, int col, float v) {
     unsigned short hi, lo;
     fm_split(v, hi, lo);
-    XH[row * FM_LDP + col] = hi;
-    XL[row * FM_LDP + col] = lo;
+    XH[row * LDP + col] = hi;
+    XL[row * LDP + col] = lo;
 }
 template <class R>
 __device__ __forceinline__ fm_h8 fm_buf_h8(R rs, int voff, int soff) {
@@ -344,13 +345,14 @@ __device__ __forceinline__ fm_h8 fm_buf_h8(R rs, int voff, int soff) {
 }
 
 // acc[MT][NT] += A(planes, rows m0.., KB k32-blocks) * W(column tiles nt0..nt0+NT-1); Wsp: packed planes, wave-uniform base.
-template <int MT, int NT>
+// LDP = row pitch of the planes in bf16 elements (16 * odd: 32-byte units odd)
+template <int MT, int NT, int LDP>
 __device__ __forceinline__ void fm_sp_frag_load(fm_h8 (&ah)[MT], fm_h8 (&al)[MT], fm_h8 (&bh)[NT], fm_h8 (&bl)[NT], const unsigned short* aph, const unsigned short* apl,
                                                 const void* wsp, int ntiles, int nt0, int kb, int lane) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        ah[mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(aph + mt * 16 * FM_LDP + kb * 32);      // one ds_read_b128
-        al[mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(apl + mt * 16 * FM_LDP + kb * 32);
+        ah[mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(aph + mt * 16 * LDP + kb * 32);      // one ds_read_b128
+        al[mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(apl + mt * 16 * LDP + kb * 32);
     }
     const auto rs = fm_buf(wsp);
 #pragma unroll
@@ -376,20 +378,21 @@ __device__ __forceinline__ void fm_sp_frag_mma(f32x4 (&acc)[MT][NT], const fm_h8
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
 }
-template <int MT, int NT>
+template <int MT, int NT, int LDP = FM_LDP>
 __device__ __forceinline__ void fm_wave_gemm_sp(f32x4 (&acc)[MT][NT], const unsigned short* XH, const unsigned short* XL, int row0, int KB,
                                                 const void* wsp, int ntiles, int nt0, int lane) {
-    const unsigned short* aph = XH + (row0 + (lane & 15)) * FM_LDP + 8 * (lane >> 4);
-    const unsigned short* apl = XL + (row0 + (lane & 15)) * FM_LDP + 8 * (lane >> 4);
+    static_assert(LDP % 16 == 0 && (LDP / 16) % 2 == 1, "plane pitch must be 32 bytes * odd");
+    const unsigned short* aph = XH + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
+    const unsigned short* apl = XL + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
     fm_h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-    fm_sp_frag_load<MT, NT>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, 0, lane);
+    fm_sp_frag_load<MT, NT, LDP>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, 0, lane);
     int kb = 0;
     for (; kb + 2 <= KB; kb += 2) {          // double-buffered: the fragments of block kb+1 are requested before the MFMAs of block kb issue
-        fm_sp_frag_load<MT, NT>(ah1, al1, bh1, bl1, aph, apl, wsp, ntiles, nt0, kb + 1, lane);
+        fm_sp_frag_load<MT, NT, LDP>(ah1, al1, bh1, bl1, aph, apl, wsp, ntiles, nt0, kb + 1, lane);
         __builtin_amdgcn_sched_barrier(0);
         fm_sp_frag_mma<MT, NT>(acc, ah0, al0, bh0, bl0);
         __builtin_amdgcn_sched_barrier(0);
-        if (kb + 2 < KB) fm_sp_frag_load<MT, NT>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, kb + 2, lane);
+        if (kb + 2 < KB) fm_sp_frag_load<MT, NT, LDP>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, kb + 2, lane);
         __builtin_amdgcn_sched_barrier(0);
         fm_sp_frag_mma<MT, NT>(acc, ah1, al1, bh1, bl1);
         __builtin_amdgcn_sched_barrier(0);
@@ -536,7 +539,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = FIRST ? pre[i][j][r] + bias : bias;
         }
         FM_MARKB(2);
-        if (SP) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane);
+        if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
         else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)

@@ -39,6 +39,7 @@ struct UpdW {
     FmGvpW pos[3];
     const float2* Wasd; const float2* W1; const float* b1; const float2* W2; const float* b2;
     const float *ln_g, *ln_b;
+    const void *W1_sp = nullptr, *W2_sp = nullptr;      // split-precision builds
 };
 
 }  // namespace
@@ -253,6 +254,7 @@ size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
 size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 5 * FM_TM * 4; }
 size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }
 size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
+size_t lds_edge_upd_sp(int TM) { return (size_t)TM * 132 * 4 + (size_t)TM * 176 * 2 * 2 + TM * 3 * 4; }
 
 // ---------------------------------------------------------------------------------------- launch helper
 int kid_of(fm_ctx* c, const char* name) {
@@ -394,7 +396,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
         dim3 gmsg = get;
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
-        if constexpr (HX == 0 && TE <= 32) {
+        if constexpr (HX == 0) {
             if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
             else L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
         } else {
@@ -438,7 +440,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
             eu.ln_g = uw.ln_g; eu.ln_b = uw.ln_b; eu.rbf_mu_step = c->rbf_mu_step; eu.rbf_inv_sigma = c->rbf_inv_sigma;
             eu.f_real = c->F;
-            if (c->F != 128) L("edge_update", fm_k_edge_update<32, true>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
+            if (cf.precision == FM_PREC_BF16X3) {
+                FmEdgeUpdSpW sw{uw.W1_sp, uw.W2_sp};
+                L("edge_update", fm_k_edge_update_sp<32>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
+            } else if (c->F != 128) L("edge_update", fm_k_edge_update<32, true>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             else if (c->tm_eupd == 32) L("edge_update", fm_k_edge_update<32, false>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             else L("edge_update", fm_k_edge_update<64, false>, dim3((E + 63) / 64), blk, lds_edge_upd(64), eu);
             const std::string ui = "upd" + std::to_string(i);
@@ -772,6 +777,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         pad_vec(B, uw.b1, b1, F, 128);
         pack_linear(B, uw.W2, W2, F, F, 128, 128, ident);
         pad_vec(B, uw.b2, b2, F, 128);
+        if (cfg->precision == FM_PREC_BF16X3) {
+            pack_linear_sp(B, uw.W1_sp, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : 2 * S + F + (k - 128); });
+            pack_linear_sp(B, uw.W2_sp, W2, F, F, 128, 128, ident);
+        }
         pad_vec(B, uw.ln_g, g, F, 128); pad_vec(B, uw.ln_b, be, F, 128);
     }
     // ---- output heads
@@ -820,7 +829,9 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
 #undef FM_SETH
     set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
+    set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
+    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
@@ -862,7 +873,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
     // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
     w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
-    if ((c->HX || !c->cfg.has_mask || c->cfg.precision != FM_PREC_F32) && (w.tm_edge > 32)) w.tm_edge = 32;
+    if ((c->HX || !c->cfg.has_mask) && (w.tm_edge > 32)) w.tm_edge = 32;
     w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 31) / 32 <= c->n_cus ? 16 : 32);
     if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
     w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;

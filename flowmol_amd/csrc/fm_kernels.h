@@ -1042,6 +1042,106 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     }
 }
 
+// EdgeUpdate in the opt-in split precision (fm_device.h "bf16x3"): both linear layers on v_mfma_f32_16x16x32_bf16 with hi/lo planes;
+// the f32 copy of ef stays in LDS for the residual and the LayerNorm.  With the matrix work off the f32 ALU the kernel is bound by
+// its 1 KB per edge of HBM traffic and by VALU (SiLU, LayerNorm, the splits).
+struct FmEdgeUpdSpW { const void* W1; const void* W2; };
+template <int TM>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update_sp(FmEdgeUpdArgs a, FmEdgeUpdSpW w) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int LDF = 132, LD1 = 176, LD2 = 144, MT = TM / 16, LPR = FM_THREADS / TM;     // f32 ef tile; planes of [ef | rbf] (K = 160) and of the hidden layer (K = 128)
+    float* Xf = lds;                                                         // [TM][132] ef (f32), later ef + update
+    unsigned short* P1H = reinterpret_cast<unsigned short*>(Xf + TM * LDF);  // [TM][176] x 2
+    unsigned short* P1L = P1H + TM * LD1;
+    unsigned short* P2H = P1H;                                               // [TM][144] x 2, over the (then dead) layer-1 planes: 39.8 KB per
+    unsigned short* P2L = P2H + TM * LD2;                                    // workgroup, four workgroups per CU hide the HBM latency of the ef tile
+    int* m_src = reinterpret_cast<int*>(P1L + TM * LD1);
+    int* m_dst = m_src + TM;
+    float* m_d = reinterpret_cast<float*>(m_dst + TM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), e0 = blockIdx.x * TM;
+    const int left = a.b.E - e0;
+    const auto rs_ef = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
+    constexpr int NEF = TM * 32 / FM_THREADS;
+    float4 efv[NEF];
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs_ef, tid * 16 + k * FM_THREADS * 16, 0);
+    if (tid < TM) {
+        const int e = e0 + tid;
+        int s = -1, d = -1; float dist = 0.f;
+        if (e < a.b.E) {
+            s = a.b.e_src[e]; d = a.b.e_dst[e];
+            dist = fm_norm3(a.x[s * 3] - a.x[d * 3], a.x[s * 3 + 1] - a.x[d * 3 + 1], a.x[s * 3 + 2] - a.x[d * 3 + 2]) + 1e-8f;
+        }
+        m_src[tid] = s; m_dst[tid] = d; m_d[tid] = dist;
+    }
+    __syncthreads();
+    const int col = wave * 16 + (lane & 15);
+    float pre_s[MT][4], pre_d[MT][4];
+    const float b1 = a.b1[col], b2 = a.b2[col];
+    {
+        const auto rs = fm_buf(a.Asd, (unsigned)a.b.N * 1024u);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + 4 * (lane >> 4) + r;
+                const int sidx = m_src[row], didx = m_dst[row];
+                pre_s[i][r] = fm_buf_f32(rs, sidx >= 0 ? sidx * 1024 + (lane & 15) * 4 : FM_BUF_OOB, wave * 64);
+                pre_d[i][r] = fm_buf_f32(rs, sidx >= 0 ? didx * 1024 + (lane & 15) * 4 : FM_BUF_OOB, 512 + wave * 64);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) {
+        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(Xf + r * LDF + 4 * c4) = efv[k];
+        fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 0, efv[k].x); fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 1, efv[k].y);
+        fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 2, efv[k].z); fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 3, efv[k].w);
+        fm_split_store<LD1>(P1H, P1L, r, 128 + c4, fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma));
+    }
+    __syncthreads();
+    {
+        f32x4 acc[MT][1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][0][r] = (pre_s[i][r] + pre_d[i][r]) + b1;
+        fm_wave_gemm_sp<MT, 1, LD1>(acc, P1H, P1L, 0, 5, w.W1, 8, wave, lane);
+        __syncthreads();                     // every wave has read the layer-1 planes: the hidden layer's planes take their place
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fm_split_store<LD2>(P2H, P2L, i * 16 + 4 * (lane >> 4) + r, col, fm_silu(acc[i][0][r]));
+    }
+    __syncthreads();
+    {
+        f32x4 acc[MT][1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{b2, b2, b2, b2};
+        fm_wave_gemm_sp<MT, 1, LD2>(acc, P2H, P2L, 0, 4, w.W2, 8, wave, lane);
+        float* xo = Xf + (4 * (lane >> 4)) * LDF + col;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * LDF] += fm_silu(acc[i][0][r]);   // own element: ef + update
+    }
+    __syncthreads();
+    const int r = tid / LPR, sub = tid % LPR;
+    float mean, rstd;
+    fm_row_stats<LPR>(Xf + r * LDF, a.f_real, sub, mean, rstd);
+#pragma unroll
+    for (int j = 0; j < 32 / LPR; ++j) {
+        const int c = (j * LPR + sub) * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(Xf + r * LDF + c);
+        const float4 g = reinterpret_cast<const float4*>(a.ln_g)[c >> 2], bb = reinterpret_cast<const float4*>(a.ln_b)[c >> 2];
+        float4 o;
+        o.x = (xv.x - mean) * rstd * g.x + bb.x;
+        o.y = (xv.y - mean) * rstd * g.y + bb.y;
+        o.z = (xv.z - mean) * rstd * g.z + bb.z;
+        o.w = (xv.w - mean) * rstd * g.w + bb.w;
+        fm_buf_store_f32x4(rs_ef, r * 512 + c * 4, 0, o);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // small element-wise kernels
 // ------------------------------------------------------------------------------------------------

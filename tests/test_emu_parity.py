@@ -299,3 +299,21 @@ def test_endpoint_model_sample_api_on_emulation(emu_lib):
     assert mols[0].atom_type_map == ['C', 'H', 'N', 'O', 'F'] and all(s in mols[0].atom_type_map for s in mols[0].atom_types)
     with pytest.raises(_lib.FlowMolHipError, match='fm_forward_dense'):
         m.engine.forward(m.engine.prior_state(torch.zeros(m.engine.N, 3)), 0.5)        # token entry point refuses a dense model
+
+
+@pytest.mark.parametrize('name,sizes', [('flowmol3', [4, 7, 2]), ('geom_ctmc', [6, 3]), ('dev_narrow', [5, 3])])
+def test_split_precision_on_emulation(emu_lib, name, sizes):
+    """Opt-in split precision (bf16x3 scalar / gate GEMMs of the edge messages and both EdgeUpdate layers on the emulated
+    v_mfma_f32_16x16x32_bf16) against the f32 oracle: every stage within 5e-5, outputs within 2e-5 -- and measurably NOT the f32 path
+    (the per-edge scalar messages differ from the exact path by more than its own error), i.e. the flag really selects other arithmetic."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    orc = cpu_ref.OracleVF(cfg, sd)
+    eng = Engine(cfg, sd, device='cpu', lib=emu_lib, precision='bf16x3')
+    errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), 0.5, True)
+    bad = {k: v for k, v in errs.items() if not (v < (2e-5 if k.startswith('out.') else 5e-5))}
+    assert not bad, bad
+    assert errs['conv0.msg.s'] > 2e-6          # f32 path: ~1e-6
+    with pytest.raises(ValueError):
+        Engine(cfg, sd, device='cpu', lib=emu_lib, precision='fp8')

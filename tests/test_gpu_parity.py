@@ -731,3 +731,15 @@ def test_split_precision_trajectories_flip_counts(golden_dir, fname, name):
     if flips == 0:
         assert res['x_rel'] < 1e-4, res
     assert (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()
+
+
+def test_split_precision_c3_full_size_properties():
+    """BASELINE configs[2] at full size in the opt-in split precision (1024 x 47 atoms, 250 steps): finite, no mask tokens left,
+    zero per-molecule centre of mass of the final coordinates -- the size-independent properties of the f32 path's C3 test."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('flowmol3', precision='bf16x3').cuda().eval()
+    torch.manual_seed(21)
+    out, n_atoms = model.sample(torch.full((1024,), 47), n_timesteps=250, return_tensors=True)
+    assert torch.isfinite(out['x']).all()
+    assert (out['a'] != model.cfg.n_atom_types).all() and (out['e'] != model.cfg.n_bond_types).all()
+    assert out['x'].reshape(1024, 47, 3).mean(1).abs().max() < 1e-3
