@@ -31,6 +31,7 @@ struct MlpW { const float2* W1; const float* b1; const float2* W2; const float* 
 
 struct ConvW {
     const float2* Wps; const float2* Wpv; const float* w0;
+    const void* Wps_sp = nullptr;      // split precision
     FmGvpW dproj{}; const float2* Wsd = nullptr; const float2* Wpvd = nullptr;     // use_dst_feats: projection GVP + hoisted destination terms
     FmGvpW msg[3]; FmGvpW upd[3];
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -39,7 +40,7 @@ struct UpdW {
     FmGvpW pos[3];
     const float2* Wasd; const float2* W1; const float* b1; const float2* W2; const float* b2;
     const float *ln_g, *ln_b;
-    const void *W1_sp = nullptr, *W2_sp = nullptr;      // split-precision builds
+    const void *W1_sp = nullptr, *W2_sp = nullptr, *Wasd_sp = nullptr;      // split-precision builds
 };
 
 }  // namespace
@@ -421,8 +422,18 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             }
         }
         nu.s_real = c->S;
-        if (c->S == 256) L("node_update", fm_k_node_update<V, TN, false>, gnt, blk, lds_gvp(V, TN, false), nu);
-        else L("node_update", fm_k_node_update<V, TN, true>, gnt, blk, lds_gvp(V, TN, false), nu);
+        bool launched = false;
+        if constexpr (HX == 0 && TN <= 32) {
+            if (cf.precision == FM_PREC_BF16X3 && fuse) {      // split-precision node kernel (fused sequence only)
+                if (i + 1 < cf.n_convs) nu.Wps_sp = c->conv[i + 1].Wps_sp;
+                if (u >= 0) nu.Wasd_sp = c->upd[u].Wasd_sp;
+                L("node_update", fm_k_node_update<V, TN, true, 1>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
+                launched = true;
+            }
+        }
+        if (launched) {}
+        else if (c->S == 256) L("node_update", fm_k_node_update<V, TN, false, 0>, gnt, blk, lds_gvp(V, TN, false), nu);
+        else L("node_update", fm_k_node_update<V, TN, true, 0>, gnt, blk, lds_gvp(V, TN, false), nu);
         if (tagg) { tap(ci + ".agg.s", c->tap_s, (size_t)N * 256 * 4); tap(ci + ".agg.v", c->tap_v, (size_t)N * 3 * V * 4); }
         tap(ci + ".s", c->s, (size_t)N * 256 * 4);
         tap(ci + ".v", c->v, (size_t)N * 3 * V * 4);
@@ -745,7 +756,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             pad_vec(B, dp.bg, pbg, HX, 16);
         }
         for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g], sp)) return bail(bl.err);
-        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g])) return bail(bl.err);
+        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g], sp)) return bail(bl.err);
+        if (sp) pack_linear_sp(B, cw.Wps_sp, Ws, S, kin0, 256, 256, [&](int k) { return k < S ? k : -1; });
         const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", S); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", S);
         const float* l2g = bl.get(p + "update_layer_norm.feat_norm.weight", S); const float* l2b = bl.get(p + "update_layer_norm.feat_norm.bias", S);
         if (!l1g || !l1b || !l2g || !l2b) return bail(bl.err);
@@ -760,7 +772,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!used) continue;
         UpdW& uw = c->upd[u];
         const std::string p = "node_position_updaters." + std::to_string(u) + ".gvps.";
-        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0]) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1]) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2]))
+        const bool spu = cfg->precision == FM_PREC_BF16X3;
+        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu))
             return bail(bl.err);
         const std::string q = "edge_updaters." + std::to_string(u) + ".";
         const int kin = 2 * S + F + 32;
@@ -778,6 +791,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         pack_linear(B, uw.W2, W2, F, F, 128, 128, ident);
         pad_vec(B, uw.b2, b2, F, 128);
         if (cfg->precision == FM_PREC_BF16X3) {
+            B.putv(uw.Wasd_sp, pack_sp(256, 256, [&](int k, int n) -> float {
+                const int o = n < 128 ? n : n - 128;
+                if (k >= S || o >= F) return 0.f;
+                return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
             pack_linear_sp(B, uw.W1_sp, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : 2 * S + F + (k - 128); });
             pack_linear_sp(B, uw.W2_sp, W2, F, F, 128, 128, ident);
         }
@@ -820,7 +837,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cus = prop.multiProcessorCount;
     }
-#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true>, lds_gvp(V_, T_, false)); \
+#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false, 0>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true, 0>, lds_gvp(V_, T_, false)); \
     set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
     FM_SET(32, 16) FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 16) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
@@ -830,6 +847,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
+    set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));
+    set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));

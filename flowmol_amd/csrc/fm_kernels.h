@@ -693,12 +693,15 @@ struct FmNodeUpdArgs {
     const float2* Wpv; float* PV;
     const float2* Wasd; float* Asd;
     FmGvpW p0, p1, p2; float* x;     // x != null: x += GVP3(GVP2(GVP1(s, v))).v[:, 0]
+    const void* Wps_sp; const void* Wasd_sp;      // split-precision instance: Wps / Wasd as bf16 hi/lo planes
     int s_real;                      // NARROW instances: real scalar width (< 256); the LayerNorm statistics run over it
 };
 
 // GVPLayerNorm of a tile held in X[:, 0..255] / Vin (gvp.py:169-184); result written to LDS in place and,
 // when out_s/out_v are given, to HBM.
-template <int V, int TM>
+// SP = 1 (split precision): the normalised scalars leave as the bf16 hi/lo planes the following GVPs / projections read (the planes
+// overlay the f32 tile, so every thread first finishes reading its row -- values in registers, one barrier -- then writes).
+template <int V, int TM, int SP = 0>
 __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, const float* g, const float* b_,
                                                       int row0, int nrows, float* out_s, float* out_v, int s_width = 256) {
     typedef FmGvpTile<V, TM> T;
@@ -717,10 +720,26 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     const float vn = __builtin_amdgcn_sqrtf(q * (1.0f / (float)V) + 1e-5f) + 1e-5f;
     const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
     const bool valid = row0 + r < nrows;
+    if constexpr (SP) {
+        float ys[256 / LPR];
+#pragma unroll
+        for (int k = 0; k < 256 / LPR; ++k) {
+            const int c = sub + k * LPR;
+            ys[k] = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
+            if (out_s && valid) out_s[(size_t)(row0 + r) * 256 + c] = ys[k];
+        }
+        __syncthreads();
+        unsigned short* XH = reinterpret_cast<unsigned short*>(X);
+        unsigned short* XL = XH + TM * FM_LDP;
+#pragma unroll
+        for (int k = 0; k < 256 / LPR; ++k) fm_split_store(XH, XL, r, sub + k * LPR, ys[k]);
+        for (int c = 256 + V + 8 + sub; c < 320; c += LPR) { XH[r * FM_LDP + c] = 0; XL[r * FM_LDP + c] = 0; }      // K padding of the [s | sh] layout
+    } else {
     for (int c = sub; c < 256; c += LPR) {
         const float y = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
         X[r * FM_LDX + c] = y;
         if (out_s && valid) out_s[(size_t)(row0 + r) * 256 + c] = y;
+    }
     }
     for (int u = sub; u < V; u += LPR)
 #pragma unroll
@@ -732,14 +751,16 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     __syncthreads();
 }
 
-template <int V, int TM, bool NARROW>
+// SP = 1: opt-in split precision (fm_device.h "bf16x3"): the scalar / gate GEMMs of its six GVPs and the two 256 x 256 projections on the
+// bf16 matrix cores; LayerNorm, residuals, the vector path and the hidden-vector projection stay f32.
+template <int V, int TM, bool NARROW, int SP>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) {
     typedef FmGvpTile<V, TM> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
-    float* Vin = X + T::X_FLOATS;
+    float* Vin = X + (SP ? TM * FM_LDP : T::X_FLOATS);
     float* Vh = Vin + T::VIN_FLOATS;
-    float* G = Vh + T::VH_FLOATS;
+    float* G = SP ? Vh + TM * FM_LDG : Vh + T::VH_FLOATS;
     const int tid = threadIdx.x, row0 = blockIdx.x * TM;
     const int N = a.b.N, P = a.b.P;
     const int rows = N - row0 < TM ? N - row0 : TM;                // rows of this tile that exist
@@ -808,13 +829,13 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     }
     __syncthreads();
     const int s_width = NARROW ? a.s_real : 256;
-    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v, s_width);     // s1, v1 -> HBM (needed for the residual)
+    fm_gvp_layernorm_tile<V, TM, SP>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v, s_width);     // s1, v1 -> HBM (needed for the residual)
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, true>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));      // SP: leaves the f32 tile for the residual
     }
     {   // residual: + (s1, v1), re-read from HBM with 16-byte loads (rows beyond N read 0)
         constexpr int NQ = TM * 64 / FM_THREADS;
@@ -840,9 +861,33 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         }
     }
     __syncthreads();
-    fm_gvp_layernorm_tile<V, TM>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v, s_width);       // ends with a barrier: X = s, Vin = v
+    fm_gvp_layernorm_tile<V, TM, SP>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v, s_width);       // ends with a barrier: X = s (planes if SP), Vin = v
     // ---- fused tail: projections first (they only read the tile), then the position GVPs (which overwrite it)
     constexpr int MT = TM / 16;
+    if constexpr (SP) {
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned short* XH = reinterpret_cast<const unsigned short*>(X);
+        const unsigned short* XL = XH + TM * FM_LDP;
+        auto project = [&](const void* wsp, float* out) {       // (TM x 256) x (256 x 256): wave w owns column tiles 2w, 2w+1 for all row tiles
+            f32x4 acc[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fm_wave_gemm_sp<MT, 2>(acc, XH, XL, 0, 8, wsp, 16, 2 * wave, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i * 16 + 4 * (lane >> 4) + r;
+                        if (row0 + row < N) out[(size_t)(row0 + row) * 256 + (2 * wave + j) * 16 + (lane & 15)] = acc[i][j][r];
+                    }
+        };
+        if (a.Ps) project(a.Wps_sp, a.Ps);
+        if (a.Asd) project(a.Wasd_sp, a.Asd);
+    } else {
     if (a.Ps)
         fm_block_gemm<MT, 2>(X, FM_LDX, MT, 32, a.Wps, 16, [&](int row, int col, float val) {
             if (row0 + row < N) a.Ps[(size_t)(row0 + row) * 256 + col] = val;
@@ -851,6 +896,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         fm_block_gemm<MT, 2>(X, FM_LDX, MT, 32, a.Wasd, 16, [&](int row, int col, float val) {
             if (row0 + row < N) a.Asd[(size_t)(row0 + row) * 256 + col] = val;
         });
+    }
     if (a.PV)
         fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * MT, V / 8, a.Wpv, (V + 16) / 16, [&](int row, int col, float val) {
             const int c = row / TM, r = row % TM;
@@ -860,9 +906,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         __syncthreads();                     // every wave has read the tile for the projections
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, 1, false, false, TM, FM_THREADS>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, 1, false, false, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
         if (tid < TM * 3) {
             const int r = tid / 3, c = tid % 3, n = row0 + r;
             if (n < N) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];
