@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FM_ABI_VERSION = 3
+FM_ABI_VERSION = 4
 FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
 FM_NOISE_TENSORS, FM_NOISE_PHILOX = 0, 1
 FM_PREC_F32, FM_PREC_BF16X3 = 0, 1
@@ -30,6 +30,7 @@ class fm_config(C.Structure):
         ('time_embedding_dim', C.c_int32), ('a_token_dim', C.c_int32), ('c_token_dim', C.c_int32),
         ('e_token_dim', C.c_int32), ('rbf_dmax', C.c_float), ('msg_z', C.c_float),
         ('s_dst_feats', C.c_int32), ('v_dst_feats', C.c_int32), ('has_mask', C.c_int32), ('precision', C.c_int32),
+        ('n_recycles', C.c_int32), ('edge_update_no_distance', C.c_int32),
     ]
 
 

@@ -114,11 +114,16 @@ class VFConfig:
 
     @property
     def msg_z(self) -> float:
-        """Divisor applied to the aggregated messages (gvp.py:495-501)."""
+        """Divisor applied to the aggregated messages (gvp.py:495-501); -1.0 stands for message_norm='mean' (DGL fn.mean over the
+        in-edges, gvp.py:401-404), which the library expresses as 'divide by the node's in-degree'."""
         if isinstance(self.message_norm, str):
             if self.message_norm == 'sum':
                 return 1.0
-            raise NotImplementedError("message_norm='mean' is not enabled by any shipped config")
+            if self.message_norm == 'mean':
+                return -1.0
+            raise ValueError(f"message_norm must be either 'mean', 'sum', or a number, got {self.message_norm}")      # gvp.py:395-396
+        if float(self.message_norm) <= 0:
+            raise ValueError(f"message_norm must be positive, got {self.message_norm}")
         return float(self.message_norm)
 
     def update_schedule(self):
@@ -151,10 +156,8 @@ class VFConfig:
                 raise NotImplementedError("use_dst_feats with dst_feat_msg_reduction_factor == 1 (no projection GVP) is not implemented")
             if not (1 <= self.v_dst_feats <= 8 and 1 <= self.s_dst_feats <= 256):
                 raise NotImplementedError(f"destination-feature widths out of range: v={self.v_dst_feats} s={self.s_dst_feats}")
-        if self.n_recycles != 1:
-            raise NotImplementedError("n_recycles>1 is never enabled by a shipped config")
-        if not self.update_edge_w_distance:
-            raise NotImplementedError("update_edge_w_distance=False is never enabled by a shipped config")
+        if not 1 <= int(self.n_recycles) <= 64:
+            raise ValueError(f"n_recycles must be 1..64, got {self.n_recycles}")
         if self.dfm_type not in ('campbell', 'gat'):
             raise ValueError(f"Invalid dfm_type: {self.dfm_type}")           # ctmc_vector_field.py:62-63
         if not isinstance(self.cat_temperature_schedule, (int, float)) and self.cat_temperature_schedule != 'decay':
@@ -166,7 +169,7 @@ class VFConfig:
             raise NotImplementedError("token dims must be all zero or all non-zero")
         if self.n_atom_types + 1 > 16 or self.n_charges + 1 > 8 or self.n_bond_types + 1 > 8:
             raise NotImplementedError("categorical widths exceed kernel limits (a<=16, c<=8, e<=8 incl. mask)")
-        self.msg_z  # raises for 'mean'
+        self.msg_z  # raises for an unknown message_norm
         if self.parameterization not in ('ctmc', 'endpoint'):
             raise NotImplementedError(f"parameterization {self.parameterization!r}: 'ctmc' and 'endpoint' are implemented "
                                       "(the deprecated 'vector-field' / 'dirichlet' families are out of scope)")
@@ -176,8 +179,9 @@ class VFConfig:
             if self.self_conditioning:
                 raise NotImplementedError('self-conditioning with the endpoint parameterization is not implemented (no such model ships)')
             for k in 'ace':
-                if self.prior_types.get(k) not in ('gaussian', 'uniform-simplex', 'barycenter'):
-                    raise NotImplementedError(f"prior type {self.prior_types.get(k)!r} for {k!r}: implemented for endpoint models: gaussian, uniform-simplex, barycenter")
+                if self.prior_types.get(k) not in ('gaussian', 'uniform-simplex', 'barycenter', 'biased-simplex', 'marginal', 'c-given-a'):
+                    raise NotImplementedError(f"prior type {self.prior_types.get(k)!r} for {k!r}: implemented for endpoint models: gaussian, "
+                                              "uniform-simplex, barycenter, biased-simplex, marginal, c-given-a")
             if self.continuous_inv_temp_schedule not in (None, 'linear'):
                 raise ValueError(f'Invalid continuous_inv_temp_schedule: {self.continuous_inv_temp_schedule}')
         for k in 'xace':

@@ -373,12 +373,14 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const dim3 gnt((N + TN - 1) / TN), get((E + TE - 1) / TE);              // GVP kernels
     // FM_FUSE_NODE=0 (read at fm_create) keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own
     const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
-    for (int i = 0; i < cf.n_convs; ++i) {
+    const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
+    for (int it = 0; it < n_pass; ++it) {
+        const int i = it % cf.n_convs;
         const ConvW& cw = c->conv[i];
-        if (i == 0 || !fuse) {      // later convs: projected in the previous conv's node_update
+        if (it == 0 || !fuse) {      // later convs: projected in the previous conv's node_update
             FmProjArgs pa{};
             pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV; pa.pv_w = c->PVW;
-            if (i == 0) { pa.v_init = c->v; pa.x_src = x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
+            if (it == 0) { pa.v_init = c->v; pa.x_src = x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
             L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
         }
         FmMsgArgs m{};
@@ -393,7 +395,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         m.part_s = c->part_s; m.part_v = c->part_v;
         m.rbf_mu_step = c->rbf_mu_step; m.rbf_inv_sigma = c->rbf_inv_sigma;
         // per-edge message taps are written straight into the caller's buffers (both must be registered)
-        const bool dbg = taps_on && i == 0 && c->taps.count("conv0.msg.s") && c->taps.count("conv0.msg.v");
+        const bool dbg = taps_on && it == 0 && c->taps.count("conv0.msg.s") && c->taps.count("conv0.msg.v");
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
         dim3 gmsg = get;
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
@@ -405,7 +407,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         }
         const int u = cf.update_after[i];
         FmNodeUpdArgs nu{};
-        nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = 1.0f / cf.msg_z;
+        nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = cf.msg_z < 0.f ? -1.0f : 1.0f / cf.msg_z;
         nu.g0 = cw.upd[0]; nu.g1 = cw.upd[1]; nu.g2 = cw.upd[2];
         nu.ln1_g = cw.ln1_g; nu.ln1_b = cw.ln1_b; nu.ln2_g = cw.ln2_g; nu.ln2_b = cw.ln2_b;
         const std::string ci = "conv" + std::to_string(i);
@@ -415,7 +417,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         nu.agg_v = tagg ? c->tap_v : nullptr;
         nu.tile_e = TE;
         if (fuse) {
-            if (i + 1 < cf.n_convs) { const ConvW& nx = c->conv[i + 1]; nu.Wps = nx.Wps; nu.Ps = c->Ps; nu.Wpv = nx.Wpv; nu.PV = c->PV; }
+            if (it + 1 < n_pass) { const ConvW& nx = c->conv[(i + 1) % cf.n_convs]; nu.Wps = nx.Wps; nu.Ps = c->Ps; nu.Wpv = nx.Wpv; nu.PV = c->PV; }
             if (u >= 0) {
                 const UpdW& uw = c->upd[u];
                 nu.Wasd = uw.Wasd; nu.Asd = c->Asd; nu.p0 = uw.pos[0]; nu.p1 = uw.pos[1]; nu.p2 = uw.pos[2]; nu.x = c->xw;
@@ -425,7 +427,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         bool launched = false;
         if constexpr (HX == 0 && TN <= 32) {
             if (cf.precision == FM_PREC_BF16X3 && fuse) {      // split-precision node kernel (fused sequence only)
-                if (i + 1 < cf.n_convs) nu.Wps_sp = c->conv[i + 1].Wps_sp;
+                if (it + 1 < n_pass) nu.Wps_sp = c->conv[(i + 1) % cf.n_convs].Wps_sp;
                 if (u >= 0) nu.Wasd_sp = c->upd[u].Wasd_sp;
                 L("node_update", fm_k_node_update<V, TN, true, 1>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
                 launched = true;
@@ -583,6 +585,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         return fail(nullptr, FM_ERR_INVALID, "fm_create: need 8 <= n_hidden_scalars <= 256, 8 <= n_hidden_edge_feats <= 128, rbf_dim == 32");
     if (cfg->n_vec_channels != 16 && cfg->n_vec_channels != 32) return fail(nullptr, FM_ERR_INVALID, "fm_create: n_vec_channels must be 16 or 32");
     if (cfg->n_convs < 1 || cfg->n_convs > FM_MAX_CONVS) return fail(nullptr, FM_ERR_INVALID, "fm_create: bad n_convs");
+    if (cfg->n_recycles < 0 || cfg->n_recycles > 64) return fail(nullptr, FM_ERR_INVALID, "fm_create: n_recycles must be 0..64");
+    if (cfg->msg_z == 0.f) return fail(nullptr, FM_ERR_INVALID, "fm_create: msg_z must be > 0 (divisor) or < 0 (mean over the in-edges)");
     if (cfg->n_atom_types + 1 > 16 || cfg->n_charges + 1 > 16 || cfg->n_bond_types + 1 > 16 || cfg->n_atom_types + cfg->n_charges > 32)
         return fail(nullptr, FM_ERR_INVALID, "fm_create: categorical widths exceed kernel limits");
     const bool tok = cfg->a_token_dim > 0;
@@ -776,7 +780,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu))
             return bail(bl.err);
         const std::string q = "edge_updaters." + std::to_string(u) + ".";
-        const int kin = 2 * S + F + 32;
+        const bool with_d = !cfg->edge_update_no_distance;
+        const int kin = 2 * S + F + (with_d ? 32 : 0);
         const float* W1 = bl.get(q + "edge_update_fn.0.weight", F, kin); const float* b1 = bl.get(q + "edge_update_fn.0.bias", F);
         const float* W2 = bl.get(q + "edge_update_fn.2.weight", F, F); const float* b2 = bl.get(q + "edge_update_fn.2.bias", F);
         const float* g = bl.get(q + "edge_norm.weight", F); const float* be = bl.get(q + "edge_norm.bias", F);
@@ -786,7 +791,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             const int o = n < 128 ? n : n - 128;
             if (k >= S || o >= F) return 0.f;
             return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
-        pack_linear(B, uw.W1, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : 2 * S + F + (k - 128); });
+        // without update_edge_w_distance the rbf(d) block of the tile meets zero weights
+        pack_linear(B, uw.W1, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : (with_d ? 2 * S + F + (k - 128) : -1); });
         pad_vec(B, uw.b1, b1, F, 128);
         pack_linear(B, uw.W2, W2, F, F, 128, 128, ident);
         pad_vec(B, uw.b2, b2, F, 128);
@@ -795,7 +801,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
                 const int o = n < 128 ? n : n - 128;
                 if (k >= S || o >= F) return 0.f;
                 return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
-            pack_linear_sp(B, uw.W1_sp, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : 2 * S + F + (k - 128); });
+            pack_linear_sp(B, uw.W1_sp, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : (with_d ? 2 * S + F + (k - 128) : -1); });
             pack_linear_sp(B, uw.W2_sp, W2, F, F, 128, 128, ident);
         }
         pad_vec(B, uw.ln_g, g, F, 128); pad_vec(B, uw.ln_b, be, F, 128);

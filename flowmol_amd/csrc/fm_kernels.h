@@ -681,7 +681,7 @@ struct FmNodeUpdArgs {
     FmBatch b;
     float* s; float* v;              // (N,256), (N,3,V) updated in place
     const float* part_s; const float* part_v;
-    float inv_z;
+    float inv_z;                     // 1 / z; < 0: divide by the node's in-degree (message_norm 'mean')
     int tile_e;                      // rows per tile of the edge-message kernel (defines the pieces)
     FmGvpW g0, g1, g2;
     const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
@@ -769,9 +769,11 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     // rows beyond N and pieces beyond a row's count read 0 through the range check (a per-element version of this
     // prologue with its dependent index loads was the latency of the whole kernel at small batch sizes).
     int* r_np = reinterpret_cast<int*>(G);
+    float* r_iz = G + TM;            // 1 / z per row: a.inv_z, or 1 / in-degree for message_norm 'mean' (a.inv_z < 0)
     if (tid < TM) {
         const int n = row0 + tid;
         int np = 0;
+        float iz = a.inv_z;
         if (n < N) {
             const int m = a.b.node_mol[n];
             const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
@@ -779,8 +781,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
                 const int fe = a.b.node_first_edge[n];
                 np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
             }
+            if (iz < 0.f) iz = deg > 0 ? 1.0f / (float)deg : 0.f;
         }
-        r_np[tid] = np;
+        r_np[tid] = np; r_iz[tid] = iz;
     }
     __syncthreads();
     const auto rs_s = fm_buf(a.s + (size_t)row0 * 256, (unsigned)rows * 1024u);
@@ -802,7 +805,8 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc.x += q[j].x; acc.y += q[j].y; acc.z += q[j].z; acc.w += q[j].w; }
             }
-            acc.x *= a.inv_z; acc.y *= a.inv_z; acc.z *= a.inv_z; acc.w *= a.inv_z;
+            const float iz = r_iz[r];
+            acc.x *= iz; acc.y *= iz; acc.z *= iz; acc.w *= iz;
             if (a.agg_s && r < rows) *reinterpret_cast<float4*>(a.agg_s + (size_t)(row0 + r) * 256 + c4 * 4) = acc;
             *reinterpret_cast<float4*>(X + r * FM_LDX + c4 * 4) = make_float4(sv.x + acc.x, sv.y + acc.y, sv.z + acc.z, sv.w + acc.w);
         }
@@ -822,7 +826,8 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc.x += q[j].x; acc.y += q[j].y; acc.z += q[j].z; acc.w += q[j].w; }
             }
-            acc.x *= a.inv_z; acc.y *= a.inv_z; acc.z *= a.inv_z; acc.w *= a.inv_z;
+            const float iz = r_iz[r];
+            acc.x *= iz; acc.y *= iz; acc.z *= iz; acc.w *= iz;
             if (a.agg_v && r < rows) *reinterpret_cast<float4*>(a.agg_v + ((size_t)(row0 + r) * 3 + c) * V + u4 * 4) = acc;
             *reinterpret_cast<float4*>(Vin + (c * TM + r) * T::LDVI + u4 * 4) = make_float4(vv.x + acc.x, vv.y + acc.y, vv.z + acc.z, vv.w + acc.w);
         }

@@ -251,6 +251,8 @@ class Engine:
         c.s_dst_feats, c.v_dst_feats = cfg.s_dst_feats, cfg.v_dst_feats
         c.has_mask = int(cfg.has_mask)
         c.precision = _lib.FM_PREC_BF16X3 if precision == 'bf16x3' else _lib.FM_PREC_F32
+        c.n_recycles = int(cfg.n_recycles)
+        c.edge_update_no_distance = int(not cfg.update_edge_w_distance)
         self._ctx = C.c_void_p()
         with self._dev():
             rc = self.lib.fm_create(C.byref(c), descs, len(shapes), C.c_void_p(blob.data_ptr()), C.byref(self._ctx))

@@ -34,6 +34,27 @@ def load_n_atoms_hist(name: str):
     return torch.tensor(data[name]['n_atoms'], dtype=torch.int64), torch.tensor(data[name]['counts'], dtype=torch.int64)
 
 
+def load_marginal_dists(name: str):
+    """(p_a, p_c, p_e, p_c_given_a) of a dataset: the reference's data/<set>/train_data_marginal_dists.pt as shipped JSON."""
+    data = json.loads((PKG / 'data' / 'marginal_dists.json').read_text())
+    if name not in data:
+        raise KeyError(f'no marginal distributions named {name!r}; have {sorted(data)}')
+    d = data[name]
+    return tuple(torch.tensor(d[k], dtype=torch.float32) for k in ('p_a', 'p_c', 'p_e', 'p_c_given_a'))
+
+
+def simplex_projection(x: torch.Tensor) -> torch.Tensor:
+    """Euclidean projection of every row onto the probability simplex (Wang & Carreira-Perpinan, arXiv:1309.1541), the operation the
+    reference's blurred barycenter prior applies (priors.py:36-44 -> flowmol/utils/dirflow.py:35-49): with the row sorted descending,
+    u, and c_j = (sum_{i<=j} u_i - 1) / j, the threshold is c_rho for rho = #{j : u_j > c_j}; the result is max(x - c_rho, 0)."""
+    y = x.reshape(-1, x.shape[-1])
+    u, _ = torch.sort(y, dim=-1, descending=True)
+    c = (torch.cumsum(u, dim=-1) - 1) / torch.arange(1, y.shape[1] + 1, dtype=y.dtype, device=y.device).unsqueeze(0)
+    rho = (u > c).sum(dim=1, keepdim=True)
+    tau = torch.gather(c, 1, rho - 1)
+    return torch.max(y - tau, torch.zeros_like(y)).view(x.shape)
+
+
 class _Lenient(pickle.Unpickler):
     """Unpickler for Lightning checkpoints without Lightning installed: unknown classes
     (pytorch_lightning AttributeDict & co.) become plain dict / object stand-ins."""
@@ -68,6 +89,9 @@ SUPPORTED_PARAMETERIZATIONS = ('ctmc', 'endpoint')
 SUPPORTED_SCHEDULES = ('linear', 'cosine')
 
 
+ENDPOINT_PRIORS = ('gaussian', 'uniform-simplex', 'barycenter', 'biased-simplex', 'marginal', 'c-given-a')     # priors.py:253-262 minus x / ctmc
+
+
 def check_reference_hparams(hp: dict) -> None:
     """Reject -- loudly, before any weight is touched -- every checkpoint configuration the HIP path does not reproduce, so that
     no model is ever integrated with the wrong schedule or prior.  Missing keys take the REFERENCE's defaults
@@ -91,9 +115,10 @@ def check_reference_hparams(hp: dict) -> None:
         mt = (pc.get(mod, {}) or {}).get('type')
         if par == 'ctmc' and (mt or 'ctmc') != 'ctmc':
             raise NotImplementedError('only ctmc masked priors are supported for CTMC models (as in the reference, flowmol.py:189-193)')
-        if par == 'endpoint' and mt not in ('gaussian', 'uniform-simplex', 'barycenter'):
-            raise NotImplementedError(f"categorical prior {mt!r} of an endpoint model: implemented: gaussian, uniform-simplex, barycenter "
-                                      "('marginal' / 'c-given-a' need the dataset's marginal files)")
+        if par == 'endpoint' and mt not in ENDPOINT_PRIORS:
+            raise NotImplementedError(f"categorical prior {mt!r} of an endpoint model: implemented: {ENDPOINT_PRIORS}")
+        if par == 'endpoint' and mt == 'c-given-a' and mod != 'c':
+            raise ValueError("the 'c-given-a' prior is the charge prior (flowmol.py:437-438)")
     if hp.get('exclude_charges', False):
         raise NotImplementedError('exclude_charges=True is not implemented (no shipped v3 model uses it)')
 
@@ -331,8 +356,11 @@ class FlowMol:
 
     # ------------------------------------------------------------------ endpoint-parameterised models
     @staticmethod
-    def _categorical_prior(kind: str, n: int, d: int, kw: dict) -> torch.Tensor:
-        """The reference's prior functions on the CPU generator, as FlowMol.sample_prior calls them (priors.py:8-68; flowmol.py:426-441)."""
+    def _categorical_prior(kind: str, n: int, d: int, kw: dict, a_0: Optional[torch.Tensor] = None, default_p=None) -> torch.Tensor:
+        """The reference's categorical prior functions on the CPU generator, as FlowMol.sample_prior calls them (priors.py:8-107;
+        flowmol.py:426-441) -- same draws in the same order.  'marginal' / 'c-given-a' take their distribution from the prior kwargs
+        (`p` / `p_c_given_a`, as the reference would) or, when absent, from the shipped marginals of the model's dataset (`default_p`)."""
+        F = torch.nn.functional
         if kind == 'gaussian':
             p = torch.randn(n, d) * kw.get('std', 1.0)
             return p + 1 / d if kw.get('simplex_center', False) else p
@@ -340,10 +368,45 @@ class FlowMol:
             sample = torch.distributions.Exponential(torch.tensor(1.0)).sample((n, d))
             return sample / sample.sum(dim=1, keepdim=True)
         if kind == 'barycenter':
-            if kw.get('blur', 0.0) != 0.0:
-                raise NotImplementedError('barycenter prior with blur needs the simplex projection of flowmol/utils/dirflow.py')
-            return torch.ones(n, d) / d
+            p = torch.ones(n, d) / d
+            blur = kw.get('blur', 0.0)
+            if blur != 0.0:
+                p = simplex_projection(p + torch.randn_like(p) * blur)
+            return p
+        if kind == 'biased-simplex':          # priors.py:47-56
+            vp, std, vi = kw.get('vertex_prob', 0.75), kw.get('std', 0.2), kw.get('vertex_idx', 0)
+            mu = torch.ones(d) * ((1 - vp) / (d - 1))
+            mu[vi] = vp
+            return F.softmax((mu.unsqueeze(0) + torch.randn(n, d) * std) / (1 / d), dim=1)
+        if kind in ('marginal', 'c-given-a'):
+            key = 'p' if kind == 'marginal' else 'p_c_given_a'
+            p = kw.get(key, default_p)
+            if p is None:
+                raise ValueError(f"prior {kind!r} needs kwargs[{key!r}] (or a dataset whose shipped marginals have {d} categories)")
+            p = torch.as_tensor(p, dtype=torch.float32)
+            if p.shape[-1] != d:
+                raise ValueError(f"prior {kind!r}: distribution has {p.shape[-1]} categories, the model {d}")
+            if kind == 'marginal':            # priors.py:67-79
+                idx = torch.multinomial(p, n, replacement=True)
+            else:                             # priors.py:81-98: charges conditioned on the sampled atom-type prior
+                if a_0 is None:
+                    raise ValueError("the 'c-given-a' prior needs the atom-type prior")
+                idx = torch.multinomial(p[a_0.argmax(dim=1)], 1, replacement=True).squeeze(-1)
+            one = F.one_hot(idx, num_classes=d).float()
+            blur = kw.get('blur')
+            if blur is not None:
+                one = F.softmax((one + torch.randn_like(one) * blur) / (1 / d), dim=1)
+            return one
         raise NotImplementedError(f'prior type {kind!r}')
+
+    def _default_marginal(self, feat: str, d: int):
+        """Shipped marginals of the model's dataset for the 'marginal' / 'c-given-a' priors, when their category count fits."""
+        try:
+            p_a, p_c, p_e, p_ca = load_marginal_dists(self.cfg.n_atoms_hist)
+        except KeyError:
+            return None
+        p = {'a': p_a, 'c': p_c, 'e': p_e, 'c|a': p_ca}[feat]
+        return p if p.shape[-1] == d else None
 
     def _sample_endpoint(self, n_atoms, n_timesteps, xt_traj, ep_traj, prior, return_tensors, kwargs):
         """FlowMol.sample for parameterization='endpoint' (flowmol.py:489-589 with EndpointVectorField.integrate, vector_field.py:388-499):
@@ -363,9 +426,11 @@ class FlowMol:
             x0 = torch.randn(N, 3, device=dev)
             eng.remove_com(x0)
             pk = cfg.prior_kwargs
-            a0 = self._categorical_prior(cfg.prior_types['a'], N, cfg.n_atom_types, pk.get('a', {}))
-            c0 = self._categorical_prior(cfg.prior_types['c'], N, cfg.n_charges, pk.get('c', {}))
-            e0 = self._categorical_prior(cfg.prior_types['e'], U, cfg.n_bond_types, pk.get('e', {}))
+            a0 = self._categorical_prior(cfg.prior_types['a'], N, cfg.n_atom_types, pk.get('a', {}), default_p=self._default_marginal('a', cfg.n_atom_types))
+            c_kind = cfg.prior_types['c']
+            c0 = self._categorical_prior(c_kind, N, cfg.n_charges, pk.get('c', {}), a_0=a0,
+                                         default_p=self._default_marginal('c|a' if c_kind == 'c-given-a' else 'c', cfg.n_charges))
+            e0 = self._categorical_prior(cfg.prior_types['e'], U, cfg.n_bond_types, pk.get('e', {}), default_p=self._default_marginal('e', cfg.n_bond_types))
         else:
             x0, a0, c0 = prior['x_0'], prior['a_0'], prior['c_0']
             e0 = prior['e_0']

@@ -82,4 +82,19 @@ def endpoint_small() -> VFConfig:
     ).validate()
 
 
-PRESETS = {'endpoint_small': endpoint_small, 'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}
+def arch_variants() -> VFConfig:
+    """The architecture switches of EndpointVectorField.__init__ that no shipped YAML turns on, all at once on the narrow model:
+    n_recycles=2 (vector_field.py:307), message_norm='mean' (gvp.py:401-404), update_edge_w_distance=False (vector_field.py:851-853),
+    two convolutions per molecule update with ONE shared updater (separate_mol_updaters=False, vector_field.py:320-326)."""
+    return VFConfig(
+        atom_type_map=list(GEOM_ATOMS), fake_atoms=True,
+        n_vec_channels=16, n_cp_feats=4, n_hidden_scalars=64, n_hidden_edge_feats=64,
+        n_molecule_updates=2, convs_per_update=2, separate_mol_updaters=False, n_recycles=2,
+        message_norm='mean', update_edge_w_distance=False, rbf_dmax=10.0, rbf_dim=32,
+        time_embedding_dim=64, a_token_dim=64, c_token_dim=64, e_token_dim=64,
+        self_conditioning=True, stochasticity=20.0, high_confidence_threshold=0.9,
+        n_atoms_hist='geom_full_kekulized',
+    ).validate()
+
+
+PRESETS = {'arch_variants': arch_variants, 'endpoint_small': endpoint_small, 'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}

@@ -80,7 +80,7 @@ def state_dict_shapes(cfg: VFConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         d.update(_gvp_shapes(f'{p}.2', V, 1, S, S, ncp))
     for u in range(cfg.n_updaters):
         p = f'edge_updaters.{u}'
-        d[f'{p}.edge_update_fn.0.weight'] = (F, 2 * S + F + R)
+        d[f'{p}.edge_update_fn.0.weight'] = (F, 2 * S + F + (R if cfg.update_edge_w_distance else 0))
         d[f'{p}.edge_update_fn.0.bias'] = (F,)
         d[f'{p}.edge_update_fn.2.weight'] = (F, F)
         d[f'{p}.edge_update_fn.2.bias'] = (F,)

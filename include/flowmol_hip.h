@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 3
+#define FM_ABI_VERSION 4
 #define FM_MAX_CONVS 16
 
 typedef enum fm_status {
@@ -70,7 +70,8 @@ typedef struct fm_config {
     int32_t time_embedding_dim;   /* 1 = raw t */
     int32_t a_token_dim, c_token_dim, e_token_dim;   /* 0 = one-hot input */
     float rbf_dmax;
-    float msg_z;                  /* divisor of the aggregated messages (1 for 'sum') */
+    float msg_z;                  /* divisor of the aggregated messages (1 for message_norm 'sum'); < 0: message_norm 'mean' -- every node's
+                                   * sum is divided by its in-degree n_i - 1 (DGL fn.mean, gvp.py:401-404; 0 for a 1-atom molecule) */
     /* --- ABI 3: use_dst_feats (flowmol/models/gvp.py:300-316,472-473,527-537): widths of the projected destination-node
      * features that join every message's inputs; 0 / 0 = off */
     int32_t s_dst_feats;          /* int(n_hidden_scalars / dst_feat_msg_reduction_factor) */
@@ -83,6 +84,9 @@ typedef struct fm_config {
      * f32 operand carried as hi + lo bf16 and three products per term (~2^-17 relative per product instead of 2^-24).  Not f32
      * arithmetic: per-stage errors are ~10x larger; meant for throughput runs, never for parity claims. */
     int32_t precision;
+    /* --- ABI 4: remaining architecture switches of EndpointVectorField.__init__ that no shipped YAML enables */
+    int32_t n_recycles;           /* vector_field.py:307: the conv / update stack runs n_recycles times over the same weights (0 or 1 = once) */
+    int32_t edge_update_no_distance;   /* 1 = update_edge_w_distance False: EdgeUpdate's first Linear has no rbf(d) columns (vector_field.py:851-853,876-877) */
 } fm_config;
 
 enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1 };

@@ -283,7 +283,7 @@ class OracleVF:
         dij = norm_no_nan(xd, keepdims=True) + 1e-8
         return xd / dij, rbf(dij.squeeze(1), D_max=self.cfg.rbf_dmax, D_count=self.cfg.rbf_dim)
 
-    def conv(self, i, batch: Batch, s, v, ef, x_diff, d):
+    def conv(self, i, batch: Batch, s, v, ef, x_diff, d, tap_msgs=True):
         """GVPConv.forward / message, gvp.py:435-543 (no attention / compression); with use_dst_feats the projected
         destination-node features join the message inputs (gvp.py:300-316, 472-473, 527-537)."""
         key = f'conv_layers.{i}'
@@ -297,15 +297,21 @@ class OracleVF:
         sca = torch.cat(sca, dim=1)
         for g in range(self.cfg.n_message_gvps):
             sca, vec = self.gvp(f'{key}.edge_message.{g}', sca, vec)
-            if i == 0:
+            if i == 0 and tap_msgs:
                 self._tap(f'conv0.msg{g}.s', sca)
                 self._tap(f'conv0.msg{g}.v', vec)
         N = s.shape[0]
         ms = torch.zeros(N, sca.shape[1], dtype=s.dtype, device=s.device).index_add_(0, batch.dst, sca)
         mv = torch.zeros(N, vec.shape[1], 3, dtype=s.dtype, device=s.device).index_add_(0, batch.dst, vec)
-        z = self.cfg.msg_z
-        ms = ms / z
-        mv = mv / z
+        if self.cfg.message_norm == 'mean':        # DGL fn.mean over the in-edges (gvp.py:401-404); nodes without in-edges get 0
+            deg = torch.zeros(N, dtype=s.dtype, device=s.device).index_add_(0, batch.dst, torch.ones_like(batch.dst, dtype=s.dtype))
+            deg = deg.clamp(min=1.0)
+            ms = ms / deg[:, None]
+            mv = mv / deg[:, None, None]
+        else:
+            z = self.cfg.msg_z
+            ms = ms / z
+            mv = mv / z
         self._tap(f'conv{i}.agg.s', ms)
         self._tap(f'conv{i}.agg.v', mv)
         s1, v1 = self.gvp_layer_norm(f'{key}.message_layer_norm', s + ms, v + mv)
@@ -326,7 +332,10 @@ class OracleVF:
     def edge_update(self, u, batch: Batch, s, ef, d):
         """EdgeUpdate, vector_field.py:844-880."""
         key = f'edge_updaters.{u}'
-        inp = torch.cat([s[batch.src], s[batch.dst], ef, d], dim=-1)
+        parts = [s[batch.src], s[batch.dst], ef]
+        if self.cfg.update_edge_w_distance:           # vector_field.py:876-877
+            parts.append(d)
+        inp = torch.cat(parts, dim=-1)
         h = F.silu(self._lin(f'{key}.edge_update_fn.0', inp))
         h = F.silu(self._lin(f'{key}.edge_update_fn.2', h))
         return self._ln(f'{key}.edge_norm', ef + h)
@@ -362,8 +371,9 @@ class OracleVF:
         cfg = self.cfg
         x_diff, d = self.distances(batch, x)
         sched = cfg.update_schedule()
-        for i in range(cfg.n_convs):
-            s, v = self.conv(i, batch, s, v, ef, x_diff, d)
+        for it in range(cfg.n_convs * cfg.n_recycles):       # vector_field.py:307: the stack is repeated n_recycles times over the same weights
+            i = it % cfg.n_convs
+            s, v = self.conv(i, batch, s, v, ef, x_diff, d, tap_msgs=it == 0)
             self._tap(f'conv{i}.s', s)
             self._tap(f'conv{i}.v', v)
             u = sched[i]

@@ -529,6 +529,38 @@ def gen_ctmc_step(ns):
     np.savez_compressed(OUT / 'ctmc_step.npz', **_np(out))
 
 
+PRIOR_CASES = [          # (kind, n, d, kwargs): every categorical prior FlowMol.sample_prior can dispatch to (priors.py:253-262)
+    ('gaussian', 7, 5, {'std': 0.7, 'simplex_center': True}),
+    ('uniform-simplex', 6, 4, {}),
+    ('barycenter', 5, 6, {}),
+    ('barycenter', 9, 6, {'blur': 0.3}),
+    ('biased-simplex', 8, 5, {'vertex_prob': 0.6, 'std': 0.25, 'vertex_idx': 2}),
+    ('marginal', 11, 5, {'p': [0.5, 0.2, 0.1, 0.15, 0.05]}),
+    ('marginal', 11, 5, {'p': [0.5, 0.2, 0.1, 0.15, 0.05], 'blur': 0.2}),
+    ('c-given-a', 10, 6, {'blur': 0.1}),
+    ('c-given-a', 10, 6, {}),
+]
+
+
+def gen_priors(ns):
+    """Outputs of the reference's own prior functions under torch.manual_seed(100 + case) on the CPU generator."""
+    out = {}
+    p_ca = torch.softmax(torch.randn(4, 6, generator=torch.Generator().manual_seed(5)) * 2, -1)
+    a_0 = torch.nn.functional.one_hot(torch.tensor([0, 3, 1, 2, 2, 0, 1, 3, 3, 0]), 4).float()
+    out['p_c_given_a'], out['a_0'] = p_ca, a_0
+    for i, (kind, n, d, kw) in enumerate(PRIOR_CASES):
+        fn = ns.inference_prior_register[kind]
+        kw = {k: (torch.tensor(v) if k == 'p' else v) for k, v in kw.items()}
+        args = [n, d]
+        if kind == 'c-given-a':
+            args.append(a_0)
+            kw['p_c_given_a'] = p_ca
+        torch.manual_seed(100 + i)
+        out[f'case{i}'] = fn(*args, **kw)
+    import json
+    np.savez_compressed(OUT / 'priors.npz', cases_json=np.array(json.dumps(PRIOR_CASES)), **_np(out))
+
+
 def main():
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
@@ -537,11 +569,12 @@ def main():
     gen_ctmc_step(ns)
     gen_stability()
     gen_moldata()
-    for name in ('flowmol3', 'geom_ctmc', 'qm9', 'dev'):       # dev = configs/dev.yml:78-108 (64/64/16 dims, use_dst_feats)
+    gen_priors(ns)
+    for name in ('flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants'):       # dev = configs/dev.yml:78-108 (64/64/16 dims, use_dst_feats)
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, seed=0)
         gen_forward(ns, name, cfg, sd)
-        if name != 'qm9':
+        if name not in ('qm9', 'arch_variants'):
             gen_modules(ns, name, cfg, sd)
     cfg = presets.flowmol3(); sd = weights.synth_state_dict(cfg, 0)
     gen_integrate(ns, 'flowmol3', cfg, sd, [5, 12, 20, 33], 20, 'F7')

@@ -205,6 +205,7 @@ def import_reference():
     pr = importlib.import_module('flowmol.data_processing.priors')
     ns.ctmc_masked_prior, ns.edge_prior = pr.ctmc_masked_prior, pr.edge_prior
     ns.centered_normal_prior_batched_graph = pr.centered_normal_prior_batched_graph
+    ns.inference_prior_register = pr.inference_prior_register
     ns.dgl = sys.modules['dgl']
     return ns
 

@@ -19,7 +19,8 @@ from parity_util import forward_compare
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [4, 7, 2], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False),
                                                ('flowmol3', [3, 1, 2, 1], 0.5, True),        # 1-atom molecules: no edges, no messages
                                                ('dev_narrow', [5, 3, 6], 0.5, True), ('dev_narrow', [4, 7], 0.0, False),    # 64/64-wide model on zero-padded tiles
-                                               ('dev', [5, 3, 6], 0.5, True), ('dev', [4, 7, 1], 0.0, False)])             # configs/dev.yml incl. use_dst_feats
+                                               ('dev', [5, 3, 6], 0.5, True), ('dev', [4, 7, 1], 0.0, False),              # configs/dev.yml incl. use_dst_feats
+                                               ('arch_variants', [5, 1, 4], 0.5, True)])      # n_recycles=2, message_norm='mean', EdgeUpdate without distances, shared updater
 def test_emulated_forward_matches_oracle(emu_lib, monkeypatch, name, sizes, t, prev, tile):
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
@@ -299,6 +300,14 @@ def test_endpoint_model_sample_api_on_emulation(emu_lib):
     assert mols[0].atom_type_map == ['C', 'H', 'N', 'O', 'F'] and all(s in mols[0].atom_type_map for s in mols[0].atom_types)
     with pytest.raises(_lib.FlowMolHipError, match='fm_forward_dense'):
         m.engine.forward(m.engine.prior_state(torch.zeros(m.engine.N, 3)), 0.5)        # token entry point refuses a dense model
+    # the dataset-statistics priors (priors.py:67-98): atom types from the shipped QM9 marginals, charges conditioned on them
+    cfg = presets.endpoint_small()
+    cfg.prior_types = {'a': 'marginal', 'c': 'c-given-a', 'e': 'biased-simplex'}
+    cfg.prior_kwargs = {'a': {'blur': 0.1}, 'c': {}, 'e': {'vertex_prob': 0.7}}
+    m2 = flowmol.FlowMol(cfg.validate(), weights.synth_state_dict(cfg, 0), prefix='', _engine_lib=emu_lib).to('cpu')
+    torch.manual_seed(1)
+    mols2 = m2.sample(torch.tensor([5, 2]), n_timesteps=3)
+    assert [x.num_atoms for x in mols2] == [5, 2] and all(torch.isfinite(x.positions).all() for x in mols2)
 
 
 @pytest.mark.parametrize('name,sizes', [('flowmol3', [4, 7, 2]), ('geom_ctmc', [6, 3]), ('dev_narrow', [5, 3])])

@@ -78,6 +78,8 @@ def test_native_library_is_the_hip_build():
     ('dev', [5, 9, 12, 3, 2], 0.5, True),              # configs/dev.yml:78-108: narrow dims + use_dst_feats (gvp.py:300-316,472-473,527-537)
     ('dev', [5, 9, 12, 3, 2], 0.0, False),
     ('dev', [47, 1, 30], 0.4, True),
+    ('arch_variants', [5, 9, 1, 30, 2], 0.5, True),    # n_recycles=2, message_norm='mean' (1-atom molecule: no in-edges), EdgeUpdate without distances, one shared updater
+    ('arch_variants', [47, 3], 0.0, False),
 ])
 @pytest.mark.parametrize('tile', [16, 32])
 def test_forward_matches_oracle(name, sizes, t, prev, tile):
@@ -614,7 +616,7 @@ def test_rccl_one_rank_group_gather_and_cli(tmp_path, monkeypatch):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev'])
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants'])
 def test_forward_matches_reference_fixture_directly(golden_dir, name):
     """The HIP forward against the REFERENCE's own outputs (tests/golden/forward_<name>.npz: EndpointVectorField.forward of the
     reference's modules, incl. configs/dev.yml with use_dst_feats) -- no oracle in between: bootstrap pass at t = 0 and a

@@ -1,6 +1,8 @@
 """Host-side logic (no GPU): configs, step scalars, result extraction, checkpoint reader, sharding."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -35,8 +37,11 @@ def test_unsupported_configs_fail_loudly():
         VFConfig(n_hidden_scalars=320).validate()            # wider than the 256-column tiles
     with pytest.raises(NotImplementedError):
         VFConfig(n_hidden_edge_feats=192).validate()
-    with pytest.raises(NotImplementedError):
-        VFConfig(message_norm='mean').validate()
+    VFConfig(message_norm='mean', n_recycles=2, update_edge_w_distance=False).validate()       # implemented since ABI 4
+    with pytest.raises(ValueError):
+        VFConfig(message_norm='max').validate()              # gvp.py:395-396
+    with pytest.raises(ValueError):
+        VFConfig(n_recycles=0).validate()
 
 
 @pytest.mark.parametrize('eta,hc,T', [(30.0, 0.9, 250), (10.0, 0.0, 20), (0.0, 0.9, 7)])
@@ -265,3 +270,40 @@ def test_endpoint_hparams_are_read_like_the_reference():
         check_reference_hparams({**hp, 'prior_config': {**hp['prior_config'], 'a': {'type': 'marginal', 'kwargs': {}}}})
     with pytest.raises(NotImplementedError):
         from_reference_hparams({**hp, 'vector_field_config': {**hp['vector_field_config'], 'self_conditioning': True}})
+
+
+def test_categorical_priors_match_reference_functions(golden_dir):
+    """Every categorical prior FlowMol.sample_prior can dispatch to (reference priors.py:8-107, register :253-262): the host
+    implementations consume the CPU generator exactly like the reference's functions -- fixture = their outputs under
+    torch.manual_seed(100 + case), generated by oracle/make_golden.py:gen_priors."""
+    import json
+    from flowmol_amd.model import FlowMol
+    g = np.load(golden_dir / 'priors.npz')
+    cases = json.loads(str(g['cases_json']))
+    a_0, p_ca = torch.from_numpy(g['a_0']), torch.from_numpy(g['p_c_given_a'])
+    assert len(cases) >= 9
+    for i, (kind, n, d, kw) in enumerate(cases):
+        if kind == 'c-given-a':
+            kw = dict(kw, p_c_given_a=p_ca)
+        torch.manual_seed(100 + i)
+        got = FlowMol._categorical_prior(kind, n, d, kw, a_0=a_0 if kind == 'c-given-a' else None)
+        want = torch.from_numpy(g[f'case{i}'])
+        assert got.shape == want.shape and got.dtype == want.dtype, (kind, got.shape)
+        assert torch.equal(got, want), (kind, kw, (got - want).abs().max())
+    with pytest.raises(ValueError):
+        FlowMol._categorical_prior('marginal', 4, 5, {})                          # no distribution given
+    with pytest.raises(ValueError):
+        FlowMol._categorical_prior('marginal', 4, 5, {'p': [0.5, 0.5]})           # wrong number of categories
+
+
+def test_shipped_marginals_and_simplex_projection():
+    from flowmol_amd.model import load_marginal_dists, simplex_projection
+    p_a, p_c, p_e, p_ca = load_marginal_dists('geom_full_kekulized')              # reference data/geom_full_kekulized/train_data_marginal_dists.pt
+    assert p_a.shape == (10,) and p_c.shape == (6,) and p_e.shape == (4,) and p_ca.shape == (10, 6)
+    for p in (p_a, p_c, p_e):
+        assert abs(float(p.sum()) - 1.0) < 1e-5
+    x = torch.randn(50, 7, generator=torch.Generator().manual_seed(0)) * 2
+    y = simplex_projection(x)
+    assert (y >= 0).all() and torch.allclose(y.sum(-1), torch.ones(50), atol=1e-6)
+    inside = torch.softmax(x, -1)
+    assert torch.allclose(simplex_projection(inside), inside, atol=1e-6)          # a point of the simplex is its own projection

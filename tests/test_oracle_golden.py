@@ -24,7 +24,7 @@ def _onehots(cfg, batch, a, c, eu):
     return F.one_hot(a, cfg.n_atom_types + 1).float(), F.one_hot(c, cfg.n_charges + 1).float(), e
 
 
-@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev'])
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants'])      # arch_variants: n_recycles=2, message_norm='mean', no distance in EdgeUpdate, shared updater
 def test_forward_matches_reference(golden_dir, name):
     cfg = presets.PRESETS[name]()
     g = _load(golden_dir, f'forward_{name}.npz')
