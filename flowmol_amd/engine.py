@@ -471,9 +471,11 @@ class Engine:
         self._check(rc, 'fm_endpoint_step')
         return state
 
-    def integrate_endpoint(self, state, n_timesteps: int, inv_temp_func=None, tspan=None):
+    def integrate_endpoint(self, state, n_timesteps: int, inv_temp_func=None, tspan=None, traj: Optional[Dict[str, torch.Tensor]] = None):
         """EndpointVectorField.integrate (vector_field.py:388-499): Euler steps of all four modalities; the per-step scalars are computed
-        with the reference's float32 tensor arithmetic on the host, the steps are enqueued back to back (no host synchronisation)."""
+        with the reference's float32 tensor arithmetic on the host, the steps are enqueued back to back (no host synchronisation).
+        ``traj`` (optional, vector_field.py:412-466 `visualize`): preallocated per-step frames -- 'x' (steps,N,3) and the argmax categories
+        'a','c' (steps,N), 'e' (steps,U) of the state after each step, 'x1','a1','c1','e1' of the step's endpoint prediction."""
         cfg = self.cfg
         t = torch.linspace(0, 1, n_timesteps) if tspan is None else tspan.detach().to('cpu', torch.float32).clone()
         alpha, alpha_p = alpha_tables(t, cfg.schedule_type, cfg.cosine_params)
@@ -490,6 +492,11 @@ class Engine:
             out = dst[s_idx & 1]
             self.forward_dense(state, float(t_i), remove_com=True, out=out)
             self.endpoint_step(state, out, float(s_i - t_i), [float(ap_i[k] / (1 - a_i[k])) for k in range(4)], _f32(inv_temp_func(t_i)))
+            if traj is not None:
+                f = s_idx - 1
+                traj['x'][f].copy_(state['x_t']); traj['x1'][f].copy_(out['x'])
+                for k in 'ace':
+                    traj[k][f].copy_(state[f'{k}_t'].argmax(-1)); traj[f'{k}1'][f].copy_(out[k].argmax(-1))
         self.synchronize()
         return dst[(t.shape[0] - 1) & 1] if t.shape[0] > 1 else None
 

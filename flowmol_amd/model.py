@@ -412,8 +412,6 @@ class FlowMol:
         """FlowMol.sample for parameterization='endpoint' (flowmol.py:489-589 with EndpointVectorField.integrate, vector_field.py:388-499):
         the categorical modalities are continuous vectors integrated with the same Euler step as the positions; the sampled
         molecule takes their argmax.  RNG order = the reference's: randn(N,3) on the device, then a, c, e priors on the CPU generator."""
-        if xt_traj or ep_traj:
-            raise NotImplementedError('trajectory frames are implemented for CTMC models')
         unknown = set(kwargs) - {'inv_temp_func', 'tspan'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
@@ -442,9 +440,20 @@ class FlowMol:
                     off += 2 * u
                 e0 = e0[torch.cat(idx)]
         state = eng.make_dense_state(x0, a0, c0, e0)
+        visualize = bool(xt_traj or ep_traj)
+        traj = None
+        if visualize:        # frames as category indices (the molecule of a frame is its argmax, molecule_builder.py:231-247) + fp32 coordinates
+            ts = kwargs.get('tspan')
+            n_steps = (n_timesteps if ts is None else int(ts.shape[0])) - 1
+            i32 = dict(dtype=torch.int32, device=dev)
+            traj = {'x': torch.empty(n_steps, N, 3, device=dev), 'a': torch.empty(n_steps, N, **i32),
+                    'c': torch.empty(n_steps, N, **i32), 'e': torch.empty(n_steps, U, **i32),
+                    'x1': torch.empty(n_steps, N, 3, device=dev), 'a1': torch.empty(n_steps, N, **i32),
+                    'c1': torch.empty(n_steps, N, **i32), 'e1': torch.empty(n_steps, U, **i32)}
+            init = {'x': state['x_t'].clone(), 'a': state['a_t'].argmax(-1).int(), 'c': state['c_t'].argmax(-1).int(), 'e': state['e_t'].argmax(-1).int()}
         import time
         t0 = time.perf_counter()
-        eng.integrate_endpoint(state, n_timesteps, inv_temp_func=kwargs.get('inv_temp_func'), tspan=kwargs.get('tspan'))
+        eng.integrate_endpoint(state, n_timesteps, inv_temp_func=kwargs.get('inv_temp_func'), tspan=kwargs.get('tspan'), traj=traj)
         self.last_timing = {'integrate': time.perf_counter() - t0}
         if return_tensors == 'dense':
             return {k: state[f'{k}_t'] for k in 'xace'}, n_atoms
@@ -454,7 +463,11 @@ class FlowMol:
         out = _to_host(out_dev)
         if return_tensors:
             return out, n_atoms
-        return self._package(out, n_atoms, None, False, False)
+        frames = None
+        if visualize:
+            frames = {k: torch.cat([init[k].unsqueeze(0), traj[k]]).cpu() for k in 'xace'}
+            frames.update({f'{k}_1_pred': traj[f'{k}1'].cpu() for k in 'xace'})
+        return self._package(out, n_atoms, frames, xt_traj, ep_traj)
 
     # ------------------------------------------------------------------ helpers
     def _state_from_prior(self, prior):

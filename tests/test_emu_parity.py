@@ -308,6 +308,15 @@ def test_endpoint_model_sample_api_on_emulation(emu_lib):
     torch.manual_seed(1)
     mols2 = m2.sample(torch.tensor([5, 2]), n_timesteps=3)
     assert [x.num_atoms for x in mols2] == [5, 2] and all(torch.isfinite(x.positions).all() for x in mols2)
+    # trajectory frames of an endpoint model (EndpointVectorField.integrate visualize=True, vector_field.py:412-466): frame 0 = prior,
+    # one frame per step; the last state frame is the returned molecule, the run itself is unchanged by recording
+    torch.manual_seed(0)
+    tm = m.sample(torch.tensor([4, 3]), n_timesteps=4, xt_traj=True, ep_traj=True)
+    assert torch.equal(tm[0].positions, mols[0].positions) and tm[1].atom_types == mols[1].atom_types
+    fr = tm[0].traj_frames
+    assert fr['x'].shape == (4, 4, 3) and fr['x_1_pred'].shape == (3, 4, 3) and fr['e'].shape[0] == 4 and fr['a_1_pred'].shape == (3, 4)
+    assert torch.equal(fr['x'][-1], tm[0].positions)
+    assert len(tm[0].traj_mol_blocks()) == 4 and len(tm[0].traj_mol_blocks(ep_traj=True)) == 3
 
 
 @pytest.mark.parametrize('name,sizes', [('flowmol3', [4, 7, 2]), ('geom_ctmc', [6, 3]), ('dev_narrow', [5, 3])])
