@@ -41,12 +41,12 @@ def counter(txt, kernel, name):
     return float(re.search(rf'{name}\s+([0-9.]+)', blk).group(1))
 
 
-k = 'fm_k_edge_message<32, 32, 512, 0>'
+k = 'fm_k_edge_message<32, 32, 512, 0, 0>'
 f, w = counter(fetch, k, 'FETCH_SIZE'), counter(write, k, 'WRITE_SIZE')
 E = bench['config']['directed_edges_per_gpu']
 N = bench['config']['nodes_per_gpu']
 traffic = {
-    'kernel': 'fm_k_edge_message<32,32,512,0>',
+    'kernel': 'fm_k_edge_message<32,32,512,0,0>',
     'workload': bench['config']['workload'],
     'source': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`, '
               f'per-dispatch averages: profiles/{tag}_pmc_fetch.txt, profiles/{tag}_pmc_write_tcc.txt',
