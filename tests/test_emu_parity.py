@@ -335,3 +335,48 @@ def test_split_precision_on_emulation(emu_lib, name, sizes):
     assert errs['conv0.msg.s'] > 2e-6          # f32 path: ~1e-6
     with pytest.raises(ValueError):
         Engine(cfg, sd, device='cpu', lib=emu_lib, precision='fp8')
+
+
+def test_c_abi_error_behaviour_on_emulation(emu_lib, monkeypatch):
+    """Error contract of include/flowmol_hip.h: every call returns 0 or a negative fm_status and leaves the text in fm_last_error;
+    nothing throws or exits across the ABI; a context stays usable after a refused call.  (Raw ctypes calls, no Engine.)"""
+    import ctypes as C
+    from flowmol_amd._lib import fm_config
+    from flowmol_amd.engine import Engine
+    lib = emu_lib
+    cfg = presets.qm9()
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = Engine(cfg, sd, device='cpu', lib=lib)
+
+    def err(ctx=None):
+        return lib.fm_last_error(ctx).decode()
+    # fm_create: null arguments, wrong ABI version, unsupported dimensions, a missing tensor
+    ctx = C.c_void_p()
+    assert lib.fm_create(None, None, 0, None, C.byref(ctx)) == -1 and 'null argument' in err()
+    bad = fm_config(); bad.abi_version = _lib.FM_ABI_VERSION - 1
+    dummy = (C.c_float * 4)()
+    from flowmol_amd._lib import fm_tensor_desc
+    descs = (fm_tensor_desc * 1)()
+    assert lib.fm_create(C.byref(bad), descs, 0, dummy, C.byref(ctx)) == -1 and 'ABI version' in err()
+    with pytest.raises(KeyError, match='token_embeddings.a.weight'):                   # the host layer checks the state dict first ...
+        Engine(cfg, {k: v for k, v in sd.items() if k != 'token_embeddings.a.weight'}, device='cpu', lib=lib)
+    import flowmol_amd.engine as engine_mod
+    monkeypatch.setattr(engine_mod, 'state_dict_shapes', lambda c: {k: tuple(v.shape) for k, v in sd.items() if k != 'token_embeddings.a.weight'})
+    monkeypatch.setattr(engine_mod, 'check_state_dict', lambda *a, **k: None, raising=False)
+    with pytest.raises(_lib.FlowMolHipError, match='token_embeddings.a.weight'):       # ... and the library itself names a missing tensor (FM_ERR_WEIGHTS)
+        Engine(cfg, {k: v for k, v in sd.items() if k != 'token_embeddings.a.weight'}, device='cpu', lib=lib)
+    monkeypatch.undo()
+    # call order: nothing bound yet -> FM_ERR_STATE
+    st = eng.lib.fm_remove_com(eng._ctx, None, None)
+    assert st < 0 and err(eng._ctx)
+    # workspace: too small / misaligned -> FM_ERR_INVALID, context still usable
+    n = torch.tensor([4, 3], dtype=torch.int32)
+    need = C.c_size_t()
+    assert lib.fm_workspace_bytes(eng._ctx, C.c_void_p(n.data_ptr()), 2, C.byref(need)) == 0 and need.value > 0
+    ws = torch.empty(need.value + 512, dtype=torch.uint8)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    assert lib.fm_batch_bind(eng._ctx, None, C.c_void_p(n.data_ptr()), 2, C.c_void_p(base), need.value - 1) == -1 and 'workspace' in err(eng._ctx)
+    assert lib.fm_batch_bind(eng._ctx, None, C.c_void_p(n.data_ptr()), 2, C.c_void_p(base + 8), need.value) == -1 and 'aligned' in err(eng._ctx)
+    eng.bind(torch.tensor([4, 3]))
+    out = eng.forward(eng.prior_state(torch.zeros(eng.N, 3)), 0.0, bootstrap=True)
+    assert torch.isfinite(out['x']).all()
