@@ -745,3 +745,22 @@ def test_split_precision_c3_full_size_properties():
     assert torch.isfinite(out['x']).all()
     assert (out['a'] != model.cfg.n_atom_types).all() and (out['e'] != model.cfg.n_bond_types).all()
     assert out['x'].reshape(1024, 47, 3).mean(1).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_forward_matches_oracle_on_random_batches(seed):
+    """Seeded random batches (ragged sizes 1..90 with a degenerate / tile-edge size in every batch, random time, with / without a
+    previous endpoint, every preset, both tile sizes): every stage and output of a network evaluation against the oracle."""
+    rng = np.random.default_rng(1234 + seed)
+    name = ['flowmol3', 'geom_ctmc', 'dev', 'dev_narrow', 'arch_variants', 'qm9'][seed % 6]
+    tile = [16, 32][int(rng.integers(0, 2))]
+    nmol = int(rng.integers(2, 9))
+    sizes = [int(v) for v in rng.integers(1, 91 if name in ('flowmol3', 'geom_ctmc') else 40, size=nmol)]
+    sizes[int(rng.integers(0, nmol))] = [1, 2, 17, 33][int(rng.integers(0, 4))]
+    t = float(np.float32(rng.uniform(0.05, 0.95)))
+    cfg, sd, eng, orc = engine_for(name, tile)
+    prev = bool(rng.integers(0, 2)) and cfg.self_conditioning
+    errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev)
+    _report(f'forward_random[{seed}: {name},{sizes},{t:.3f},prev={prev},tile{tile}]', errs)
+    bad = {k: v for k, v in errs.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
+    assert not bad, f'{name} {sizes} t={t} tile={tile}: {bad}'
