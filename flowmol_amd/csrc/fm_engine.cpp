@@ -56,6 +56,7 @@ struct fm_ctx {
     int tm_edge = 32, tm_node = 32, tm_eupd = 32;
     int tm_edge_forced = 0, tm_node_forced = 0;
     int n_cus = 256;
+    int pair_mlps_forced = -1;      // FM_PAIR_MLPS
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (FM_FUSE_NODE=0: separate launches)
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
@@ -324,6 +325,12 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const int nc1 = c->nc + 1;
     auto tap = [&](const std::string& n, const void* p, size_t bytes) { if (taps_on) L.tap(n, p, bytes); };
 
+    // Node- and pair-side MLPs with the same inputs share one launch while the batch is small (two launches less per step where launches
+    // are what a step costs).  The shared launch allocates the LARGER tile's LDS (node tiles: 147 KB -> one workgroup per CU) for every
+    // workgroup, so once the pair tiles alone fill the chip they run as a launch of their own at two workgroups per CU
+    // (profiles/r02n: 1.16 -> 0.94 ms and 0.83 -> 0.68 ms per step at 1024 molecules).  FM_PAIR_MLPS=0|1 forces either.
+    const int mlp_tiles = (N + FM_TM - 1) / FM_TM + (U + FM_TM - 1) / FM_TM;
+    const bool pair_mlps = c->fuse_node && (c->pair_mlps_forced >= 0 ? c->pair_mlps_forced != 0 : mlp_tiles <= c->n_cus);
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -355,7 +362,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         e.out = c->ef;
         e.p_e0 = b.p_e0; e.p_e1 = b.p_e1;
         // one row per unordered pair, written to both directed edges; node and pair tiles share one launch
-        if (c->fuse_node) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U);
+        if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U);
         else { launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N); launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U); }
         tap("sc.s", c->s, (size_t)N * 256 * 4);
         tap("sc.ef", c->ef, (size_t)E * 128 * 4);
@@ -469,7 +476,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         a.in = c->s; a.out = out->a; a.out2 = out->c;
         FmMlpArgs e = ma;
         e.ef = c->ef; e.p_e0 = b.p_e0; e.p_e1 = b.p_e1; e.out = out->e;
-        if (c->fuse_node) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U);
+        if (pair_mlps) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U);
         else { launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N); launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U); }
     }
     if (remove_com != 2) {       // 2: the caller's fused CTMC kernel centres the raw positions (c->xw) and writes out->x itself
@@ -832,6 +839,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node_forced = atoi(e2);
     if (const char* e4 = getenv("FM_XCD_SWIZZLE")) c->xcd_swizzle = atoi(e4);
     if (const char* e5 = getenv("FM_FUSE_NODE")) c->fuse_node = atoi(e5);
+    if (const char* e6 = getenv("FM_PAIR_MLPS")) c->pair_mlps_forced = atoi(e6) != 0;
     if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
     if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
