@@ -266,8 +266,11 @@ def test_endpoint_hparams_are_read_like_the_reference():
     cfg = from_reference_hparams(hp)
     assert cfg.parameterization == 'endpoint' and not cfg.has_mask and cfg.token_dims == (5, 6, 4)
     assert cfg.prior_types == {'a': 'gaussian', 'c': 'uniform-simplex', 'e': 'barycenter'} and cfg.continuous_inv_temp_max == 4.0
+    check_reference_hparams({**hp, 'prior_config': {**hp['prior_config'], 'a': {'type': 'marginal', 'kwargs': {}}}})       # dataset-statistics priors: implemented
     with pytest.raises(NotImplementedError):
-        check_reference_hparams({**hp, 'prior_config': {**hp['prior_config'], 'a': {'type': 'marginal', 'kwargs': {}}}})
+        check_reference_hparams({**hp, 'prior_config': {**hp['prior_config'], 'a': {'type': 'no-such-prior', 'kwargs': {}}}})
+    with pytest.raises(ValueError):
+        check_reference_hparams({**hp, 'prior_config': {**hp['prior_config'], 'a': {'type': 'c-given-a', 'kwargs': {}}}})   # a charge prior only
     with pytest.raises(NotImplementedError):
         from_reference_hparams({**hp, 'vector_field_config': {**hp['vector_field_config'], 'self_conditioning': True}})
 
