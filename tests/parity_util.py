@@ -275,3 +275,47 @@ def endpoint_golden(eng, g, device=None):
     for k, ref in (('x', 'x_1'), ('a', 'a_1'), ('c', 'c_1'), ('e', 'e_1_upper')):
         res[f'int.{k}'] = rel(st[f'{k}_t'], g[ref])
     return res
+
+
+def oracle_rounding_sensitivity(cfg, sd, n_atoms, t_val, with_prev, seed=3, frac_masked=0.4):
+    """How far the reference arithmetic itself moves when only its rounding changes: the oracle in float32 against the oracle in float64 on
+    the inputs forward_compare() uses (same generator order).  {stage: max |f32 - f64| / max |f64|} for every tap and output -- the yardstick for
+    kernel errors in ill-conditioned regimes (large weights), where a fixed tolerance says nothing."""
+    batch = cpu_ref.build_batch(n_atoms)
+    gen = torch.Generator().manual_seed(seed)
+    N = int(n_atoms.sum())
+    U = int((n_atoms * (n_atoms - 1) // 2).sum())
+    a = rand_tokens(N, cfg.n_atom_types, frac_masked, gen)
+    c = rand_tokens(N, cfg.n_charges, frac_masked, gen)
+    eu = rand_tokens(U, cfg.n_bond_types, frac_masked, gen)
+    x = torch.randn(N, 3, generator=gen) * 1.5
+    prev = None
+    if with_prev and cfg.self_conditioning:
+        prev = {'x': x + 0.3 * torch.randn(N, 3, generator=gen),
+                'a': torch.softmax(torch.randn(N, cfg.n_atom_types, generator=gen), -1),
+                'c': torch.softmax(torch.randn(N, cfg.n_charges, generator=gen), -1),
+                'e': torch.softmax(torch.randn(U, cfg.n_bond_types, generator=gen), -1)}
+    a1h, c1h, e1h = onehots(cfg, batch, a, c, eu)
+    res = {}
+    try:
+        for dt in (torch.float32, torch.float64):
+            torch.set_default_dtype(dt)
+            orc = cpu_ref.OracleVF(cfg, sd)
+            orc.p = {k: v.to(dt) for k, v in orc.p.items()}
+            orc.taps = {}
+            with torch.no_grad():
+                out = orc.forward(batch, x.to(dt), a1h.to(dt), c1h.to(dt), e1h.to(dt), torch.full((batch.B,), float(t_val), dtype=dt),
+                                  prev=None if prev is None else {k: v.to(dt) for k, v in prev.items()}, apply_softmax=True, remove_com=True)
+            res[dt] = dict(orc.taps)
+            res[dt].update({f'out.{k}': v for k, v in out.items()})
+    finally:
+        torch.set_default_dtype(torch.float32)
+    lo, hi = res[torch.float32], res[torch.float64]
+    return {k: float((lo[k].double() - hi[k]).abs().max() / hi[k].abs().max().clamp(min=1e-30)) for k in hi if k in lo}
+
+
+def scaled_weights(sd, scale):
+    """Every Linear / GVP weight matrix times ``scale`` (biases, LayerNorm affine parameters and embeddings untouched): an ill-conditioned
+    network whose stage-to-stage error amplification is ~10x per convolution at scale 3."""
+    return {k: (v * scale if ('weight' in k or k.endswith(('Wh', 'Wu', 'Wcp'))) and 'norm' not in k and '.4.' not in k and 'token_embeddings' not in k else v)
+            for k, v in sd.items()}

@@ -380,3 +380,22 @@ def test_c_abi_error_behaviour_on_emulation(emu_lib, monkeypatch):
     eng.bind(torch.tensor([4, 3]))
     out = eng.forward(eng.prior_state(torch.zeros(eng.N, 3)), 0.0, bootstrap=True)
     assert torch.isfinite(out['x']).all()
+
+
+def test_error_tracks_the_reference_rounding_sensitivity_on_emulation(emu_lib):
+    """Ill-conditioned regime (all weight matrices x3: rounding differences grow ~10x per convolution; the f32 reference itself drifts
+    percent-level from its own float64 evaluation by the last conv).  A fixed tolerance is meaningless there -- the claim that holds is
+    that the kernels are as accurate as the reference's f32 arithmetic: every stage's error against the f32 oracle stays within a small
+    multiple of the oracle's own f32-vs-f64 discrepancy at that stage."""
+    from flowmol_amd.engine import Engine
+    from parity_util import oracle_rounding_sensitivity, scaled_weights
+    cfg = presets.flowmol3()
+    sd = scaled_weights(weights.synth_state_dict(cfg, 0), 3.0)
+    sizes = torch.tensor([4, 7, 2])
+    sens = oracle_rounding_sensitivity(cfg, sd, sizes, 0.5, True)
+    assert sens['conv5.s'] > 1e-3                      # the regime really is ill-conditioned (standard weights: 6e-7)
+    eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+    errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, sizes, 0.5, True)
+    bad = {k: (v, sens[k]) for k, v in errs.items() if k in sens and not v <= max(5e-5, 8 * sens[k])}
+    assert not bad, bad
+    assert all(torch.isfinite(v).all() for v in out.values())

@@ -764,3 +764,25 @@ def test_forward_matches_oracle_on_random_batches(seed):
     _report(f'forward_random[{seed}: {name},{sizes},{t:.3f},prev={prev},tile{tile}]', errs)
     bad = {k: v for k, v in errs.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
     assert not bad, f'{name} {sizes} t={t} tile={tile}: {bad}'
+
+
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3'])
+def test_error_tracks_the_reference_rounding_sensitivity(precision):
+    """Ill-conditioned regime (all weight matrices x3: rounding differences grow ~10x per convolution, the f32 reference itself drifts
+    percent-level from its own float64 evaluation by the last conv): every stage's error against the f32 oracle stays within a small
+    multiple of the oracle's own f32-vs-f64 discrepancy at that stage -- the kernels are as accurate as the reference's arithmetic, not
+    merely inside a tolerance tuned for benign weights.  The opt-in split-precision mode is held to its own (documented, ~10x) factor."""
+    from flowmol_amd.engine import Engine
+    from parity_util import oracle_rounding_sensitivity, scaled_weights
+    cfg = presets.flowmol3()
+    sd = scaled_weights(weights.synth_state_dict(cfg, 0), 3.0)
+    sizes = torch.tensor([5, 12, 47, 2])
+    sens = oracle_rounding_sensitivity(cfg, sd, sizes, 0.5, True)
+    assert sens['conv5.s'] > 1e-3
+    eng = Engine(cfg, sd, device='cuda:0', precision=precision)
+    errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, sizes, 0.5, True)
+    factor, floor = (8, 5e-5) if precision == 'f32' else (80, 5e-4)
+    _report(f'rounding_sensitivity[{precision}]', {k: (errs[k], sens[k]) for k in errs if k in sens})
+    bad = {k: (v, sens[k]) for k, v in errs.items() if k in sens and not v <= max(floor, factor * sens[k])}
+    assert not bad, bad
+    assert all(torch.isfinite(v).all() for v in out.values())
