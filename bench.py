@@ -175,8 +175,8 @@ def main():
                     help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
                          "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) -- a separately reported mode")
     ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
-    ap.add_argument('--cpu-mols', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-mols', type=int, default=16)
+    ap.add_argument('--cpu-steps', type=int, default=8)
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
