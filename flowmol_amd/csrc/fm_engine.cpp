@@ -23,6 +23,8 @@
 
 namespace {
 
+constexpr int FM_TAB_SLOTS = 32;      // embedding tables kept per bound batch: fm_integrate builds those of up to 32 steps in one launch
+
 thread_local std::string g_create_error;
 
 struct ProfEvent { int kid; hipEvent_t a, b; };
@@ -76,6 +78,7 @@ struct fm_ctx {
     int n_tiles_e = 0, n_tiles_n = 0, n_tiles_u = 0;
     float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
     float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *Psd = nullptr, *PVd = nullptr;
+    float* s_tab_base = nullptr; size_t tab_slot_floats = 0;      // FM_TAB_SLOTS embedding tables (one per step of a chunk); s_tab = the current step's
     float *tap_s = nullptr, *tap_v = nullptr;    // scratch of the aggregated-message taps (parity runs only)
     fm_dst boot{};
     int32_t *sa1 = nullptr, *sc1 = nullptr, *se1 = nullptr;
@@ -501,22 +504,30 @@ int evaluate_dispatch(fm_ctx* c, hipStream_t st, const fm_state* state, const fm
     return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d dst_vectors=%d", c->V, c->tm_edge, c->tm_node, c->HX);
 }
 
-int embed_table(fm_ctx* c, hipStream_t st, const float* temb) {
+// The (atom type, charge) embedding table(s) of `n_tables` consecutive time points (temb: n_tables x time_embedding_dim) into the
+// workspace's table slots 0..n_tables-1, ONE launch: the table depends on the time only, so fm_integrate builds the tables of a
+// whole chunk of steps up front (a launch that fills the chip) instead of one 2-tile launch on every step's critical path.
+int embed_table(fm_ctx* c, hipStream_t st, const float* temb, int n_tables = 1) {
     Launch L{c, st};
     const fm_config& cf = c->cfg;
     FmMlpArgs a{};
     a.in = nullptr; a.n_c1 = c->nc + 1;          // rows = (a,c) token pairs; the input row is built in the kernel's prologue
     a.emb_a = c->emb_a; a.emb_c = c->emb_c; a.temb = temb;
     a.ta = cf.a_token_dim ? cf.a_token_dim : c->na + 1; a.tc = cf.c_token_dim ? cf.c_token_dim : c->nc + 1; a.tt = cf.time_embedding_dim;
-    a.out = c->s_tab; a.out_ld = 256; a.ln_g = c->node_ln_g; a.ln_b = c->node_ln_b; a.ln_n = c->S;
-    launch_mlp<FM_MLP_TABLE>(L, "embed_table", a, c->node_embed, c->tab_rows);
+    a.out = c->s_tab_base; a.out_ld = 256; a.ln_g = c->node_ln_g; a.ln_b = c->node_ln_b; a.ln_n = c->S;
+    fill_mlp(a, c->node_embed, c->tab_rows);
+    a.tab_tiles = (c->tab_rows + FM_TM - 1) / FM_TM; a.tab_stride = a.tab_tiles * FM_TM * 256;
+    L("embed_table", fm_k_mlp2<FM_MLP_TABLE>, dim3(a.tab_tiles * n_tables), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
     return L.rc;
 }
 
+// tables_ready: the caller (fm_integrate) has already built this step's table into slot `table_slot`
 int forward_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const float* temb, const fm_dst* prev, int bootstrap,
-                 int remove_com, const fm_dst* out) {
-    int rc = embed_table(c, st, temb);
+                 int remove_com, const fm_dst* out, int table_slot = -1) {
+    int rc = 0;
+    if (table_slot < 0) { table_slot = 0; rc = embed_table(c, st, temb); }
     if (rc) return rc;
+    c->s_tab = c->s_tab_base + (size_t)table_slot * c->tab_slot_floats;
     const bool sc = c->cfg.self_conditioning != 0;
     if (sc && !prev && bootstrap) {
         rc = evaluate_dispatch(c, st, state, nullptr, 0, &c->boot, false);
@@ -922,7 +933,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.off_Ps = take((size_t)N * 256 * 4); w.off_Asd = take((size_t)N * 256 * 4); w.off_PV = take((size_t)N * 3 * c->PVW * 4);
     w.off_Psd = take(c->HX ? (size_t)N * 256 * 4 : 0); w.off_PVd = take(c->HX ? (size_t)N * 3 * c->PVW * 4 : 0);
     w.off_part_s = take((size_t)N * w.P * 256 * 4); w.off_part_v = take((size_t)N * w.P * 3 * V * 4);
-    w.off_stab = take((size_t)align_up(w.tab_rows, FM_TM) * 256 * 4);
+    w.off_stab = take((size_t)align_up(w.tab_rows, FM_TM) * 256 * 4 * FM_TAB_SLOTS);
     w.off_bx = take((size_t)N * 3 * 4); w.off_ba = take((size_t)N * c->na * 4); w.off_bc = take((size_t)N * c->nc * 4); w.off_be = take((size_t)w.U * c->ne * 4);
     w.off_tap_s = take((size_t)N * 256 * 4); w.off_tap_v = take((size_t)N * 3 * V * 4);
     w.off_gid = take((size_t)B * 4);
@@ -973,7 +984,8 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     c->Ps = (float*)(base + w.off_Ps); c->Asd = (float*)(base + w.off_Asd); c->PV = (float*)(base + w.off_PV);
     c->part_s = (float*)(base + w.off_part_s); c->part_v = (float*)(base + w.off_part_v);
     c->Psd = (float*)(base + w.off_Psd); c->PVd = (float*)(base + w.off_PVd);
-    c->s_tab = (float*)(base + w.off_stab);
+    c->s_tab = c->s_tab_base = (float*)(base + w.off_stab);
+    c->tab_slot_floats = (size_t)align_up(w.tab_rows, FM_TM) * 256;
     c->boot.x = (float*)(base + w.off_bx); c->boot.a = (float*)(base + w.off_ba); c->boot.c = (float*)(base + w.off_bc); c->boot.e = (float*)(base + w.off_be);
     c->tap_s = (float*)(base + w.off_tap_s); c->tap_v = (float*)(base + w.off_tap_v);
     c->mol_gid = (int*)(base + w.off_gid);
@@ -1071,7 +1083,13 @@ int fm_integrate(fm_ctx* c, void* stream, const fm_state* state, int n_steps, co
         const int boot = (!prev && steps[i].t == 0.0f) ? 1 : 0;      // prev is None and (t == 0).all(), vector_field.py:269-272
         // campbell steps: the COM removal of the endpoint positions runs inside the fused CTMC kernel (one launch and one copy less)
         const bool defer_com = steps[i].dfm_type == FM_DFM_CAMPBELL;
-        int rc = forward_impl(c, st, state, temb + (size_t)i * tt, prev, boot, defer_com ? 2 : 1, out);
+        // embedding tables of the next FM_TAB_SLOTS steps in one launch
+        if (i % FM_TAB_SLOTS == 0) {
+            const int nt = n_steps - i < FM_TAB_SLOTS ? n_steps - i : FM_TAB_SLOTS;
+            const int rc0 = embed_table(c, st, temb + (size_t)i * tt, nt);
+            if (rc0) return rc0;
+        }
+        int rc = forward_impl(c, st, state, temb + (size_t)i * tt, prev, boot, defer_com ? 2 : 1, out, i % FM_TAB_SLOTS);
         if (rc) return rc;
         fm_sampled smp{};
         if (sink) {

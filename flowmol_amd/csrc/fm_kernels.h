@@ -93,6 +93,9 @@ struct FmMlpArgs {
     const float* prev_e; const float* T1; const float* ef_tab;
     // TABLE with in == null: rows are the (a,c) token pairs, x = [emb_a[a] | emb_c[c] | temb] (or one-hots when emb_* are null)
     const float* emb_a; const float* emb_c; const float* temb; int ta, tc, tt;
+    // TABLE, several tables in one launch (the embedding tables of a whole chunk of integration steps): workgroup b builds tile
+    // b % tab_tiles of table b / tab_tiles, whose time embedding is temb + table * tt and whose rows start at out + table * tab_stride
+    int tab_tiles; int tab_stride;
 };
 
 template <int MODE>
@@ -318,7 +321,14 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
 template <int MODE>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
     HIP_DYNAMIC_SHARED(float, lds)
-    fm_mlp2_tile<MODE>(a, blockIdx.x, lds);
+    int tile = blockIdx.x;
+    if (MODE == FM_MLP_TABLE && a.tab_tiles > 0) {
+        const int tab = tile / a.tab_tiles;
+        tile -= tab * a.tab_tiles;
+        a.temb += tab * a.tt;
+        a.out += (size_t)tab * a.tab_stride;
+    }
+    fm_mlp2_tile<MODE>(a, tile, lds);
 }
 
 // Two independent MLP passes in ONE launch (node-side tiles first, then the pair-side tiles): the self-conditioning layers

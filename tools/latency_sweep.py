@@ -35,12 +35,15 @@ for B in sizes:
     torch.cuda.synchronize()
     gpu_ms = 0.0
     nl = 0
+    per_kernel = {}
     for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head',
               'node_head', 'sc', 'heads', 'ctmc', 'embed_table', 'remove_com', 'x_step'):
         ms, cnt = eng.profile_get(k)
         gpu_ms += ms
         nl += cnt
+        if cnt:
+            per_kernel[k] = round(ms / cnt * 1e3, 1)       # us per launch
     eng.profile(False)
     import os
     print(json.dumps({'mols': B, 'noise': 'philox' if philox else 'torch', 'fuse_node': os.environ.get('FM_FUSE_NODE', '1'), 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
-                      'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2)}))
+                      'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2), 'us_per_launch': per_kernel}))
