@@ -173,19 +173,22 @@ def mol_block(positions, atom_types, atom_charges, bond_src, bond_dst, bond_type
     """MDL V2000 mol block as RDKit's writer lays it out (the reference writes SDF through Chem.SDWriter, test.py:212-257):
     counts line, atom lines with the legacy charge column, bond lines, `M  CHG` property lines (8 entries per line) for the
     charged atoms, `M  END`.  ('$$$$' is the caller's job.)"""
-    na, nb = len(atom_types), int(bond_types.shape[0])
+    def as_list(t):          # one bulk conversion instead of a tensor index per element (trajectory dumps write hundreds of frames per molecule)
+        return t.tolist() if hasattr(t, 'tolist') else list(t)
+    pos, chgs = as_list(positions), as_list(atom_charges)
+    b_src, b_dst, b_typ = as_list(bond_src), as_list(bond_dst), as_list(bond_types)
+    na, nb = len(atom_types), len(b_typ)
     lines = [name, '  flowmol_amd          3D', '', f'{na:3d}{nb:3d}  0  0  0  0  0  0  0  0999 V2000']
     charged = []
     for i, sym in enumerate(atom_types):
-        x, y, z = (float(v) for v in positions[i])
-        q = int(atom_charges[i])
+        x, y, z = pos[i]
+        q = int(chgs[i])
         chg = _CHG.get(q, 0)
         if q != 0:
             charged.append((i + 1, q))
         lines.append(f'{x:10.4f}{y:10.4f}{z:10.4f} {sym:<3s} 0{chg:3d}  0  0  0  0  0  0  0  0  0  0')
     for k in range(nb):
-        bt = int(bond_types[k])
-        lines.append(f'{int(bond_src[k]) + 1:3d}{int(bond_dst[k]) + 1:3d}{bt:3d}  0')
+        lines.append(f'{int(b_src[k]) + 1:3d}{int(b_dst[k]) + 1:3d}{int(b_typ[k]):3d}  0')
     for o in range(0, len(charged), 8):
         part = charged[o:o + 8]
         lines.append(f'M  CHG{len(part):3d}' + ''.join(f' {a:3d} {q:3d}' for a, q in part))
