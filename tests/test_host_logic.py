@@ -310,3 +310,28 @@ def test_shipped_marginals_and_simplex_projection():
     assert (y >= 0).all() and torch.allclose(y.sum(-1), torch.ones(50), atol=1e-6)
     inside = torch.softmax(x, -1)
     assert torch.allclose(simplex_projection(inside), inside, atol=1e-6)          # a point of the simplex is its own projection
+
+
+def test_trajectory_blocks_batched_path_equals_per_frame_path():
+    """traj_mol_blocks() (all frames in numpy, one batched SVD) against frame_moldata() + rigid_alignment() + mol_block() per frame:
+    same atoms, charges and bonds; coordinates equal to the last printed digit's rounding."""
+    from flowmol_amd.molecule import rigid_alignment
+    torch.manual_seed(0)
+    n, T = 9, 12
+    amap = ['C', 'H', 'N', 'O', 'F']
+    fr = {'x': torch.randn(T, n, 3) * 2, 'a': torch.randint(0, 7, (T, n), dtype=torch.int32), 'c': torch.randint(0, 7, (T, n), dtype=torch.int32),
+          'e': (torch.randint(0, 5, (T, n * (n - 1) // 2), dtype=torch.int32) * (torch.rand(T, n * (n - 1) // 2) < 0.3)).int()}
+    fr.update({k + '_1_pred': v[1:] for k, v in fr.items()})
+    m = SampledMolecule(fr['x'][-1], fr['a'][-1].clamp(max=5), fr['c'][-1].clamp(max=5), fr['e'][-1].clamp(max=3), amap, fake_atoms=True, traj_frames=fr)
+    for ep in (False, True):
+        key = 'x_1_pred' if ep else 'x'
+        new = m.traj_mol_blocks(ep_traj=ep)
+        assert len(new) == fr[key].shape[0]
+        for f, blk in enumerate(new):
+            pos, sym, chg, bt, bs, bd = m.frame_moldata(f, ep_traj=ep)
+            ref = mol_block(rigid_alignment(pos, fr[key][-1]), sym, chg, bs, bd, bt, name=f'frame {f}').splitlines()
+            got = blk.splitlines()
+            assert len(ref) == len(got)
+            for a, b in zip(ref, got):
+                if a != b:          # an atom line whose 4th decimal rounds the other way
+                    assert a[30:] == b[30:] and all(abs(float(a[i:i + 10]) - float(b[i:i + 10])) <= 1.01e-4 for i in (0, 10, 20)), (a, b)
