@@ -167,6 +167,8 @@ class FlowMol:
                 self._engine.close()
                 self._engine = None
             self.device = device
+        if device.type == 'cuda':
+            self.engine          # like nn.Module.to(): the weights are repacked and uploaded NOW (fm_create), not inside the first sample() call
         return self
 
     def cuda(self, device=None) -> "FlowMol":
