@@ -414,7 +414,9 @@ class FlowMol:
         """FlowMol.sample for parameterization='endpoint' (flowmol.py:489-589 with EndpointVectorField.integrate, vector_field.py:388-499):
         the categorical modalities are continuous vectors integrated with the same Euler step as the positions; the sampled
         molecule takes their argmax.  RNG order = the reference's: randn(N,3) on the device, then a, c, e priors on the CPU generator."""
-        unknown = set(kwargs) - {'inv_temp_func', 'tspan'}
+        if kwargs.get('rng', 'torch') != 'torch' or '_philox' in kwargs:
+            raise NotImplementedError("per-molecule Philox noise covers CTMC models; endpoint models draw their priors with torch (noise='per_rank' / 'replicated')")
+        unknown = set(kwargs) - {'inv_temp_func', 'tspan', '_rows', 'rng'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         eng, cfg = self.engine, self.cfg
@@ -422,15 +424,20 @@ class FlowMol:
         n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
         eng.bind(n_atoms)
         N, U = eng.N, eng.U
+        rows = kwargs.get('_rows')      # sample_distributed(noise='replicated'): (N_full, U_full, node rows, pair rows) -- draw the full batch's priors, keep this shard's
         if prior is None:
-            x0 = torch.randn(N, 3, device=dev)
-            eng.remove_com(x0)
+            nN, nU = (rows[0], rows[1]) if rows is not None else (N, U)
+            x0 = torch.randn(nN, 3, device=dev)
             pk = cfg.prior_kwargs
-            a0 = self._categorical_prior(cfg.prior_types['a'], N, cfg.n_atom_types, pk.get('a', {}), default_p=self._default_marginal('a', cfg.n_atom_types))
+            a0 = self._categorical_prior(cfg.prior_types['a'], nN, cfg.n_atom_types, pk.get('a', {}), default_p=self._default_marginal('a', cfg.n_atom_types))
             c_kind = cfg.prior_types['c']
-            c0 = self._categorical_prior(c_kind, N, cfg.n_charges, pk.get('c', {}), a_0=a0,
+            c0 = self._categorical_prior(c_kind, nN, cfg.n_charges, pk.get('c', {}), a_0=a0,
                                          default_p=self._default_marginal('c|a' if c_kind == 'c-given-a' else 'c', cfg.n_charges))
-            e0 = self._categorical_prior(cfg.prior_types['e'], U, cfg.n_bond_types, pk.get('e', {}), default_p=self._default_marginal('e', cfg.n_bond_types))
+            e0 = self._categorical_prior(cfg.prior_types['e'], nU, cfg.n_bond_types, pk.get('e', {}), default_p=self._default_marginal('e', cfg.n_bond_types))
+            if rows is not None:
+                x0 = x0[rows[2]].contiguous()
+                a0, c0, e0 = a0[rows[2].cpu()], c0[rows[2].cpu()], e0[rows[3].cpu()]
+            eng.remove_com(x0)          # per molecule, so centring after the row selection equals centring the full batch
         else:
             x0, a0, c0 = prior['x_0'], prior['a_0'], prior['c_0']
             e0 = prior['e_0']

@@ -65,7 +65,7 @@ def test_shard_and_gather_world2(sizes):
     assert all(n == int(n_atoms.sum()) for _, _, n in res)
 
 
-def _sample_worker(rank, world, port, sizes, q, noise='per_rank'):
+def _sample_worker(rank, world, port, sizes, q, noise='per_rank', preset='qm9'):
     """Each rank: emulated engine on the CPU, its own RNG stream (or the same one in replicated-noise mode),
     sample_distributed over gloo."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -75,7 +75,7 @@ def _sample_worker(rank, world, port, sizes, q, noise='per_rank'):
     import flowmol_amd as flowmol
     from flowmol_amd import _lib
     emu = _lib.load(Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so')
-    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=emu).to('cpu')
+    model = flowmol.FlowMol.from_preset(preset, _engine_lib=emu).to('cpu')
     torch.manual_seed(100 + (rank if noise == 'per_rank' else 0))
     full, n = model.sample_distributed(torch.tensor(sizes), n_timesteps=3, return_tensors=True, noise=noise)
     q.put((rank, {k: v.numpy().copy() for k, v in full.items()}))    # plain arrays: torch's fd-based tensor sharing needs the producer alive
@@ -144,23 +144,25 @@ def test_cli_under_two_ranks_writes_once(tmp_path, emu_lib_path):
     assert out.read_text().count('$$$$') == 5
 
 
-def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path):
+@pytest.mark.parametrize('preset', ['qm9', 'endpoint_small'])
+def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path, preset):
     """Parity mode of the sharded path: with every rank drawing the full batch's noise from the same seed, two ranks
     reproduce the single-process sample(n_atoms): identical tokens, coordinates to summation order (molecules are
-    independent: SURVEY.md §8e)."""
+    independent: SURVEY.md §8e).  For an endpoint-parameterised model the only randomness is the priors, drawn for the full
+    batch on every rank and sliced."""
     import flowmol_amd as flowmol
     from flowmol_amd import _lib
     sizes = [4, 6, 3, 5]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q, 'replicated')) for r in range(2)]
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q, 'replicated', preset)) for r in range(2)]
     for p in procs:
         p.start()
     res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=300) for _ in procs)}
     for p in procs:
         p.join(timeout=60)
-    model = flowmol.FlowMol.from_preset('qm9', _engine_lib=_lib.load(emu_lib_path)).to('cpu')
+    model = flowmol.FlowMol.from_preset(preset, _engine_lib=_lib.load(emu_lib_path)).to('cpu')
     torch.manual_seed(100)
     single, _ = model.sample(torch.tensor(sizes), n_timesteps=3, return_tensors=True)
     for r in range(2):
