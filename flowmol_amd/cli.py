@@ -31,7 +31,7 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description='FlowMol3 sampling on MI355X')
     p.add_argument('--model_dir', type=Path, default=None, help='model directory holding checkpoints/last.ckpt')
     p.add_argument('--checkpoint', type=Path, default=None, help='path to a Lightning checkpoint')
-    p.add_argument('--preset', type=str, default=None, help='architecture preset with synthetic weights (flowmol3, geom_ctmc, qm9)')
+    p.add_argument('--preset', type=str, default=None, help='architecture preset with synthetic weights: ' + ', '.join(sorted(__import__('flowmol_amd.presets', fromlist=['PRESETS']).PRESETS)))
     p.add_argument('--output_file', type=Path, default=None)
     p.add_argument('--n_mols', type=int, default=100)
     p.add_argument('--n_atoms_per_mol', type=int, default=None)
