@@ -59,6 +59,7 @@ struct fm_ctx {
     int tm_edge_forced = 0, tm_node_forced = 0;
     int n_cus = 256;
     int pair_mlps_forced = -1;      // FM_PAIR_MLPS
+    int small_mlp_forced = -1;      // FM_MLP_SMALL_TILES
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (FM_FUSE_NODE=0: separate launches)
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
@@ -256,8 +257,8 @@ size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
     size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, HX) + 4) + TM * FM_LDG;
     return fl * 4 + (with_meta ? (size_t)TM * 9 * 4 : 0);
 }
-size_t lds_mlp(int ldx, int ldh) { return ((size_t)FM_TM * ldx + (size_t)FM_TM * ldh) * 4 + 5 * FM_TM * 4; }
-size_t lds_proj(int V) { return ((size_t)FM_TM * 260 + 3 * FM_TM * (V + 4)) * 4; }
+size_t lds_mlp(int ldx, int ldh, int tm = FM_TM) { return ((size_t)tm * ldx + (size_t)tm * ldh) * 4 + 5 * (size_t)tm * 4; }
+size_t lds_proj(int V, int tm = FM_TM) { return ((size_t)tm * 260 + 3 * (size_t)tm * (V + 4)) * 4; }
 size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
 size_t lds_edge_upd_sp(int TM) { return (size_t)TM * 132 * 4 + (size_t)TM * 176 * 2 * 2 + TM * 3 * 4; }
 
@@ -306,15 +307,19 @@ void fill_mlp(FmMlpArgs& a, const MlpW& w, int rows) {
     a.ldx = ld_for(w.K1p > w.O ? w.K1p : w.O); a.ldh = ld_for(w.H);
 }
 template <int MODE>
-void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows) {
+void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows, bool small_tiles = false) {
     fill_mlp(a, w, rows);
-    L(name, fm_k_mlp2<MODE>, dim3((rows + FM_TM - 1) / FM_TM), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
+    if (small_tiles) L(name, fm_k_mlp2<MODE, 16>, dim3((rows + 15) / 16), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh, 16), a);
+    else L(name, fm_k_mlp2<MODE>, dim3((rows + FM_TM - 1) / FM_TM), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
 }
 template <int MODE_A, int MODE_B>
-void launch_mlp_pair(Launch& L, const char* name, FmMlpArgs a, const MlpW& wa, int rows_a, FmMlpArgs b, const MlpW& wb, int rows_b) {
+void launch_mlp_pair(Launch& L, const char* name, FmMlpArgs a, const MlpW& wa, int rows_a, FmMlpArgs b, const MlpW& wb, int rows_b, bool small_tiles = false) {
     fill_mlp(a, wa, rows_a); fill_mlp(b, wb, rows_b);
-    const int ta = (rows_a + FM_TM - 1) / FM_TM, tb = (rows_b + FM_TM - 1) / FM_TM;
-    L(name, fm_k_mlp2_pair<MODE_A, MODE_B>, dim3(ta + tb), dim3(FM_THREADS), std::max(lds_mlp(a.ldx, a.ldh), lds_mlp(b.ldx, b.ldh)), a, b, ta);
+    const int tm = small_tiles ? 16 : FM_TM;
+    const int ta = (rows_a + tm - 1) / tm, tb = (rows_b + tm - 1) / tm;
+    const size_t lds = std::max(lds_mlp(a.ldx, a.ldh, tm), lds_mlp(b.ldx, b.ldh, tm));
+    if (small_tiles) L(name, fm_k_mlp2_pair<MODE_A, MODE_B, 16>, dim3(ta + tb), dim3(FM_THREADS), lds, a, b, ta);
+    else L(name, fm_k_mlp2_pair<MODE_A, MODE_B>, dim3(ta + tb), dim3(FM_THREADS), lds, a, b, ta);
 }
 
 // ---------------------------------------------------------------------------------------- one network evaluation
@@ -334,6 +339,11 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     // (profiles/r02n: 1.16 -> 0.94 ms and 0.83 -> 0.68 ms per step at 1024 molecules).  FM_PAIR_MLPS=0|1 forces either.
     const int mlp_tiles = (N + FM_TM - 1) / FM_TM + (U + FM_TM - 1) / FM_TM;
     const bool pair_mlps = c->fuse_node && (c->pair_mlps_forced >= 0 ? c->pair_mlps_forced != 0 : mlp_tiles <= c->n_cus);
+    // 16-row MLP tiles while even those do not fill the chip (4 per CU fit in LDS): a tile's two dependent GEMMs are matrix-pipe time on one CU,
+    // so a quarter of the rows is a quarter of the latency (FM_MLP_SMALL_TILES=0|1 forces either)
+    const bool small_node = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (N + 15) / 16 <= 4 * c->n_cus;      // decided per side: the node side
+    const bool small_pair = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (U + 15) / 16 <= 4 * c->n_cus;      // stays small ~25x longer than the pair side
+    const bool small_mlp = small_node && small_pair;                                                                   // shared launches
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -365,8 +375,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         e.out = c->ef;
         e.p_e0 = b.p_e0; e.p_e1 = b.p_e1;
         // one row per unordered pair, written to both directed edges; node and pair tiles share one launch
-        if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U);
-        else { launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N); launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U); }
+        if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U, small_mlp);
+        else { launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N, small_node); launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U, small_pair); }
         tap("sc.s", c->s, (size_t)N * 256 * 4);
         tap("sc.ef", c->ef, (size_t)E * 128 * 4);
     } else {
@@ -391,7 +401,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             FmProjArgs pa{};
             pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV; pa.pv_w = c->PVW;
             if (it == 0) { pa.v_init = c->v; pa.x_src = x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
-            L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
+            if (small_node) L("node_proj", fm_k_node_proj<V, 16>, dim3((N + 15) / 16), blk, lds_proj(V, 16), pa);
+            else L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
         }
         FmMsgArgs m{};
         m.b = b; m.x = c->xw; m.ef = c->ef; m.Ps = c->Ps; m.PV = c->PV; m.w0 = cw.w0;
@@ -457,7 +468,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
                 L("pos_update", fm_k_pos_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), pp);
                 FmProjArgs pa2{};
                 pa2.N = N; pa2.s = c->s; pa2.v = c->v; pa2.Wasd = uw.Wasd; pa2.Asd = c->Asd;
-                L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
+                if (small_node) L("node_proj_asd", fm_k_node_proj<V, 16>, dim3((N + 15) / 16), blk, lds_proj(V, 16), pa2);
+                else L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
             }
             FmEdgeUpdArgs eu{};
             eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
@@ -479,8 +491,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         a.in = c->s; a.out = out->a; a.out2 = out->c;
         FmMlpArgs e = ma;
         e.ef = c->ef; e.p_e0 = b.p_e0; e.p_e1 = b.p_e1; e.out = out->e;
-        if (pair_mlps) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U);
-        else { launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N); launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U); }
+        if (pair_mlps) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U, small_mlp);
+        else { launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N, small_node); launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U, small_pair); }
     }
     if (remove_com != 2) {       // 2: the caller's fused CTMC kernel centres the raw positions (c->xw) and writes out->x itself
         L.copy(out->x, c->xw, (size_t)N * 3 * 4);
@@ -851,6 +863,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (const char* e4 = getenv("FM_XCD_SWIZZLE")) c->xcd_swizzle = atoi(e4);
     if (const char* e5 = getenv("FM_FUSE_NODE")) c->fuse_node = atoi(e5);
     if (const char* e6 = getenv("FM_PAIR_MLPS")) c->pair_mlps_forced = atoi(e6) != 0;
+    if (const char* e7 = getenv("FM_MLP_SMALL_TILES")) c->small_mlp_forced = atoi(e7) != 0;
     if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
     if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
@@ -875,12 +888,17 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
+    set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
     set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max);
     set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>, mlp_max);
+    const size_t mlp_small = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260, 16);
+    set_lds(fm_k_mlp2<FM_MLP_SC_NODE, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_TABLE, 16>, mlp_small);
+    set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 16>, mlp_small);
+    set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE, 16>, mlp_small); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD, 16>, mlp_small);
     *out = c;
     return FM_OK;
 }

@@ -98,17 +98,19 @@ struct FmMlpArgs {
     int tab_tiles; int tab_stride;
 };
 
-template <int MODE>
+// TM = rows per tile: 64 (throughput: every weight fragment serves four row tiles) or 16 (small batches: a tile's two dependent GEMMs are
+// matrix-pipe time on ONE CU, so a quarter of the rows is a quarter of the latency, spread over four times as many CUs).
+template <int MODE, int TM>
 __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float* lds) {
     float* X = lds;                         // [64][ldx]
-    float* Hb = lds + FM_TM * a.ldx;        // [64][ldh]
-    int* meta = reinterpret_cast<int*>(Hb + FM_TM * a.ldh);   // [64] token / row ids
+    float* Hb = lds + TM * a.ldx;        // [64][ldh]
+    int* meta = reinterpret_cast<int*>(Hb + TM * a.ldh);   // [64] token / row ids
     const int tid = threadIdx.x;
-    const int row0 = tile * FM_TM;
+    const int row0 = tile * TM;
 
     // ---------------- prologue: fill X[:, 0..K1p)
     if (MODE == FM_MLP_TABLE) {
-        for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
+        for (int idx = tid; idx < TM * a.K1p; idx += FM_THREADS) {
             const int r = idx / a.K1p, c = idx % a.K1p, row = row0 + r;
             float v = 0.f;
             if (row < a.rows) {
@@ -123,8 +125,8 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             X[r * a.ldx + c] = v;
         }
     } else if (MODE == FM_MLP_SC_NODE) {
-        float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64] |x_t - x1_prev| per row
-        if (tid < FM_TM) {
+        float* dd = reinterpret_cast<float*>(meta + TM);     // [64] |x_t - x1_prev| per row
+        if (tid < TM) {
             const int n = row0 + tid;
             int tok = -1; float d = 0.f;
             if (n < a.rows) {
@@ -136,7 +138,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
         __syncthreads();
         {   // columns 0..255: the (a,c)-token embedding row, 16-byte loads (rows without a node read 0 via the range check)
             const auto rs = fm_buf(a.s_tab, 0x7fffffffu);
-            constexpr int NQ = FM_TM * 64 / FM_THREADS;
+            constexpr int NQ = TM * 64 / FM_THREADS;
             float4 q[NQ];
 #pragma unroll
             for (int k = 0; k < NQ; ++k) {
@@ -151,7 +153,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             }
         }
         const int kin = a.na + a.nc + 32, kw = a.K1p - 256;     // [p_a | p_c | rbf | zero padding]
-        for (int idx = tid; idx < FM_TM * kw; idx += FM_THREADS) {
+        for (int idx = tid; idx < TM * kw; idx += FM_THREADS) {
             const int r = idx / kw, c = idx % kw;
             const int n = row0 + r;
             float v = 0.f;
@@ -164,8 +166,8 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
         }
     } else if (MODE == FM_MLP_NODE_HEAD) {
         const int left = a.rows - row0;
-        const auto rs = fm_buf(a.in + (size_t)row0 * 256, (unsigned)(left < FM_TM ? left : FM_TM) * 1024u);
-        constexpr int NQ = FM_TM * 64 / FM_THREADS;
+        const auto rs = fm_buf(a.in + (size_t)row0 * 256, (unsigned)(left < TM ? left : TM) * 1024u);
+        constexpr int NQ = TM * 64 / FM_THREADS;
         float4 q[NQ];
 #pragma unroll
         for (int k = 0; k < NQ; ++k) q[k] = fm_buf_f32x4(rs, (tid + k * FM_THREADS) * 16, 0);
@@ -175,15 +177,15 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             *reinterpret_cast<float4*>(X + r * a.ldx + c4 * 4) = q[k];
         }
     } else if (MODE == FM_MLP_EDGE_HEAD) {
-        int* pr = meta + 3 * FM_TM;                              // [64] second edge of the pair
-        if (tid < FM_TM) {
+        int* pr = meta + 3 * TM;                              // [64] second edge of the pair
+        if (tid < TM) {
             const int p = row0 + tid;
             meta[tid] = (p < a.rows) ? a.p_e0[p] : -1;
             pr[tid] = (p < a.rows) ? a.p_e1[p] : -1;
         }
         __syncthreads();
         // x = ef[e0] + ef[e1]: 16-byte loads, all of a thread's requests issued before the first use
-        constexpr int NQ = FM_TM * 32 / FM_THREADS;
+        constexpr int NQ = TM * 32 / FM_THREADS;
         float4 u0[NQ], u1[NQ];
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
@@ -202,9 +204,9 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             *reinterpret_cast<float4*>(X + r * a.ldx + 4 * c4) = v;
         }
     } else {   // FM_MLP_SC_EDGE: per unordered pair (input, token and output are the same for both directions)
-        float* dd = reinterpret_cast<float*>(meta + FM_TM);     // [64][2]: d(x_t), d(x1_prev)
-        int* pr = meta + 3 * FM_TM;                              // [64] second edge of the pair
-        if (tid < FM_TM) {
+        float* dd = reinterpret_cast<float*>(meta + TM);     // [64][2]: d(x_t), d(x1_prev)
+        int* pr = meta + 3 * TM;                              // [64] second edge of the pair
+        if (tid < TM) {
             const int p = row0 + tid;
             int tok = -1, ea = -1, eb = -1;
             float dt_ = 0.f, d1_ = 0.f;
@@ -217,10 +219,10 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
                                a.prev_x[i * 3 + 2] - a.prev_x[j * 3 + 2]) + 1e-8f;
             }
             meta[tid] = tok; pr[tid] = eb; dd[2 * tid] = dt_; dd[2 * tid + 1] = d1_;
-            meta[4 * FM_TM + tid] = ea;       // [64] first edge of the pair
+            meta[4 * TM + tid] = ea;       // [64] first edge of the pair
         }
         __syncthreads();
-        for (int idx = tid; idx < FM_TM * a.K1p; idx += FM_THREADS) {
+        for (int idx = tid; idx < TM * a.K1p; idx += FM_THREADS) {
             const int r = idx / a.K1p, c = idx % a.K1p;
             float v = 0.f;
             if (meta[r] >= 0) {
@@ -235,7 +237,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
     __syncthreads();
 
     // ---------------- layer 1 -> Hb
-    fm_block_gemm<4, 1>(X, a.ldx, FM_TM / 16, a.K1p / 8, a.W1, a.H / 16, [&](int row, int col, float v) {
+    fm_block_gemm<TM / 16, 1>(X, a.ldx, TM / 16, a.K1p / 8, a.W1, a.H / 16, [&](int row, int col, float v) {
         if (MODE == FM_MLP_SC_EDGE) { const int t = meta[row]; v += (t >= 0) ? a.T1[t * 128 + col] : 0.f; }
         else v += a.b1[col];
         Hb[row * a.ldh + col] = fm_silu(v);
@@ -248,21 +250,22 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
         X[row * a.ldx + col] = v;
     };
     // the heads have 1-2 output column tiles: single-tile jobs keep 4-8 waves busy instead of 1-2
-    if (MODE == FM_MLP_NODE_HEAD || MODE == FM_MLP_EDGE_HEAD) fm_block_gemm<1, 1>(Hb, a.ldh, FM_TM / 16, a.H / 8, a.W2, a.O / 16, epi2);
-    else fm_block_gemm<4, 1>(Hb, a.ldh, FM_TM / 16, a.H / 8, a.W2, a.O / 16, epi2);
+    if (MODE == FM_MLP_NODE_HEAD || MODE == FM_MLP_EDGE_HEAD) fm_block_gemm<1, 1>(Hb, a.ldh, TM / 16, a.H / 8, a.W2, a.O / 16, epi2);
+    else fm_block_gemm<TM / 16, 1>(Hb, a.ldh, TM / 16, a.H / 8, a.W2, a.O / 16, epi2);
     __syncthreads();
 
     // ---------------- epilogue
-    const int r = tid >> 3, sub = tid & 7;          // 8 lanes per row
+    constexpr int LPR = FM_THREADS / TM;            // lanes per row: 8 (64-row tiles) or 32
+    const int r = tid / LPR, sub = tid % LPR;
     const int grow = row0 + r;
     if (MODE == FM_MLP_TABLE) {
         float mean, rstd;
-        fm_row_stats8(X + r * a.ldx, a.ln_n, sub, mean, rstd);
+        fm_row_stats<LPR>(X + r * a.ldx, a.ln_n, sub, mean, rstd);
         if (grow < a.rows) {
             // rows of a per-pair table (dense edge embedding of endpoint models) go to both directed edges of the pair
             float* o0 = a.out + (size_t)(a.p_e0 ? a.p_e0[grow] : grow) * a.out_ld;
             float* o1 = a.p_e1 ? a.out + (size_t)a.p_e1[grow] * a.out_ld : nullptr;
-            for (int c = sub; c < a.O; c += 8) {
+            for (int c = sub; c < a.O; c += LPR) {
                 const float y = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
                 o0[c] = y;
                 if (o1) o1[c] = y;
@@ -271,9 +274,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
     } else if (MODE == FM_MLP_SC_NODE) {
         if (grow < a.rows) {
             const float* trow = a.s_tab + (size_t)meta[r] * 256;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = (j * 8 + sub) * 4;
+            for (int c = sub * 4; c < 256; c += LPR * 4) {
                 const float4 t = *reinterpret_cast<const float4*>(trow + c);
                 const float4 x = *reinterpret_cast<const float4*>(X + r * a.ldx + c);
                 *reinterpret_cast<float4*>(a.out + (size_t)grow * 256 + c) = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
@@ -281,10 +282,8 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
         }
     } else if (MODE == FM_MLP_SC_EDGE) {
         if (grow < a.rows) {
-            const int ea = meta[4 * FM_TM + r], eb = meta[3 * FM_TM + r], tok = meta[r];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = (j * 8 + sub) * 4;
+            const int ea = meta[4 * TM + r], eb = meta[3 * TM + r], tok = meta[r];
+            for (int c = sub * 4; c < 128; c += LPR * 4) {
                 const float4 t = *reinterpret_cast<const float4*>(a.ef_tab + tok * 128 + c);
                 const float4 x = *reinterpret_cast<const float4*>(X + r * a.ldx + c);
                 const float4 o = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
@@ -318,7 +317,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
     }
 }
 
-template <int MODE>
+template <int MODE, int TM = FM_TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
     HIP_DYNAMIC_SHARED(float, lds)
     int tile = blockIdx.x;
@@ -328,17 +327,17 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2(FmMlpArgs a) {
         a.temb += tab * a.tt;
         a.out += (size_t)tab * a.tab_stride;
     }
-    fm_mlp2_tile<MODE>(a, tile, lds);
+    fm_mlp2_tile<MODE, TM>(a, tile, lds);
 }
 
 // Two independent MLP passes in ONE launch (node-side tiles first, then the pair-side tiles): the self-conditioning layers
 // (SC_NODE + SC_EDGE) and the output heads (NODE_HEAD + EDGE_HEAD) each depend on the same inputs only, so one kernel
 // boundary per pair is pure latency on the per-step critical path.
-template <int MODE_A, int MODE_B>
+template <int MODE_A, int MODE_B, int TM = FM_TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2_pair(FmMlpArgs a, FmMlpArgs b, int tiles_a) {
     HIP_DYNAMIC_SHARED(float, lds)
-    if ((int)blockIdx.x < tiles_a) fm_mlp2_tile<MODE_A>(a, blockIdx.x, lds);
-    else fm_mlp2_tile<MODE_B>(b, (int)blockIdx.x - tiles_a, lds);
+    if ((int)blockIdx.x < tiles_a) fm_mlp2_tile<MODE_A, TM>(a, blockIdx.x, lds);
+    else fm_mlp2_tile<MODE_B, TM>(b, (int)blockIdx.x - tiles_a, lds);
 }
 
 // gather-only initialisation when there is no self-conditioning input (bootstrap pass / non-SC models)
@@ -371,15 +370,16 @@ struct FmProjArgs {
     const float* x_src; float* x_dst;     // non-null: copy the tile's positions (working copy updated by NodePositionUpdate)
 };
 
-template <int V>
+// TM = rows per tile: 64, or 16 while even 16-row tiles do not fill the chip (latency of a small batch: see fm_mlp2_tile)
+template <int V, int TM = FM_TM>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int LDS_ = 260;                 // 260/4 = 65 odd
     constexpr int LDV = V + 4;
-    float* X = lds;                            // [64][260]
-    float* Vt = lds + FM_TM * LDS_;            // [192][V+4]
-    const int tid = threadIdx.x, row0 = blockIdx.x * FM_TM;
-    for (int idx = tid; idx < FM_TM * 64; idx += FM_THREADS) {
+    float* X = lds;                            // [TM][260]
+    float* Vt = lds + TM * LDS_;               // [3*TM][V+4]
+    const int tid = threadIdx.x, row0 = blockIdx.x * TM;
+    for (int idx = tid; idx < TM * 64; idx += FM_THREADS) {
         const int r = idx >> 6, c4 = idx & 63;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + r < a.N) val = reinterpret_cast<const float4*>(a.s)[(size_t)(row0 + r) * 64 + c4];
@@ -387,13 +387,13 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
         *reinterpret_cast<float4*>(d) = val;        // one ds_write_b128 (16-B aligned: row pitch and column offset are multiples of 16 B)
     }
     if (a.x_dst) {
-        const int i0 = row0 * 3, i1 = (row0 + FM_TM < a.N ? row0 + FM_TM : a.N) * 3;
+        const int i0 = row0 * 3, i1 = (row0 + TM < a.N ? row0 + TM : a.N) * 3;
         for (int i = i0 + tid; i < i1; i += FM_THREADS) a.x_dst[i] = a.x_src[i];
     }
     if (a.PV) {
-        const int rows = a.N - row0 < FM_TM ? a.N - row0 : FM_TM;
+        const int rows = a.N - row0 < TM ? a.N - row0 : TM;
         const auto rs_v = fm_buf(a.v + (size_t)row0 * 3 * V, (unsigned)rows * (3 * V * 4));
-        constexpr int V4 = V / 4, NCHK = FM_TM * 3 * V4, NV = (NCHK + FM_THREADS - 1) / FM_THREADS;
+        constexpr int V4 = V / 4, NCHK = TM * 3 * V4, NV = (NCHK + FM_THREADS - 1) / FM_THREADS;
         float4 qv[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -410,22 +410,22 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_proj(FmProjArgs a) {
             const int idx = tid + k * FM_THREADS;
             if (idx < NCHK) {
                 const int r = idx / (3 * V4), rem = idx % (3 * V4), c = rem / V4, u4 = rem % V4;
-                *reinterpret_cast<float4*>(Vt + (c * FM_TM + r) * LDV + u4 * 4) = qv[k];
+                *reinterpret_cast<float4*>(Vt + (c * TM + r) * LDV + u4 * 4) = qv[k];
             }
         }
     }
     __syncthreads();
     if (a.Ps)
-        fm_block_gemm<4, 2>(X, LDS_, 4, 32, a.Wps, 16, [&](int row, int col, float v) {
+        fm_block_gemm<TM / 16, 2>(X, LDS_, TM / 16, 32, a.Wps, 16, [&](int row, int col, float v) {
             if (row0 + row < a.N) a.Ps[(size_t)(row0 + row) * 256 + col] = v;
         });
     if (a.Asd)
-        fm_block_gemm<4, 2>(X, LDS_, 4, 32, a.Wasd, 16, [&](int row, int col, float v) {
+        fm_block_gemm<TM / 16, 2>(X, LDS_, TM / 16, 32, a.Wasd, 16, [&](int row, int col, float v) {
             if (row0 + row < a.N) a.Asd[(size_t)(row0 + row) * 256 + col] = v;
         });
     if (a.PV)
-        fm_block_gemm<1, 1>(Vt, LDV, 12, V / 8, a.Wpv, a.pv_w / 16, [&](int row, int col, float v) {
-            const int c = row / FM_TM, r = row % FM_TM;
+        fm_block_gemm<1, 1>(Vt, LDV, 3 * TM / 16, V / 8, a.Wpv, a.pv_w / 16, [&](int row, int col, float v) {
+            const int c = row / TM, r = row % TM;
             if (row0 + r < a.N) a.PV[((size_t)(row0 + r) * 3 + c) * a.pv_w + col] = v;
         });
 }

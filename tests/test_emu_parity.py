@@ -399,3 +399,19 @@ def test_error_tracks_the_reference_rounding_sensitivity_on_emulation(emu_lib):
     bad = {k: (v, sens[k]) for k, v in errs.items() if k in sens and not v <= max(5e-5, 8 * sens[k])}
     assert not bad, bad
     assert all(torch.isfinite(v).all() for v in out.values())
+
+
+@pytest.mark.parametrize('small', ['0', '1'])
+def test_mlp_tile_sizes_on_emulation(emu_lib, monkeypatch, small):
+    """The node- / pair-side MLP kernels (self-conditioning layers, output heads) exist with 64-row tiles (throughput) and 16-row tiles
+    (small batches, chosen automatically): both against the oracle on the same batch, paired and separate launches."""
+    from flowmol_amd.engine import Engine
+    monkeypatch.setenv('FM_MLP_SMALL_TILES', small)
+    for pair in ('0', '1'):
+        monkeypatch.setenv('FM_PAIR_MLPS', pair)
+        cfg = presets.flowmol3()
+        sd = weights.synth_state_dict(cfg, 0)
+        eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+        errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor([5, 18, 2, 1]), 0.5, True, taps=False)
+        bad = {k: v for k, v in errs.items() if not v < 1e-5}
+        assert not bad, (small, pair, bad)
