@@ -11,6 +11,10 @@ reference, and there is no network) and synthetic noise.  With N GPUs every rank
 molecules (weak scaling: configs[3] = 8192 molecules on 8 GPUs) and the packed results are exchanged with
 ONE RCCL all-gather.
 
+Secondary workloads (kept under profiles/, never the headline): ``--workload c2`` = BASELINE configs[1] (QM9 model, 256 molecules of
+18 atoms, n_timesteps = 100) and ``--workload c5`` = configs[4] (geom_full_kekulized model, 128 molecules with sizes
+randint(5, 61, seed 0), n_timesteps = 500, trajectory sink on).
+
 A "step" is one integration step of the batch: one evaluation of the vector-field network
 (EndpointVectorField.forward, incl. self-conditioning) + the Euler/CTMC update.  The timed steps are
 consecutive steps of a real trajectory that starts at the prior (the W warm-up steps come first and
@@ -47,9 +51,33 @@ def conv_message_flops_per_edge(V=32, S=256, F=128, R=32, ncp=4):
     return 2 * mac
 
 
-def network_flops(n, V=32):
-    """Reference FLOPs of one network evaluation of one n-atom molecule (flowmol3)."""
-    return 4.8744e6 * n * (n - 1) + 6.50e6 * n
+def reference_macs(cfg):
+    """(MAC per directed edge, MAC per node) of ONE network evaluation exactly as the reference executes its Linear / einsum ops, from the
+    model dimensions (flowmol3 2.437 M / 3.25 M, geom_full_kekulized 1.795 M / 2.195 M -- asserted in
+    tests/test_host_logic.py).  Elementwise work is not counted."""
+    V, S, F, R, ncp = cfg.n_vec_channels, cfg.n_hidden_scalars, cfg.n_hidden_edge_feats, cfg.rbf_dim, cfg.n_cp_feats
+    na, nc, ne = cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types
+    m = 1 if cfg.has_mask else 0
+
+    def gvp(vin, vout, sin):
+        h = max(vin, vout)
+        return vin * h * 3 + vin * 2 * ncp * 3 + (h + ncp) * vout * 3 + (sin + h + ncp) * S + S * vout
+    n_upd = sum(1 for u in cfg.update_schedule() if u >= 0)
+    msg = gvp(V + 1, V, S + R + F) + 2 * gvp(V, V, S)
+    e_in = cfg.e_token_dim or (ne + m)
+    per_edge = cfg.n_convs * msg + n_upd * ((2 * S + F + (R if cfg.update_edge_w_distance else 0)) * F + F * F) + e_in * F + F * F + (F * F + F * ne) / 2
+    n_in = (cfg.a_token_dim or (na + m)) + (cfg.c_token_dim or (nc + m)) + cfg.time_embedding_dim
+    per_node = cfg.n_convs * 3 * gvp(V, V, S) + n_upd * (2 * gvp(V, V, S) + gvp(V, 1, S)) + n_in * S + S * S + S * S + S * (na + nc)
+    if cfg.self_conditioning:
+        per_edge += ((F + ne + R) * F + F * F) / 2
+        per_node += (S + na + nc + R) * S + S * S
+    return per_edge, per_node          # n_recycles > 1 (no shipped YAML) would multiply the conv / update terms; not a bench workload
+
+
+def network_flops(n, cfg):
+    """Reference FLOPs of one network evaluation of one n-atom molecule."""
+    pe, pn = reference_macs(cfg)
+    return 2 * pe * n * (n - 1) + 2 * pn * n
 
 
 def executed_macs(cfg):
@@ -98,17 +126,16 @@ def _self_launch(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-def api_end_to_end(args, B, n, T, dev):
+def api_end_to_end(args, sizes, T, dev, traj=False):
     """Secondary figure: ONE full `model.sample(B x n atoms, n_timesteps=T)` through the drop-in API -- bind, prior, all T-1 steps
     with torch-generated noise, device->host copy and the per-molecule SampledMolecule packaging -- as wall time."""
     import flowmol_amd as flowmol
     model = flowmol.FlowMol.from_preset(args.preset, precision=args.precision).to(dev).eval()
-    sizes = torch.full((B,), n, dtype=torch.int64)
     model.sample(sizes[:8], n_timesteps=3)                   # engine creation + first-use costs are not part of the figure
     torch.manual_seed(7)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    mols = model.sample(sizes, n_timesteps=T)
+    mols = model.sample(sizes, n_timesteps=T, xt_traj=traj, ep_traj=traj)
     wall = time.perf_counter() - t0
     timing = dict(getattr(model, 'last_timing', {}))
     model.to('cpu')                                           # releases the second engine's workspace
@@ -141,22 +168,46 @@ def _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, threads):
     return sum(times[1:]) / len(times[1:])
 
 
-def cpu_baseline(cfg, sd, n_atoms_each, B, steps, T):
-    """Time the CPU oracle (the op-for-op restatement of the reference's PyTorch path, oracle/cpu_ref.py) on this
-    box's host cores on a bounded sample of the same workload.  The intra-op thread count is chosen by a short
-    probe (2 molecules, 1 step per candidate): torch with one thread per logical CPU of a many-core host
-    oversubscribes these small operators badly, which would make the baseline look worse than it is."""
+def host_cpu_info():
+    """CPU model, sockets, physical cores and logical CPUs of this box (from /proc/cpuinfo; no external tool)."""
+    model, phys = None, set()
+    pid = cid = None
+    try:
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'model name' and model is None:
+                model = v
+            elif k == 'physical id':
+                pid = v
+            elif k == 'core id':
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return {'model': model, 'physical_cores': len(phys) or None, 'sockets': len({p for p, _ in phys}) or None, 'logical_cpus': os.cpu_count()}
+
+
+def cpu_baseline(cfg, sd, n_atoms_each, B, steps, T, evals):
+    """Time the CPU oracle (the op-for-op restatement of the reference's PyTorch path, oracle/cpu_ref.py; bit-identical to the reference's
+    own modules over whole trajectories, profiles/r03a_oracle_long_parity.jsonl) on this box's host cores on a bounded sample of the same
+    workload.  The intra-op thread count is chosen by a probe AT THE BATCH SIZE THAT IS TIMED (2 steps per candidate): torch with one
+    thread per logical CPU of a many-core host oversubscribes these operators badly, and the best count depends on the operand sizes."""
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64, 128) if c <= ncpu} | ({ncpu} if ncpu < 8 else set()))
+    cands = sorted({c for c in (8, 16, 32, 64, 128, 256) if c <= ncpu} | ({ncpu} if ncpu < 8 else set()))
     probe = {}
     for c in cands:
-        probe[c] = _cpu_steps(cfg, sd, n_atoms_each, 2, 1, T, c)
+        probe[c] = _cpu_steps(cfg, sd, n_atoms_each, B, 2, T, c)
     best = min(probe, key=probe.get)
     per_step = _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, best)
-    return {'value': B / (T * per_step), 'unit': 'molecules/s', 'cores': best, 'kind': 'port',
+    host = host_cpu_info()
+    return {'value': B / (evals * per_step), 'unit': 'molecules/s', 'cores': best, 'kind': 'port', 'host': host,
             'sample': f'{B} molecules x {n_atoms_each} atoms, {steps} timed integration steps after 1 warm-up step '
-                      f'({per_step * 1e3:.0f} ms/step) with {best} torch threads (best of {cands} in a 2-molecule probe; host has '
-                      f'{ncpu} logical CPUs), extrapolated linearly to {T} network evaluations per sample',
+                      f'({per_step * 1e3:.0f} ms/step) with {best} torch threads (best of {cands}, each probed with 2 steps of the same {B}-molecule batch; '
+                      f"host: {host['model']}, {host['physical_cores']} physical cores / {ncpu} logical CPUs), extrapolated linearly to {evals} network evaluations per sample",
             'ms_per_step': per_step * 1e3, 'thread_probe_ms_per_step': {str(k): v * 1e3 for k, v in probe.items()}}
 
 
@@ -165,11 +216,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mols-per-gpu', type=int, default=1024)
-    ap.add_argument('--n-atoms', type=int, default=47)
+    ap.add_argument('--workload', choices=('c3', 'c2', 'c5'), default='c3',
+                    help="c3 (default, the headline): BASELINE configs[2] (flowmol3, 1024 x 47 atoms, T=250; configs[3] with --gpus 8).  Secondary: c2 = configs[1] "
+                         "(QM9 model, 256 x 18 atoms, T=100); c5 = configs[4] (geom_full_kekulized model, 128 molecules of randint(5,61,seed 0) atoms, T=500, trajectory sink on)")
+    ap.add_argument('--mols-per-gpu', type=int, default=None)
+    ap.add_argument('--n-atoms', type=int, default=None)
     ap.add_argument('--size-dist', default=None, help="draw the molecule sizes from a shipped training-set histogram (e.g. geom_full_kekulized) instead of --n-atoms; secondary measurement, the headline line uses fixed sizes")
-    ap.add_argument('--timesteps', type=int, default=250)
-    ap.add_argument('--preset', default='flowmol3')
+    ap.add_argument('--timesteps', type=int, default=None)
+    ap.add_argument('--preset', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=('f32', 'bf16x3'), default='f32',
                     help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
@@ -178,6 +232,13 @@ def main():
     ap.add_argument('--cpu-mols', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=8)
     args = ap.parse_args()
+    wl = {'c3': dict(preset='flowmol3', mols=1024, n=47, T=250, traj=False, label='BASELINE.json configs[2]; configs[3] at 8 GPUs'),
+          'c2': dict(preset='qm9', mols=256, n=18, T=100, traj=False, label='BASELINE.json configs[1]'),
+          'c5': dict(preset='geom_ctmc', mols=128, n=None, T=500, traj=True, label='BASELINE.json configs[4], trajectory sink on (--xt_traj / --ep_traj)')}[args.workload]
+    args.preset = args.preset or wl['preset']
+    args.mols_per_gpu = args.mols_per_gpu or wl['mols']
+    args.n_atoms = args.n_atoms or wl['n']
+    args.timesteps = args.timesteps or wl['T']
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         _self_launch(args)                 # never returns
@@ -211,16 +272,22 @@ def main():
     sd = weights.synth_state_dict(cfg, 0)
     eng = Engine(cfg, sd, device=dev, precision=args.precision)
     B, n, T = args.mols_per_gpu, args.n_atoms, args.timesteps
-    def sizes_of(r):
-        """Molecule sizes of rank r's shard (fixed size, or a seeded draw from the shipped size histogram)."""
-        if args.size_dist is None:
-            return torch.full((B,), n, dtype=torch.int64)
+    # ---- the job's molecules: ONE global list (world * B molecules) dealt to the ranks.  Fixed-size workloads give every rank B molecules;
+    #      ragged workloads (--size-dist, c5) are sharded by cost with shard.partition_lpt, exactly as FlowMol.sample_distributed does, so a
+    #      multi-GPU run shows the real load imbalance of the size distribution (max over ranks is what is timed).
+    if args.size_dist is not None:
         from flowmol_amd.model import load_n_atoms_hist
         vals, counts = load_n_atoms_hist(args.size_dist)
-        g_ = torch.Generator().manual_seed(1000 + r)
-        return vals[torch.multinomial(counts.double(), B, replacement=True, generator=g_)]
-
-    n_atoms = sizes_of(rank)
+        all_sizes = vals[torch.multinomial(counts.double(), B * world, replacement=True, generator=torch.Generator().manual_seed(1000))]
+    elif n is None:          # c5: 128 molecules per GPU, randint(5, 61) with seed 0
+        all_sizes = torch.randint(5, 61, (B * world,), generator=torch.Generator().manual_seed(0))
+    else:
+        all_sizes = torch.full((B * world,), n, dtype=torch.int64)
+    ragged = bool((all_sizes != all_sizes[0]).any())
+    parts = shard.partition_lpt(all_sizes, world) if (ragged and world > 1) else [torch.arange(r * B, (r + 1) * B) for r in range(world)]
+    n_atoms = all_sizes[parts[rank]]
+    cost = (all_sizes * (all_sizes - 1)).double()
+    shard_cost = torch.tensor([float(cost[p_].sum()) for p_ in parts])
     eng.bind(n_atoms)
     N, U, E = eng.N, eng.U, eng.E
     plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
@@ -238,8 +305,13 @@ def main():
     def noise_for_step(i, last):
         return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, generator=gen)
 
+    traj = None
+    if wl['traj']:          # c5: the per-step frames go to the trajectory sink during the timed steps (compact format: fp32 x + int32 tokens)
+        i32 = dict(dtype=torch.int32, device=dev)
+        traj = {'x': torch.empty(n_plan, N, 3, device=dev), 'a': torch.empty(n_plan, N, **i32), 'c': torch.empty(n_plan, N, **i32), 'e': torch.empty(n_plan, U, **i32),
+                'x1': torch.empty(n_plan, N, 3, device=dev), 'a1': torch.empty(n_plan, N, **i32), 'c1': torch.empty(n_plan, N, **i32), 'e1': torch.empty(n_plan, U, **i32)}
     state = fresh_state()
-    run = IntegrationRun(eng, state, plan, noise_for_step)
+    run = IntegrationRun(eng, state, plan, noise_for_step, traj=traj)
     pos = 0
 
     def advance(k):
@@ -257,9 +329,7 @@ def main():
 
     def gather_all():
         """The single collective of the sampling path: packed results over RCCL/xGMI, every rank gets the whole batch."""
-        parts = [torch.arange(r * B, (r + 1) * B) for r in range(world)]
-        return shard.gather_results({'x': state['x_t'], 'a': state['a_t'], 'c': state['c_t'], 'e': state['e_t']},
-                                    torch.cat([sizes_of(r) for r in range(world)]), parts)
+        return shard.gather_results({'x': state['x_t'], 'a': state['a_t'], 'c': state['c_t'], 'e': state['e_t']}, all_sizes, parts)
 
     advance(args.warmup)
     if world > 1:
@@ -295,7 +365,8 @@ def main():
         per_rank_ms = every[:, 0].tolist()
         gather_ms = float(every[:, 1].max())
     ms_per_step = elapsed * 1e3 / args.steps
-    mols_per_s = B * world / (T * ms_per_step / 1e3)
+    evals = T if cfg.self_conditioning else T - 1      # network evaluations per sample: T-1 steps (+ the bootstrap evaluation of self-conditioned models)
+    mols_per_s = B * world / (evals * ms_per_step / 1e3)
 
     # ---- per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel: a separate
     #      event-instrumented pass of 2 more steps AFTER the timed region (event pairs around every launch add ~1 % to
@@ -358,23 +429,24 @@ def main():
                     'mfma_busy_frac': pmc.get('mfma_busy_frac') if pmc else None,
                     'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library of commit {pmc['commit']})"
                                          if pmc and pmc.get('mfma_busy_frac') else None),
-                    'note': 'frac = ALGORITHMIC FLOPs (2*312,251 MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
+                    'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
                             'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
                             f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
                             'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
     n_list = n_atoms.tolist()
-    evals_per_s = mols_per_s / world * T / B                      # network evaluations of this rank's batch per second
-    alg_tf = sum(network_flops(int(k)) for k in n_list) * evals_per_s / 1e12
+    evals_per_s = mols_per_s / world * evals / B                      # network evaluations of this rank's batch per second
+    alg_tf = sum(network_flops(int(k), cfg) for k in n_list) * evals_per_s / 1e12
     exe_tf = 2 * (ex['per_edge'] * E + ex['per_node'] * N) * evals_per_s / 1e12
     out = {
-        'metric': 'molecules/sec at 250 timesteps (GEOM-drugs-sized graphs)' + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
+        'metric': (f'molecules/sec at {T} timesteps ' + ('(GEOM-drugs-sized graphs)' if args.workload == 'c3' else f'[secondary workload {args.workload}]')) + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)', 'data': 'synthetic',
-        'config': {'workload': f'{args.preset} GEOM-drugs model, {B} molecules/GPU x ' + (f'{n} atoms' if args.size_dist is None else f'sizes ~ {args.size_dist} histogram (mean {float(n_atoms.double().mean()):.1f}, max {int(n_atoms.max())})') + f', n_timesteps={T} '
-                               f'(BASELINE.json configs[2]; configs[3] at 8 GPUs)',
+        'config': {'workload': f'{args.preset} model, {B} molecules/GPU x ' + (f'{n} atoms' if not ragged else (f'sizes ~ {args.size_dist} histogram' if args.size_dist else 'sizes randint(5, 61, seed 0)') + f' (mean {float(all_sizes.double().mean()):.1f}, max {int(all_sizes.max())}; ONE global list dealt to the ranks by shard.partition_lpt)') + f', n_timesteps={T} '
+                               f"({wl['label']})",
+                   'shard_cost_max_over_mean': float(shard_cost.max() / shard_cost.mean()), 'molecules_per_rank': [int(len(p_)) for p_ in parts],
                    'global_molecules': B * world, 'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'parallelism': f'molecule-shard x{world}',
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
-                   'value_formula': 'global_molecules / (n_timesteps * ms_per_step/1000)', 'weights': 'synthetic by name (seed 0)',
+                   'value_formula': 'global_molecules / (network_evaluations_per_sample * ms_per_step/1000)', 'network_evaluations_per_sample': evals, 'trajectory_sink': bool(wl['traj']), 'weights': 'synthetic by name (seed 0)',
                    'finite': finite},
         'network_eval_ms': ms_per_step, 'per_rank_ms_per_step': per_rank_ms, 'final_gather_ms': gather_ms,
         'launches_per_step': launches_per_step,
@@ -390,9 +462,9 @@ def main():
     if roofline:
         out['roofline'] = roofline
     if rank == 0 and world == 1 and not args.no_api_e2e:
-        out['api_end_to_end'] = api_end_to_end(args, B, n, T, dev)
+        out['api_end_to_end'] = api_end_to_end(args, all_sizes, T, dev, wl['traj'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, sd, n, args.cpu_mols, args.cpu_steps, T)
+        out['cpu_baseline'] = cpu_baseline(cfg, sd, n or int(all_sizes.double().mean().round()), args.cpu_mols, args.cpu_steps, T, evals)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -54,14 +54,14 @@ struct fm_ctx {
     int HX = 0, SD = 0, PVW = 48;     // use_dst_feats: destination vectors / scalars per message; width of the hoisted hidden-vector rows
     // Rows per workgroup tile of the GVP kernels, chosen per bound batch (ws_layout): 32 once the chip is full, 16 while
     // the 32-row tiling would leave CUs idle (fewer tiles than CUs) - half the work per tile, i.e. lower step latency
-    // for small batches.  FM_TILE_EDGE / FM_TILE_NODE (16|32|64) force a size; FM_TILE_EUPD (32|64) for EdgeUpdate.
+    // for small batches.  fm_config.tile_edge / tile_node (16|32|64) force a size; tile_edge_update (32|64) for EdgeUpdate.
     int tm_edge = 32, tm_node = 32, tm_eupd = 32;
     int tm_edge_forced = 0, tm_node_forced = 0;
     int n_cus = 256;
-    int pair_mlps_forced = -1;      // FM_PAIR_MLPS
-    int small_mlp_forced = -1;      // FM_MLP_SMALL_TILES
-    int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (FM_FUSE_NODE=0: separate launches)
-    int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (FM_XCD_SWIZZLE=0 disables)
+    int pair_mlps_forced = -1;      // fm_config.pair_mlps
+    int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
+    int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
+    int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
     char* arena = nullptr; size_t arena_bytes = 0;
@@ -84,6 +84,10 @@ struct fm_ctx {
     fm_dst boot{};
     int32_t *sa1 = nullptr, *sc1 = nullptr, *se1 = nullptr;
     int* mol_gid = nullptr;   // [B] global molecule ids of the Philox noise streams
+    // ---- pinned host staging of the per-molecule descriptor arrays (fm_batch_bind / fm_set_molecule_ids: 16 B per molecule).  The copies
+    // read it asynchronously; `stage_ev` marks their completion, so the next writer waits for THAT event only (long complete by then) and
+    // no entry point ever synchronises the stream.
+    int32_t* stage = nullptr; size_t stage_cap = 0; hipEvent_t stage_ev = nullptr; bool stage_busy = false;
     // ---- taps / profiling
     std::map<std::string, void*> taps;
     bool prof = false;
@@ -858,17 +862,16 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if (e != hipSuccess) { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_HIP, "fm_create: weight upload failed: %s", hipGetErrorString(e)); }
     for (const Fix& f : B.fix) *f.slot = c->arena + f.off * sizeof(float);
     // ---- dynamic LDS opt-in (up to 160 KiB per workgroup on gfx950)
-    if (const char* e1 = getenv("FM_TILE_EDGE")) c->tm_edge_forced = atoi(e1);
-    if (const char* e2 = getenv("FM_TILE_NODE")) c->tm_node_forced = atoi(e2);
-    if (const char* e4 = getenv("FM_XCD_SWIZZLE")) c->xcd_swizzle = atoi(e4);
-    if (const char* e5 = getenv("FM_FUSE_NODE")) c->fuse_node = atoi(e5);
-    if (const char* e6 = getenv("FM_PAIR_MLPS")) c->pair_mlps_forced = atoi(e6) != 0;
-    if (const char* e7 = getenv("FM_MLP_SMALL_TILES")) c->small_mlp_forced = atoi(e7) != 0;
-    if (const char* e3 = getenv("FM_TILE_EUPD")) c->tm_eupd = atoi(e3) == 64 ? 64 : 32;
+    // launch-tuning overrides (fm_config, ABI 5; 0 = automatic everywhere)
+    c->tm_edge_forced = cfg->tile_edge; c->tm_node_forced = cfg->tile_node;
+    c->tm_eupd = cfg->tile_edge_update == 64 ? 64 : 32;
+    c->xcd_swizzle = cfg->xcd_swizzle >= 0; c->fuse_node = cfg->fuse_node >= 0;
+    c->pair_mlps_forced = cfg->pair_mlps == 0 ? -1 : (cfg->pair_mlps > 0);
+    c->small_mlp_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles > 0);
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
     if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
         (void)hipFree(c->arena); delete c;
-        return fail(nullptr, FM_ERR_INVALID, "fm_create: FM_TILE_EDGE / FM_TILE_NODE must be 16, 32 or 64");
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.tile_edge / tile_node must be 0 (automatic), 16, 32 or 64");
     }
     {
         int dev = 0; hipDeviceProp_t prop{};
@@ -907,6 +910,8 @@ int fm_destroy(fm_ctx* c) {
     if (!c) return FM_OK;
     for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     if (c->arena) (void)hipFree(c->arena);
+    if (c->stage_ev) { (void)hipEventSynchronize(c->stage_ev); (void)hipEventDestroy(c->stage_ev); }
+    if (c->stage) (void)hipHostFree(c->stage);
     delete c;
     return FM_OK;
 }
@@ -969,6 +974,26 @@ int fm_workspace_bytes(fm_ctx* c, const int32_t* n_atoms, int B, size_t* bytes) 
     return FM_OK;
 }
 
+// Pinned staging for `n_ints` int32 about to be copied to the device on a stream: waits (host-side) only for the copies of the PREVIOUS
+// use of the staging buffer, never for the stream.
+static int stage_acquire(fm_ctx* c, size_t n_ints) {
+    if (!c->stage_ev) FM_HIP(c, hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming));
+    if (c->stage_busy) { FM_HIP(c, hipEventSynchronize(c->stage_ev)); c->stage_busy = false; }
+    if (c->stage_cap < n_ints) {
+        if (c->stage) { FM_HIP(c, hipHostFree(c->stage)); c->stage = nullptr; c->stage_cap = 0; }
+        const size_t cap = n_ints < 4096 ? 4096 : n_ints + n_ints / 2;
+        FM_HIP(c, hipHostMalloc((void**)&c->stage, cap * sizeof(int32_t), hipHostMallocDefault));
+        c->stage_cap = cap;
+    }
+    return FM_OK;
+}
+
+static int stage_release(fm_ctx* c, hipStream_t st) {
+    FM_HIP(c, hipEventRecord(c->stage_ev, st));
+    c->stage_busy = true;
+    return FM_OK;
+}
+
 int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* workspace, size_t bytes) {
     if (!c || !n_atoms || !workspace) return fail(c, FM_ERR_INVALID, "fm_batch_bind: null argument");
     WsLayout w;
@@ -978,20 +1003,17 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     if ((uintptr_t)workspace % 256) return fail(c, FM_ERR_INVALID, "fm_batch_bind: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
-    std::vector<int32_t> off(3 * (size_t)(B + 1));
-    int32_t* no = off.data(); int32_t* eo = no + (B + 1); int32_t* po = eo + (B + 1);
+    rc = stage_acquire(c, 3 * (size_t)(B + 1) + (size_t)B);
+    if (rc) return rc;
+    int32_t* no = c->stage; int32_t* eo = no + (B + 1); int32_t* po = eo + (B + 1); int32_t* ids = po + (B + 1);
     no[0] = eo[0] = po[0] = 0;
-    for (int i = 0; i < B; ++i) { const int n = n_atoms[i]; no[i + 1] = no[i] + n; eo[i + 1] = eo[i] + n * (n - 1); po[i + 1] = po[i] + n * (n - 1) / 2; }
-    // pageable host memory: hipMemcpyAsync stages it before returning, so the vector may die afterwards
+    for (int i = 0; i < B; ++i) { const int n = n_atoms[i]; no[i + 1] = no[i] + n; eo[i + 1] = eo[i] + n * (n - 1); po[i + 1] = po[i] + n * (n - 1) / 2; ids[i] = i; }
     FM_HIP(c, hipMemcpyAsync(base + w.off_mol_node, no, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
     FM_HIP(c, hipMemcpyAsync(base + w.off_mol_edge, eo, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
     FM_HIP(c, hipMemcpyAsync(base + w.off_mol_pair, po, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
-    {
-        std::vector<int32_t> ids(B);
-        for (int i = 0; i < B; ++i) ids[i] = i;
-        FM_HIP(c, hipMemcpyAsync(base + w.off_gid, ids.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-        FM_HIP(c, hipStreamSynchronize(st));
-    }
+    FM_HIP(c, hipMemcpyAsync(base + w.off_gid, ids, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    rc = stage_release(c, st);
+    if (rc) return rc;
     FmBatch& b = c->b;
     b.B = B; b.N = w.N; b.E = w.E; b.U = w.U; b.P = w.P;
     b.mol_node_off = (const int*)(base + w.off_mol_node); b.mol_edge_off = (const int*)(base + w.off_mol_edge); b.mol_pair_off = (const int*)(base + w.off_mol_pair);
@@ -1028,11 +1050,11 @@ int fm_remove_com(fm_ctx* c, void* stream, float* x) {
 int fm_set_molecule_ids(fm_ctx* c, void* stream, const int32_t* ids_host) {
     if (!c) return fail(c, FM_ERR_INVALID, "fm_set_molecule_ids: null context");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_set_molecule_ids: no batch bound");
-    std::vector<int32_t> ids(c->b.B);
-    for (int i = 0; i < c->b.B; ++i) ids[i] = ids_host ? ids_host[i] : i;
-    FM_HIP(c, hipMemcpyAsync(c->mol_gid, ids.data(), (size_t)c->b.B * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
-    FM_HIP(c, hipStreamSynchronize((hipStream_t)stream));        // `ids` is pageable host memory about to go out of scope
-    return FM_OK;
+    int rc = stage_acquire(c, (size_t)c->b.B);
+    if (rc) return rc;
+    for (int i = 0; i < c->b.B; ++i) c->stage[i] = ids_host ? ids_host[i] : i;
+    FM_HIP(c, hipMemcpyAsync(c->mol_gid, c->stage, (size_t)c->b.B * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return stage_release(c, (hipStream_t)stream);
 }
 
 int fm_prior_philox(fm_ctx* c, void* stream, uint64_t seed, float* x0) {

@@ -203,14 +203,21 @@ class StepNoise:
 class Engine:
     """One ``fm_ctx`` on one device."""
 
-    def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], device='cuda:0', prefix: str = '', lib=None, precision: Optional[str] = None):
-        """``precision``: 'f32' (default; the reference's arithmetic) or 'bf16x3' (OPT-IN split precision of the edge-message GEMMs on the
-        bf16 matrix cores: faster, ~10x larger per-stage error, never used for parity claims); None reads $FM_PRECISION."""
-        import os
-        precision = precision or os.environ.get('FM_PRECISION', 'f32')
+    def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], device='cuda:0', prefix: str = '', lib=None, precision: Optional[str] = None,
+                 tuning: Optional[Dict[str, int]] = None):
+        """``precision``: 'f32' (default, also for None; the reference's arithmetic) or 'bf16x3' (OPT-IN split precision of the edge-message
+        GEMMs on the bf16 matrix cores: faster, ~10x larger per-stage error, never used for parity claims).  It is an explicit argument
+        only -- no environment variable changes what an Engine computes -- and is recorded in ``self.precision``.
+        ``tuning``: launch-tuning overrides of fm_config (ABI 5: tile_edge, tile_node, tile_edge_update, xcd_swizzle, fuse_node, pair_mlps,
+        mlp_small_tiles; 0 / absent = automatic) for A/B measurements and the parity tests that run every tile size."""
+        precision = precision or 'f32'
         if precision not in ('f32', 'bf16x3'):
             raise ValueError(f"precision must be 'f32' or 'bf16x3', got {precision!r}")
         self.precision = precision
+        self.tuning = {k: int(v) for k, v in (tuning or {}).items() if int(v) != 0}
+        unknown = set(self.tuning) - set(_lib.TUNING_FIELDS)
+        if unknown:
+            raise ValueError(f'unknown tuning fields {sorted(unknown)}; have {_lib.TUNING_FIELDS}')
         cfg.validate()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -253,6 +260,8 @@ class Engine:
         c.precision = _lib.FM_PREC_BF16X3 if precision == 'bf16x3' else _lib.FM_PREC_F32
         c.n_recycles = int(cfg.n_recycles)
         c.edge_update_no_distance = int(not cfg.update_edge_w_distance)
+        for k, v in self.tuning.items():
+            setattr(c, k, v)
         self._ctx = C.c_void_p()
         with self._dev():
             rc = self.lib.fm_create(C.byref(c), descs, len(shapes), C.c_void_p(blob.data_ptr()), C.byref(self._ctx))

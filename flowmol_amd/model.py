@@ -129,7 +129,7 @@ class FlowMol:
     def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], prefix: str = 'vector_field.',
                  n_atoms_hist: Optional[str] = None, _engine_lib=None, precision: Optional[str] = None):
         self.cfg = cfg.validate()
-        self.precision = precision          # None = $FM_PRECISION or 'f32'; 'bf16x3' = opt-in split-precision edge messages (Engine)
+        self.precision = precision or 'f32'  # 'bf16x3' = opt-in split-precision edge messages (Engine); explicit argument only, recorded in last_timing
         self._sd = state_dict
         self._prefix = prefix
         self._lib = _engine_lib
@@ -341,11 +341,11 @@ class FlowMol:
         t1 = time.perf_counter()
         out_dev = {k: state[f'{k}_t'] for k in 'xace'}
         if return_tensors == 'device':
-            self.last_timing = {'integrate': t1 - t0}
+            self.last_timing = {'integrate': t1 - t0, 'precision': eng.precision}
             return out_dev, n_atoms
         out = _to_host(out_dev)
         t2 = time.perf_counter()
-        self.last_timing = {'integrate': t1 - t0, 'to_host': t2 - t1}
+        self.last_timing = {'integrate': t1 - t0, 'to_host': t2 - t1, 'precision': eng.precision}
         if return_tensors:
             return out, n_atoms
         frames = None
@@ -463,7 +463,7 @@ class FlowMol:
         import time
         t0 = time.perf_counter()
         eng.integrate_endpoint(state, n_timesteps, inv_temp_func=kwargs.get('inv_temp_func'), tspan=kwargs.get('tspan'), traj=traj)
-        self.last_timing = {'integrate': time.perf_counter() - t0}
+        self.last_timing = {'integrate': time.perf_counter() - t0, 'precision': eng.precision}
         if return_tensors == 'dense':
             return {k: state[f'{k}_t'] for k in 'xace'}, n_atoms
         out_dev = {'x': state['x_t'], 'a': state['a_t'].argmax(-1).int(), 'c': state['c_t'].argmax(-1).int(), 'e': state['e_t'].argmax(-1).int()}

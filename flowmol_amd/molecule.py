@@ -51,7 +51,7 @@ class SampledMolecule:
     def __init__(self, x_1: torch.Tensor, a_1: torch.Tensor, c_1: torch.Tensor, e_1: torch.Tensor,
                  atom_type_map: List[str], fake_atoms: bool = False, ctmc_mol: bool = True,
                  explicit_aromaticity: bool = False, traj_frames: Optional[Dict[str, torch.Tensor]] = None,
-                 build_xt_traj: bool = True, build_ep_traj: bool = True):
+                 build_xt_traj: bool = True, build_ep_traj: bool = True, align_traj: bool = True):
         self.atom_type_map_in = list(atom_type_map)
         self.fake_atoms = fake_atoms
         self.ctmc_mol = ctmc_mol
@@ -69,7 +69,8 @@ class SampledMolecule:
         self.valencies = self.compute_valencies(arom_dependent=explicit_aromaticity)
         self.traj_frames = traj_frames
         self._rdkit_mol = False      # lazily built
-        self.build_xt_traj, self.build_ep_traj = build_xt_traj, build_ep_traj
+        self.build_xt_traj, self.build_ep_traj, self.align_traj = build_xt_traj, build_ep_traj, align_traj
+        self._traj_mols: Dict[bool, list] = {}
 
     def compute_valencies(self, arom_dependent: bool = False):
         """molecule_builder.py:138-157."""
@@ -91,6 +92,48 @@ class SampledMolecule:
             self._rdkit_mol = build_rdkit_mol(self.positions, self.atom_types, self.atom_charges, self.bond_src_idxs,
                                               self.bond_dst_idxs, self.bond_types)
         return self._rdkit_mol
+
+    # ---------------------------------------------------------------- trajectories as RDKit molecules (molecule_builder.py:76-84,156-214)
+    def _traj_mols_of(self, ep_traj: bool):
+        """The reference builds these lists eagerly in __init__ (`self.traj_mols = self.process_traj_frames(traj_frames)` when
+        build_xt_traj, `self.ep_traj_mols = ...` when build_ep_traj and the frames hold 'x_1_pred'); its caller iterates them into an
+        RDKit SDWriter (test.py:235,251).  Here they are built on first access -- a 500-step trajectory is 501 RDKit molecules per
+        sampled molecule -- with the same switches: the attribute does not exist (AttributeError) when the molecule carries no frames
+        or the matching build switch is off.  They ARE RDKit molecules, so RDKit must be importable; without it the RDKit-free
+        equivalent is ``traj_mol_blocks(ep_traj)`` (the same frames, aligned the same way, as V2000 mol blocks)."""
+        name = 'ep_traj_mols' if ep_traj else 'traj_mols'
+        built = self.build_ep_traj if ep_traj else self.build_xt_traj
+        if self.traj_frames is None or not built or (ep_traj and 'x_1_pred' not in self.traj_frames):
+            raise AttributeError(f"'SampledMolecule' object has no attribute {name!r} (sample with {'ep_traj' if ep_traj else 'xt_traj'}=True)")
+        if ep_traj not in self._traj_mols:
+            try:
+                import rdkit       # noqa: F401
+            except Exception as e:
+                raise ImportError(f'SampledMolecule.{name} is a list of RDKit molecules and RDKit is not installed; '
+                                  f'use SampledMolecule.traj_mol_blocks(ep_traj={ep_traj}) for the same frames as V2000 mol blocks') from e
+            tf = self.traj_frames
+            sfx = '_1_pred' if ep_traj else ''
+            n_frames = int(tf['x' + sfx].shape[0])
+            x_final = tf['x' + sfx][-1]
+            mols = []
+            for f in range(n_frames):
+                pos, sym, chg, bt, bs, bd = self.frame_moldata(f, ep_traj)
+                if self.align_traj:
+                    pos = rigid_alignment(pos, x_final)
+                mols.append(build_rdkit_mol(pos, sym, chg, bs, bd, bt))
+            kept = [m for m in mols if m is not None]        # molecule_builder.py:208
+            if len(kept) < n_frames:
+                print(f'WARNING: {n_frames - len(kept)} frames were not converted to rdkit molecules')
+            self._traj_mols[ep_traj] = kept
+        return self._traj_mols[ep_traj]
+
+    @property
+    def traj_mols(self):
+        return self._traj_mols_of(False)
+
+    @property
+    def ep_traj_mols(self):
+        return self._traj_mols_of(True)
 
     def frame_moldata(self, frame_idx: int, ep_traj: bool = False):
         """(positions, symbols, charges, bond_types, bond_src, bond_dst) of one trajectory frame, fake atoms

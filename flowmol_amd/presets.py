@@ -3,6 +3,11 @@
 Values only (facts about the model architecture); cited so the judge can check:
   flowmol3   reference configs/flowmol3.yml:52-106
   geom_ctmc  reference configs/configs_dataprocessing/geom_full_kekulized.yaml:38-102
+  geom_arom  reference configs/configs_dataprocessing/geom_full_aromatic.yaml:38-102 and geom_5_aromatic.yaml (same model
+             block; they differ in the dataset only): geom_ctmc with mol_fm.explicit_aromaticity: true -> 5 bond types
+             (none, single, double, triple, aromatic) + mask (flowmol.py:60)
+  flowmol3_arom  flowmol3's vector_field block with explicit_aromaticity (no YAML of it ships; the switch is a constructor
+             argument of the reference's FlowMol, flowmol.py:52): the V=32 / self-conditioned kernels with 5 bond types
   qm9        SURVEY.md §8d: the tree has no QM9 YAML; "QM9 model" = flowmol3's
              vector_field block with atom_map=[C,H,N,O,F] (+ fake atom)
 """
@@ -34,6 +39,22 @@ def geom_ctmc() -> VFConfig:
         self_conditioning=False, stochasticity=10.0, high_confidence_threshold=0.0,
         n_atoms_hist='geom_full_kekulized',
     ).validate()
+
+
+def geom_arom() -> VFConfig:
+    """geom_full_aromatic.yaml / geom_5_aromatic.yaml: the geom_ctmc model with explicit aromaticity (bond token 4 = aromatic, mask = 5)."""
+    cfg = geom_ctmc()
+    cfg.explicit_aromaticity = True
+    cfg.n_bond_types = 5
+    cfg.n_atoms_hist = 'geom_5_aromatic'
+    return cfg.validate()
+
+
+def flowmol3_arom() -> VFConfig:
+    cfg = flowmol3()
+    cfg.explicit_aromaticity = True
+    cfg.n_bond_types = 5
+    return cfg.validate()
 
 
 def qm9() -> VFConfig:
@@ -97,4 +118,4 @@ def arch_variants() -> VFConfig:
     ).validate()
 
 
-PRESETS = {'arch_variants': arch_variants, 'endpoint_small': endpoint_small, 'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}
+PRESETS = {'geom_arom': geom_arom, 'flowmol3_arom': flowmol3_arom, 'arch_variants': arch_variants, 'endpoint_small': endpoint_small, 'dev': dev, 'flowmol3': flowmol3, 'geom_ctmc': geom_ctmc, 'qm9': qm9, 'dev_narrow': dev_narrow}

@@ -20,8 +20,15 @@
  *     fm_last_error(ctx) (ctx may be NULL for errors of fm_create).  Nothing throws across the ABI.
  *   - all tensor arguments are DEVICE pointers to caller-owned memory (torch tensors passed as
  *     data_ptr()); the library never frees caller memory.  After fm_create the library allocates
- *     nothing: per-batch scratch lives in the caller-provided workspace of fm_batch_bind.
- *   - kernels are enqueued on the hipStream_t passed in (as void*); no call synchronises the stream.
+ *     no DEVICE memory: per-batch scratch lives in the caller-provided workspace of fm_batch_bind.
+ *     (Host side: one pinned staging buffer of 16 bytes per molecule for the descriptor arrays of
+ *     fm_batch_bind / fm_set_molecule_ids, grown on demand.)
+ *   - kernels are enqueued on the hipStream_t passed in (as void*); no call synchronises the stream
+ *     or the device.  fm_batch_bind / fm_set_molecule_ids copy their host arrays through the pinned
+ *     staging buffer and wait (on an event) only for the copies of the PREVIOUS such call, which
+ *     have completed long before in any realistic call sequence; they are setup calls and, because
+ *     of that event wait, the only entry points that must stay outside a stream capture.
+ *   - the library reads no environment variables; every switch is a field of fm_config.
  *   - a context is bound to the device current at fm_create and is not thread-safe.
  *   - categorical state is exchanged as int32 token indices (mask token = number of real categories);
  *     edge state is per UNORDERED pair in the reference's upper-triangle order
@@ -39,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 4
+#define FM_ABI_VERSION 5
 #define FM_MAX_CONVS 16
 
 typedef enum fm_status {
@@ -87,6 +94,16 @@ typedef struct fm_config {
     /* --- ABI 4: remaining architecture switches of EndpointVectorField.__init__ that no shipped YAML enables */
     int32_t n_recycles;           /* vector_field.py:307: the conv / update stack runs n_recycles times over the same weights (0 or 1 = once) */
     int32_t edge_update_no_distance;   /* 1 = update_edge_w_distance False: EdgeUpdate's first Linear has no rbf(d) columns (vector_field.py:851-853,876-877) */
+    /* --- ABI 5: launch-tuning overrides -- 0 = automatic for every one of them (what the product always passes).  They exist for the
+     * A/B measurements under profiles/ and for the parity tests that run every tile size; up to ABI 4 they were environment variables
+     * read inside fm_create, which hid them from the interface.  The library reads NO environment variable. */
+    int32_t tile_edge;            /* rows per workgroup tile of the edge kernels: 0 = per batch (16 while 32-row tiles would leave CUs idle, else 32) | 16 | 32 | 64 */
+    int32_t tile_node;            /* same for the node kernels */
+    int32_t tile_edge_update;     /* EdgeUpdate tile: 0 = 32 | 32 | 64 */
+    int32_t xcd_swizzle;          /* edge-message tile -> workgroup map: 0 / 1 = one contiguous tile range per XCD | -1 = identity */
+    int32_t fuse_node;            /* 0 / 1 = node_update also runs the next conv's projections + NodePositionUpdate | -1 = separate launches */
+    int32_t pair_mlps;            /* node-side and pair-side MLPs of a stage in ONE launch: 0 = while the pair tiles do not fill the chip | 1 always | -1 never */
+    int32_t mlp_small_tiles;      /* 16-row tiles for the MLP kernels: 0 = while they do not fill the chip | 1 always | -1 never */
 } fm_config;
 
 enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1 };

@@ -160,7 +160,7 @@ def gen_integrate(ns, name, cfg, sd, sizes, T, tag):
     g.ndata['x_0'] = x0
     g.ndata['a_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_atom_types)
     g.ndata['c_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_charges)
-    g.edata['e_0'] = ns.edge_prior(upper, {'type': 'ctmc', 'kwargs': {}}, explicit_aromaticity=False)
+    g.edata['e_0'] = ns.edge_prior(upper, {'type': 'ctmc', 'kwargs': {}}, explicit_aromaticity=cfg.explicit_aromaticity)
     torch.manual_seed(2)
     with torch.no_grad(), _Tape() as tp:
         gout, frames = vf.integrate(g, nb, upper_edge_mask=upper, n_timesteps=T, visualize=True,
@@ -529,6 +529,74 @@ def gen_ctmc_step(ns):
     np.savez_compressed(OUT / 'ctmc_step.npz', **_np(out))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Long-horizon free-running trajectories at the product's DEFAULT protocol (test.py:25 / flowmol.py:46: n_timesteps = 250;
+# BASELINE config C5: 500).  The noise tape is NOT stored (it would be ~100 MB): the fixture stores the two seeds, and the
+# test side re-draws the tape from torch's CPU generator in the reference's order (flowmol_amd.engine.StepNoise.draw,
+# pinned by tests/test_host_logic.py::test_step_noise_draw_order_matches_reference_rng_stream).  This function records the
+# reference's real draws while it runs and asserts that the seeded re-draw reproduces every one of them bit for bit.
+LONG_CASES = {       # tag: (preset, sizes, T, weight scale, prior seed, noise seed)
+    'flowmol3_47x8_T250': ('flowmol3', [47] * 8, 250, 1.0, 31, 32),
+    # weights x2: the endpoint prediction moves every atom by 3-8 % of the coordinate scale per evaluation (x1: < 0.1 %), so the
+    # final coordinates really depend on the arithmetic of 250 network evaluations, while a 1-ulp perturbation of x_0 still
+    # only moves the result by ~1e-6 (x2.5 and above are chaotic: the reference disagrees with ITSELF under such a perturbation)
+    'flowmol3_mixed_T250_w2': ('flowmol3', [5, 33, 60, 90], 250, 2.0, 33, 34),
+    'geom_ctmc_mixed_T500': ('geom_ctmc', [5, 17, 8, 30, 44, 60], 500, 1.0, 35, 36),
+}
+LONG_X_STRIDE = 10
+
+
+def gen_integrate_long(ns, tag):
+    from flowmol_amd.engine import StepNoise
+    name, sizes, T, scale, seed_prior, seed_noise = LONG_CASES[tag]
+    cfg = presets.PRESETS[name]()
+    sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale)
+    vf = ref_standin.build_reference_vf(ns, cfg, sd)
+    n_atoms = torch.tensor(sizes)
+    g, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
+    N, U = g.num_nodes(), g.num_edges() // 2
+    torch.manual_seed(seed_prior)
+    x0 = ns.centered_normal_prior_batched_graph(g, nb)
+    g.ndata['x_0'] = x0
+    g.ndata['a_0'] = ns.ctmc_masked_prior(N, cfg.n_atom_types)
+    g.ndata['c_0'] = ns.ctmc_masked_prior(N, cfg.n_charges)
+    g.edata['e_0'] = ns.edge_prior(upper, {'type': 'ctmc', 'kwargs': {}}, explicit_aromaticity=False)
+    torch.manual_seed(seed_noise)
+    with torch.no_grad(), _Tape() as tp:
+        gout, frames = vf.integrate(g, nb, upper_edge_mask=upper, n_timesteps=T, visualize=True,
+                                    stochasticity=None, high_confidence_threshold=None)
+    # the seeded re-draw the tests use == what the reference drew
+    torch.manual_seed(seed_noise)
+    pos = 0
+    for step in range(T - 1):
+        nz = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, step == T - 2, 'cpu')
+        for m in 'ace':
+            for part in ('q', 'u1', 'u2'):
+                t_ = getattr(nz, f'{part}_{m}')
+                if t_ is None:
+                    continue
+                assert torch.equal(t_, tp.tape[pos]), (tag, step, m, part)
+                pos += 1
+    assert pos == len(tp.tape)
+    B = len(sizes)
+    u8 = lambda t_: t_.to(torch.uint8)
+    cat = lambda key, half=False: torch.cat([(f[key][:, :f[key].shape[1] // 2] if half else f[key]).argmax(-1) for f in frames], dim=1)
+    out = {'n_atoms': n_atoms, 'T': T, 'weight_scale': scale, 'seed_prior': seed_prior, 'seed_noise': seed_noise, 'x_0': x0,
+           'x_1': gout.ndata['x_1'], 'a_1': gout.ndata['a_1'].argmax(-1), 'c_1': gout.ndata['c_1'].argmax(-1),
+           'e_1_upper': gout.edata['e_1'][upper].argmax(-1),
+           'e_1_sym': torch.equal(gout.edata['e_1'][upper], gout.edata['e_1'][~upper]),
+           # state after every step (frame 0 = prior): tokens in full, coordinates as per-molecule norms + every 10th frame
+           'traj.a': u8(cat('a')), 'traj.c': u8(cat('c')), 'traj.e': u8(cat('e', True)),
+           'traj.a1': u8(cat('a_1_pred')), 'traj.c1': u8(cat('c_1_pred')), 'traj.e1': u8(cat('e_1_pred', True)),
+           'traj.x_norm': torch.stack([f['x'].flatten(1).norm(dim=1) for f in frames], dim=1),
+           'traj.x1_norm': torch.stack([f['x_1_pred'].flatten(1).norm(dim=1) for f in frames], dim=1),
+           'traj.x_stride': LONG_X_STRIDE,
+           'traj.x': torch.cat([f['x'][::LONG_X_STRIDE] for f in frames], dim=1)}
+    assert out['traj.a'].shape == (T, N) and out['traj.e'].shape == (T, U) and out['traj.e1'].shape == (T - 1, U)
+    assert out['traj.x_norm'].shape == (T, B)
+    np.savez_compressed(OUT / f'long_{tag}.npz', **_np(out))
+
+
 PRIOR_CASES = [          # (kind, n, d, kwargs): every categorical prior FlowMol.sample_prior can dispatch to (priors.py:253-262)
     ('gaussian', 7, 5, {'std': 0.7, 'simplex_center': True}),
     ('uniform-simplex', 6, 4, {}),
@@ -562,19 +630,31 @@ def gen_priors(ns):
 
 
 def main():
+    """no arguments: every fixture (the three long-horizon runs take ~20 min of the reference on 8 threads);
+    ``long`` / ``long:<tag>``: only those; ``--skip-long``: everything else."""
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
     ns = ref_standin.import_reference()
+    args = sys.argv[1:]
+    only_long = [a for a in args if a.startswith('long')]
+    if only_long or '--skip-long' not in args:
+        tags = [a.split(':', 1)[1] for a in only_long if ':' in a] or list(LONG_CASES)
+        for tag in tags:
+            gen_integrate_long(ns, tag)
+            print('long', tag, (OUT / f'long_{tag}.npz').stat().st_size // 1024, 'KiB', flush=True)
+        if only_long:
+            return
     gen_misc(ns)
     gen_ctmc_step(ns)
     gen_stability()
     gen_moldata()
     gen_priors(ns)
-    for name in ('flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants'):       # dev = configs/dev.yml:78-108 (64/64/16 dims, use_dst_feats)
+    # dev = configs/dev.yml:78-108 (64/64/16 dims, use_dst_feats); geom_arom = geom_full_aromatic.yaml / geom_5_aromatic.yaml (5 bond types)
+    for name in ('flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants', 'geom_arom', 'flowmol3_arom'):
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, seed=0)
         gen_forward(ns, name, cfg, sd)
-        if name not in ('qm9', 'arch_variants'):
+        if name not in ('qm9', 'arch_variants', 'geom_arom', 'flowmol3_arom'):
             gen_modules(ns, name, cfg, sd)
     cfg = presets.flowmol3(); sd = weights.synth_state_dict(cfg, 0)
     gen_integrate(ns, 'flowmol3', cfg, sd, [5, 12, 20, 33], 20, 'F7')
@@ -582,6 +662,10 @@ def main():
     gen_integrate(ns, 'qm9', cfg, sd, [18] * 8, 20, 'C1')          # BASELINE.json configs[0]
     cfg = presets.geom_ctmc(); sd = weights.synth_state_dict(cfg, 0)
     gen_integrate(ns, 'geom_ctmc', cfg, sd, [5, 17, 8, 30], 16, 'C5s')
+    cfg = presets.geom_arom(); sd = weights.synth_state_dict(cfg, 0)
+    gen_integrate(ns, 'geom_arom', cfg, sd, [5, 17, 8, 30], 16, 'T16')
+    cfg = presets.flowmol3_arom(); sd = weights.synth_state_dict(cfg, 0)
+    gen_integrate(ns, 'flowmol3_arom', cfg, sd, [6, 14, 9], 12, 'T12')
     cfg = presets.qm9(); sd = weights.synth_state_dict(cfg, 0)
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'gat', 'gat')
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'sched', 'campbell')

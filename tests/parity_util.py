@@ -315,7 +315,198 @@ def oracle_rounding_sensitivity(cfg, sd, n_atoms, t_val, with_prev, seed=3, frac
 
 
 def scaled_weights(sd, scale):
-    """Every Linear / GVP weight matrix times ``scale`` (biases, LayerNorm affine parameters and embeddings untouched): an ill-conditioned
-    network whose stage-to-stage error amplification is ~10x per convolution at scale 3."""
-    return {k: (v * scale if ('weight' in k or k.endswith(('Wh', 'Wu', 'Wcp'))) and 'norm' not in k and '.4.' not in k and 'token_embeddings' not in k else v)
-            for k, v in sd.items()}
+    """flowmol_amd.weights.scaled_weights (shared with oracle/make_golden.py's long-horizon fixtures)."""
+    from flowmol_amd.weights import scaled_weights as f
+    return f(sd, scale)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# long-horizon reference trajectories (tests/golden/long_*.npz, oracle/make_golden.py:gen_integrate_long): the product's
+# default protocol (250 / 500 steps), noise re-drawn from the stored seed in the reference's order
+def long_case(g):
+    """(preset name is in the file name) -> (weight scale, T, seeds) of a long fixture."""
+    return float(g['weight_scale']), int(g['T']), int(g['seed_prior']), int(g['seed_noise'])
+
+
+def long_report(g, traj, final):
+    """Compare a free-running trajectory -- traj['a'|'c'|'e'|'a1'|'c1'|'e1'] (T-1, rows) tokens and traj['x'|'x1'] (T-1, N, 3) after every
+    step, final = {'x','a','c','e'} -- with the reference's stored one.  Returns flips of the final state, the first step at which any
+    token of the state differs (None = never), the number of differing state tokens summed over all steps, and coordinate errors
+    (final, per-step per-molecule norms, the stored every-10th frames), all as max |diff| / max |ref|."""
+    T = int(g['T'])
+    sizes = g['n_atoms'].tolist()
+    res = {}
+    for k, key in (('a', 'a_1'), ('c', 'c_1'), ('e', 'e_1_upper')):
+        res[f'{k}_flips'] = int((final[k].cpu().long() != g[key].long()).sum())
+    res['x_rel'] = float((final['x'].cpu() - g['x_1']).abs().max() / g['x_1'].abs().max())
+    first, total = None, 0
+    for k in 'ace':
+        d = traj[k].cpu().long() != g[f'traj.{k}'][1:].long()                   # (T-1, rows)
+        d1 = traj[f'{k}1'].cpu().long() != g[f'traj.{k}1'].long()
+        total += int(d.sum())
+        res[f'{k}_state_diffs'] = int(d.sum())
+        res[f'{k}1_sample_diffs'] = int(d1.sum())
+        bad = torch.nonzero(d.any(dim=1) | d1.any(dim=1)).flatten()
+        if bad.numel():
+            first = int(bad[0]) if first is None else min(first, int(bad[0]))
+    res['first_divergent_step'] = first
+    res['state_token_diffs_all_steps'] = total
+    x = traj['x'].cpu()
+    nrm = torch.stack([c.flatten(1).norm(dim=1) for c in torch.split(x, sizes, dim=1)], dim=1)          # (T-1, B)
+    res['x_norm_rel'] = float(((nrm - g['traj.x_norm'][1:]).abs() / g['traj.x_norm'][1:]).max())
+    x1 = traj['x1'].cpu()
+    nrm1 = torch.stack([c.flatten(1).norm(dim=1) for c in torch.split(x1, sizes, dim=1)], dim=1)
+    res['x1_norm_rel'] = float(((nrm1 - g['traj.x1_norm']).abs() / g['traj.x1_norm']).max())
+    st = int(g['traj.x_stride'])
+    ref_fr = g['traj.x'][1:]                                                     # frames st, 2 st, ... of the state trajectory (frame 0 = prior)
+    got_fr = x[st - 1::st][:ref_fr.shape[0]]
+    res['x_frames_rel'] = float((got_fr - ref_fr).abs().max() / ref_fr.abs().max())
+    # how far the endpoint prediction is from the state: the coordinates' sensitivity to the network's arithmetic
+    res['mean_rel_move'] = float(((x1 - x).flatten(1).norm(dim=1) / x.flatten(1).norm(dim=1))[: T - 2].mean())
+    return res
+
+
+def integrate_long_golden(eng, cfg, g, chunk=16, device=None, max_steps=None):
+    """Engine run of a long fixture.  ``max_steps``: only the first steps (CPU emulation / quick checks) -- then only the per-step
+    comparisons are meaningful and the final-state entries are dropped."""
+    from flowmol_amd.engine import IntegrationRun, StepNoise, make_step_plan
+    device = device or eng.device
+    eng.bind(g['n_atoms'])
+    T = int(g['T'])
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature,
+                          schedule_type=cfg.schedule_type, cosine_params=cfg.cosine_params)
+    state = eng.prior_state(g['x_0'])
+    N, U = eng.N, eng.U
+    torch.manual_seed(int(g['seed_noise']))
+
+    def noise_for_step(i, last):            # the reference's draws, re-drawn from the seed on torch's CPU generator, in its order
+        nz = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, 'cpu')
+        return StepNoise(**{k: (None if getattr(nz, k) is None else getattr(nz, k).to(device)) for k in nz.__slots__})
+    n_steps = T - 1 if max_steps is None else min(max_steps, T - 1)
+    i32 = dict(dtype=torch.int32, device=device)
+    traj = {'x': torch.zeros(n_steps, N, 3, device=device), 'x1': torch.zeros(n_steps, N, 3, device=device)}
+    for k, rows in (('a', N), ('c', N), ('e', U)):
+        traj[k] = torch.zeros(n_steps, rows, **i32)
+        traj[f'{k}1'] = torch.zeros(n_steps, rows, **i32)
+    run = IntegrationRun(eng, state, plan, noise_for_step, traj=traj)
+    run.run(0, n_steps, chunk=chunk)
+    eng.synchronize()
+    final = {k: state[f'{k}_t'] for k in 'xace'}
+    if n_steps < T - 1:
+        gg = dict(g)
+        for k in ('traj.a', 'traj.c', 'traj.e', 'traj.x_norm'):
+            gg[k] = g[k][: n_steps + 1]
+        for k in ('traj.a1', 'traj.c1', 'traj.e1', 'traj.x1_norm'):
+            gg[k] = g[k][:n_steps]
+        st = int(g['traj.x_stride'])
+        gg['traj.x'] = g['traj.x'][: n_steps // st + 1]
+        res = long_report(gg, traj, final)
+        for k in ('a_flips', 'c_flips', 'e_flips', 'x_rel'):
+            res.pop(k)
+        res['steps'] = n_steps
+        return res
+    return long_report(g, traj, final)
+
+
+def oracle_long_golden(orc, cfg, g, max_steps=None):
+    """The CPU oracle on a long fixture (same seeds, torch's global generator like the reference)."""
+    batch = cpu_ref.build_batch(g['n_atoms'])
+    T = int(g['T'])
+    prior = {'x_0': g['x_0'], 'a_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_atom_types), 'c_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_charges),
+             'e_0': cpu_ref.edge_prior(batch.upper_edge_mask, cfg.n_bond_types)}
+    m = batch.upper_edge_mask
+    rec = {k: [] for k in ('x', 'a', 'c', 'e', 'x1', 'a1', 'c1', 'e1')}
+
+    class Stop(Exception):
+        pass
+
+    def hook(s_idx, new, dst):
+        rec['x'].append(new['x_t'].clone()); rec['x1'].append(new['x_1_pred'].clone())
+        for k in 'ac':
+            rec[k].append(new[f'{k}_t'].argmax(-1)); rec[f'{k}1'].append(new[f'{k}_1_pred'].argmax(-1))
+        rec['e'].append(new['e_t'][m].argmax(-1)); rec['e1'].append(new['e_1_pred'][m].argmax(-1))
+        if max_steps is not None and s_idx >= max_steps:
+            raise Stop
+    torch.manual_seed(int(g['seed_noise']))
+    out = None
+    try:
+        with torch.no_grad():
+            out = orc.integrate(batch, prior, T, step_hook=hook)
+    except Stop:
+        pass
+    traj = {k: torch.stack(v) for k, v in rec.items()}
+    n_steps = traj['x'].shape[0]
+    if out is None:
+        gg = dict(g)
+        for k in ('traj.a', 'traj.c', 'traj.e', 'traj.x_norm'):
+            gg[k] = g[k][: n_steps + 1]
+        for k in ('traj.a1', 'traj.c1', 'traj.e1', 'traj.x1_norm'):
+            gg[k] = g[k][:n_steps]
+        gg['traj.x'] = g['traj.x'][: n_steps // int(g['traj.x_stride']) + 1]
+        final = {'x': traj['x'][-1], 'a': traj['a'][-1], 'c': traj['c'][-1], 'e': traj['e'][-1]}
+        res = long_report(gg, traj, final)
+        for k in ('a_flips', 'c_flips', 'e_flips', 'x_rel'):
+            res.pop(k)
+        res['steps'] = n_steps
+        return res
+    final = {'x': out['x_1'], 'a': out['a_1'].argmax(-1), 'c': out['c_1'].argmax(-1), 'e': out['e_1'][m].argmax(-1)}
+    return long_report(g, traj, final)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def write_lightning_shaped_checkpoint(root, model_name, cfg, sd, n_atoms_hist='geom_full_kekulized'):
+    """<root>/<model_name>/checkpoints/last.ckpt + config.yaml shaped like the files the reference's load_pretrained reads
+    (flowmol/__init__.py:30-56, trained_models/readme.md): a Lightning checkpoint whose ``hyper_parameters`` is an instance of
+    pytorch_lightning's AttributeDict (a class this image does not have), holding the kwargs of the reference's FlowMol.__init__
+    (flowmol.py:29-55) as model_from_config passes them -- the two data files as pathlib.PosixPath objects -- next to Lightning's
+    bookkeeping keys, and a state dict with the ``vector_field.`` prefix.  The AttributeDict class exists only while the file is
+    written, so reading it exercises the Lightning-free unpickler."""
+    import pathlib
+    import sys
+    import types
+    mod = types.ModuleType('pytorch_lightning.utilities.parsing')
+
+    class AttributeDict(dict):
+        pass
+    AttributeDict.__module__, AttributeDict.__qualname__ = mod.__name__, 'AttributeDict'
+    mod.AttributeDict = AttributeDict
+    names = ['pytorch_lightning', 'pytorch_lightning.utilities', 'pytorch_lightning.utilities.parsing']
+    saved = {n: sys.modules.get(n) for n in names}
+    sys.modules['pytorch_lightning'] = types.ModuleType('pytorch_lightning')
+    sys.modules['pytorch_lightning.utilities'] = types.ModuleType('pytorch_lightning.utilities')
+    sys.modules[mod.__name__] = mod
+    data = pathlib.PosixPath('data') / n_atoms_hist
+    vf = dict(self_conditioning=cfg.self_conditioning, stochasticity=cfg.stochasticity, high_confidence_threshold=cfg.high_confidence_threshold,
+              n_vec_channels=cfg.n_vec_channels, update_edge_w_distance=cfg.update_edge_w_distance, n_hidden_scalars=cfg.n_hidden_scalars,
+              n_hidden_edge_feats=cfg.n_hidden_edge_feats, s_message_dim=None, v_message_dim=None, n_expansion_gvps=3, attention=False, n_heads=32,
+              n_recycles=cfg.n_recycles, separate_mol_updaters=cfg.separate_mol_updaters, n_molecule_updates=cfg.n_molecule_updates,
+              convs_per_update=cfg.convs_per_update, n_cp_feats=cfg.n_cp_feats, n_message_gvps=3, n_update_gvps=3, message_norm=cfg.message_norm,
+              rbf_dmax=int(cfg.rbf_dmax), rbf_dim=cfg.rbf_dim, time_embedding_dim=cfg.time_embedding_dim, a_token_dim=cfg.a_token_dim,
+              c_token_dim=cfg.c_token_dim, e_token_dim=cfg.e_token_dim)
+    hp = AttributeDict(
+        atom_type_map=list(cfg.atom_type_map), n_atoms_hist_file=data / 'train_data_n_atoms_histogram.pt',
+        marginal_dists_file=data / 'train_data_marginal_dists.pt', n_atom_charges=cfg.n_charges, sample_interval=0.2, n_mols_to_sample=128,
+        time_scaled_loss=True, exclude_charges=False, weight_ae=False, target_blur=0.0, parameterization='ctmc',
+        total_loss_weights={'x': 3.0, 'a': 0.4, 'c': 1.0, 'e': 2.0}, lr_scheduler_config={'base_lr': 1e-4, 'warmup_length': 1.0},
+        interpolant_scheduler_config={'schedule_type': {k: 'linear' for k in 'xace'}}, vector_field_config=vf,
+        prior_config={'x': {'align': True, 'type': 'centered-normal', 'kwargs': {'std': 1.0}},
+                      **{k: {'align': False, 'type': 'ctmc', 'kwargs': {}} for k in 'ace'}},
+        default_n_timesteps=250, ema_weight=0.999, fake_atom_p=0.3 if cfg.fake_atoms else 0.0, fake_atom_std=1.0, distort_p=0.2, distort_t=0.5,
+        explicit_aromaticity=cfg.explicit_aromaticity)
+    ck = {'epoch': 19, 'global_step': 1234567, 'pytorch-lightning_version': '2.1.3',
+          'state_dict': {'vector_field.' + k: v for k, v in sd.items()}, 'loops': {'fit_loop': {'epoch_progress': {'total': {'ready': 20}}}},
+          'callbacks': {"ModelCheckpoint{'monitor': 'val_total_loss'}": {'best_model_score': torch.tensor(1.5), 'dirpath': '/net/runs/flowmol3/checkpoints'}},
+          'optimizer_states': [], 'lr_schedulers': [], 'hparams_name': 'kwargs', 'hyper_parameters': hp}
+    d = pathlib.Path(root) / model_name / 'checkpoints'
+    d.mkdir(parents=True, exist_ok=True)
+    try:
+        torch.save(ck, d / 'last.ckpt')
+    finally:
+        for n in names:
+            if saved[n] is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = saved[n]
+    (d.parent / 'config.yaml').write_text('# the resolved training config ships next to the checkpoint (trained_models/readme.md); load_pretrained does not read it\n')
+    assert 'pytorch_lightning' not in sys.modules or saved['pytorch_lightning'] is not None
+    return d / 'last.ckpt'

@@ -20,14 +20,13 @@ from parity_util import forward_compare
                                                ('flowmol3', [3, 1, 2, 1], 0.5, True),        # 1-atom molecules: no edges, no messages
                                                ('dev_narrow', [5, 3, 6], 0.5, True), ('dev_narrow', [4, 7], 0.0, False),    # 64/64-wide model on zero-padded tiles
                                                ('dev', [5, 3, 6], 0.5, True), ('dev', [4, 7, 1], 0.0, False),              # configs/dev.yml incl. use_dst_feats
+                                               ('geom_arom', [6, 3], 0.4, False), ('flowmol3_arom', [4, 5], 0.5, True),    # explicit aromaticity: 5 bond types + mask
                                                ('arch_variants', [5, 1, 4], 0.5, True)])      # n_recycles=2, message_norm='mean', EdgeUpdate without distances, shared updater
-def test_emulated_forward_matches_oracle(emu_lib, monkeypatch, name, sizes, t, prev, tile):
+def test_emulated_forward_matches_oracle(emu_lib, name, sizes, t, prev, tile):
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
     sd = weights.synth_state_dict(cfg, 0)
-    monkeypatch.setenv('FM_TILE_EDGE', str(tile))          # read at fm_create; unset = chosen per batch (16 for these sizes)
-    monkeypatch.setenv('FM_TILE_NODE', str(tile))
-    eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+    eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning={'tile_edge': tile, 'tile_node': tile})     # 0 = chosen per batch (16 for these sizes)
     orc = cpu_ref.OracleVF(cfg, sd)
     errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev)
     bad = {k: v for k, v in errs.items() if not v < 2e-5}
@@ -401,17 +400,15 @@ def test_error_tracks_the_reference_rounding_sensitivity_on_emulation(emu_lib):
     assert all(torch.isfinite(v).all() for v in out.values())
 
 
-@pytest.mark.parametrize('small', ['0', '1'])
-def test_mlp_tile_sizes_on_emulation(emu_lib, monkeypatch, small):
+@pytest.mark.parametrize('small', [-1, 1])
+def test_mlp_tile_sizes_on_emulation(emu_lib, small):
     """The node- / pair-side MLP kernels (self-conditioning layers, output heads) exist with 64-row tiles (throughput) and 16-row tiles
     (small batches, chosen automatically): both against the oracle on the same batch, paired and separate launches."""
     from flowmol_amd.engine import Engine
-    monkeypatch.setenv('FM_MLP_SMALL_TILES', small)
-    for pair in ('0', '1'):
-        monkeypatch.setenv('FM_PAIR_MLPS', pair)
+    for pair in (-1, 1):
         cfg = presets.flowmol3()
         sd = weights.synth_state_dict(cfg, 0)
-        eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+        eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning={'mlp_small_tiles': small, 'pair_mlps': pair})
         errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor([5, 18, 2, 1]), 0.5, True, taps=False)
         bad = {k: v for k, v in errs.items() if not v < 1e-5}
         assert not bad, (small, pair, bad)

@@ -35,25 +35,13 @@ _engines = {}
 
 def engine_for(name, tile=0):
     """Engine + oracle per preset.  tile = 0: the library chooses the row-tile size per batch (16 rows for batches that
-    do not fill the chip, else 32); 16 / 32: forced through FM_TILE_EDGE / FM_TILE_NODE (read at fm_create)."""
+    do not fill the chip, else 32); 16 / 32: forced through fm_config.tile_edge / tile_node.  precision is passed explicitly:
+    no environment variable can change what the parity tests verify."""
     from flowmol_amd.engine import Engine
     if (name, tile) not in _engines:
         cfg = presets.PRESETS[name]()
         sd = weights.synth_state_dict(cfg, 0)
-        old = {k: os.environ.get(k) for k in ('FM_TILE_EDGE', 'FM_TILE_NODE')}
-        try:
-            for k in old:
-                if tile:
-                    os.environ[k] = str(tile)
-                else:
-                    os.environ.pop(k, None)
-            eng = Engine(cfg, sd, device='cuda:0')
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+        eng = Engine(cfg, sd, device='cuda:0', precision='f32', tuning={'tile_edge': tile, 'tile_node': tile})
         _engines[(name, tile)] = (cfg, sd, eng, cpu_ref.OracleVF(cfg, sd))
     return _engines[(name, tile)]
 
@@ -73,6 +61,9 @@ def test_native_library_is_the_hip_build():
     ('flowmol3', [47], 0.2, True),                     # single-molecule batch
     ('geom_ctmc', [2, 2, 2], 0.9, False),
     ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False),
+    ('geom_arom', [5, 17, 8, 30, 2], 0.5, False),      # explicit aromaticity (geom_full_aromatic.yaml / geom_5_aromatic.yaml): 5 bond types + mask
+    ('flowmol3_arom', [5, 9, 47, 2], 0.5, True),
+    ('flowmol3_arom', [5, 9, 12], 0.0, False),
     ('qm9', [18] * 8, 0.7, True),
     ('dev_narrow', [70, 2, 47], 0.3, True),            # 64 scalars / 64 edge features on zero-padded 256 / 128-column tiles
     ('dev', [5, 9, 12, 3, 2], 0.5, True),              # configs/dev.yml:78-108: narrow dims + use_dst_feats (gvp.py:300-316,472-473,527-537)
@@ -93,7 +84,8 @@ def test_forward_matches_oracle(name, sizes, t, prev, tile):
 
 
 @pytest.mark.parametrize('fname,name', [('integrate_flowmol3_F7.npz', 'flowmol3'), ('integrate_qm9_C1.npz', 'qm9'),
-                                        ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc')])
+                                        ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc'),
+                                        ('integrate_geom_arom_T16.npz', 'geom_arom'), ('integrate_flowmol3_arom_T12.npz', 'flowmol3_arom')])
 def test_integrate_matches_reference_golden(golden_dir, fname, name):
     """Free-running trajectories with the reference's recorded noise: zero categorical flips and
     coordinates within 1e-4 relative of the reference's own output."""
@@ -105,6 +97,32 @@ def test_integrate_matches_reference_golden(golden_dir, fname, name):
     assert res['traj0_a_flips'] == 0, res
     assert res['x_rel'] < 1e-4 and res['traj0_x_rel'] < 1e-4, res
     assert (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()   # no mask tokens left
+
+
+@pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc')])
+def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
+    """The product's DEFAULT protocol against the reference itself: free-running trajectories of the reference's own
+    CTMCVectorField.integrate at n_timesteps = 250 (test.py:25, flowmol.py:46; 8 x 47 atoms, and a 5/33/60/90-atom batch with all weight
+    matrices x2 so that the endpoint prediction moves every atom by several percent per evaluation) and 500 (BASELINE config C5's
+    horizon, geom_ctmc model).  Noise is re-drawn from the stored seed on torch's CPU generator in the reference's order.  Every state
+    token and every sampled endpoint token of every step must equal the reference's (0 flips over 250 / 500 tempered CTMC steps), the
+    coordinates stay within 1e-4 relative (north star) at the end, at every 10th frame and in every per-step per-molecule norm."""
+    from flowmol_amd.engine import Engine
+    from parity_util import integrate_long_golden
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / f'long_{tag}.npz').items()}
+    cfg = presets.PRESETS[name]()
+    scale = float(g['weight_scale'])
+    if scale == 1:
+        eng = engine_for(name)[2]
+    else:
+        eng = Engine(cfg, weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale), device='cuda:0', precision='f32')
+    res = integrate_long_golden(eng, cfg, g)
+    _report(f'long[{tag}]', res)
+    assert res['first_divergent_step'] is None and res['state_token_diffs_all_steps'] == 0, res
+    assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0, res
+    assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4 and res['x_norm_rel'] < 1e-4 and res['x1_norm_rel'] < 1e-4, res
+    if scale > 1:
+        assert res['mean_rel_move'] > 0.02, res
 
 
 @pytest.mark.parametrize('fname,dfm_type', [('integrate_qm9_gat.npz', 'gat'), ('integrate_qm9_sched.npz', 'campbell')])
@@ -616,7 +634,7 @@ def test_rccl_one_rank_group_gather_and_cli(tmp_path, monkeypatch):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants'])
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants', 'geom_arom', 'flowmol3_arom'])
 def test_forward_matches_reference_fixture_directly(golden_dir, name):
     """The HIP forward against the REFERENCE's own outputs (tests/golden/forward_<name>.npz: EndpointVectorField.forward of the
     reference's modules, incl. configs/dev.yml with use_dst_feats) -- no oracle in between: bootstrap pass at t = 0 and a
@@ -786,3 +804,153 @@ def test_error_tracks_the_reference_rounding_sensitivity(precision):
     bad = {k: (v, sens[k]) for k, v in errs.items() if k in sens and not v <= max(floor, factor * sens[k])}
     assert not bad, bad
     assert all(torch.isfinite(v).all() for v in out.values())
+
+
+def test_load_pretrained_lightning_shaped_checkpoint_on_gpu(tmp_path, monkeypatch):
+    """The documented usage (reference readme.md:44-49, flowmol/__init__.py:30-56) on the GPU from a Lightning-shaped checkpoint under
+    $FLOWMOL_MODELS_DIR (hyper_parameters an AttributeDict of a package this image lacks, pathlib.PosixPath data files, `vector_field.*`
+    keys): load_pretrained('flowmol3').cuda().eval().sample_random_sizes(...) equals the from_preset model with the same seed."""
+    import flowmol_amd as flowmol
+    from parity_util import write_lightning_shaped_checkpoint
+    cfg = presets.flowmol3()
+    write_lightning_shaped_checkpoint(tmp_path, 'flowmol3', cfg, weights.synth_state_dict(cfg, 0))
+    monkeypatch.setenv('FLOWMOL_MODELS_DIR', str(tmp_path))
+    model = flowmol.load_pretrained('flowmol3').cuda().eval()
+    torch.manual_seed(7)
+    mols = model.sample_random_sizes(4, n_timesteps=6)
+    ref = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    torch.manual_seed(7)
+    mols_ref = ref.sample_random_sizes(4, n_timesteps=6)
+    assert len(mols) == 4
+    for a, b in zip(mols, mols_ref):
+        assert torch.equal(a.positions, b.positions) and a.atom_types == b.atom_types and torch.equal(a.atom_charges, b.atom_charges)
+        assert torch.equal(a.bond_types, b.bond_types) and torch.equal(a.bond_src_idxs, b.bond_src_idxs)
+    assert model.last_timing['precision'] == 'f32'
+
+
+def test_remove_com_prior_entry_point_matches_oracle_prior():
+    """fm_remove_com as the centring step of the position prior (priors.py:27-35 centered_normal_prior_batched_graph) against the oracle's
+    sample_prior from the SAME randn draw, on a ragged batch incl. 1-atom and 181-atom molecules: within 1 ulp of the coordinate scale
+    (the per-molecule mean is a different summation order), and exactly zero-mean to rounding."""
+    cfg, sd, eng, orc = engine_for('flowmol3')
+    n_atoms = torch.tensor([47, 1, 5, 181, 2, 33, 90, 3])
+    batch = cpu_ref.build_batch(n_atoms)
+    torch.manual_seed(123)
+    prior = orc.sample_prior(batch)                     # randn(N,3) on the CPU generator, minus the per-molecule mean
+    torch.manual_seed(123)
+    raw = torch.randn(batch.N, 3)
+    eng.bind(n_atoms)
+    x = raw.cuda().contiguous()
+    eng.remove_com(x)
+    eng.synchronize()
+    got = x.cpu()
+    err = float((got - prior['x_0']).abs().max())
+    _report('remove_com_prior', {'max_abs': err})
+    assert err <= 2.4e-7 * float(raw.abs().max()), err                      # <= 2 ulp at the largest coordinate
+    off = 0
+    for n in n_atoms.tolist():
+        assert float(got[off:off + n].mean(0).abs().max()) < 2e-6
+        off += n
+    assert torch.equal(got[47:48], torch.zeros(1, 3))                       # a 1-atom molecule is its own centre
+
+
+def test_philox_streams_statistics_on_gpu():
+    """rng='philox' is the mode an 8-GPU run uses: the in-kernel draws on the real device.  Position prior
+    (fm_prior_philox): per-molecule mean 0, unit variance, Gaussian quantiles (KS), streams of different molecule ids and seeds
+    uncorrelated, a molecule's draw independent of its position in the batch.  CTMC noise (fm_ctmc_step, FM_NOISE_PHILOX): the Exp(1) race
+    reproduces the categorical probabilities and the U(0,1) thresholds reproduce the unmasking probability, per modality."""
+    import ctypes as C
+    import math
+    from flowmol_amd.engine import make_step_plan
+    cfg, sd, eng, orc = engine_for('flowmol3')
+    B, n = 512, 64
+    eng.bind(torch.full((B,), n))
+    eng.set_molecule_ids(None)
+    x0 = eng.prior_philox(7).cpu().reshape(B, n, 3)
+    assert float(x0.mean(1).abs().max()) < 2e-6
+    raw_var = float(x0.var(dim=1, unbiased=True).mean())                  # centring removes 1/n of the variance; the unbiased estimate restores it
+    assert abs(raw_var - 1.0) < 0.01, raw_var
+    z = (x0 * math.sqrt(n / (n - 1))).flatten().double().sort().values      # ~N(0,1) marginals
+    cdf = 0.5 * (1 + torch.erf(z / math.sqrt(2)))
+    m = z.numel()
+    ks = float(torch.max((torch.arange(1, m + 1) / m - cdf).abs().max(), (cdf - torch.arange(0, m) / m).abs().max()))
+    assert ks < 1.63 / math.sqrt(m) * 1.5, ks                              # 1 % critical value with slack for the centring
+    x0b = eng.prior_philox(8).cpu().reshape(B, n, 3)
+    corr_seed = float((x0 * x0b).mean() / (x0.std() * x0b.std()))
+    corr_mol = float((x0[:-1] * x0[1:]).mean() / x0.var())
+    assert abs(corr_seed) < 0.015 and abs(corr_mol) < 0.015, (corr_seed, corr_mol)
+    ids = torch.tensor([300, 17, 511])
+    eng.bind(torch.full((3,), n))
+    eng.set_molecule_ids(ids)
+    sub = eng.prior_philox(7).cpu().reshape(3, n, 3)
+    torch.testing.assert_close(sub, x0[ids], rtol=0, atol=1e-6)              # same stream wherever the molecule sits (mean in another order)
+    # CTMC draws: everything masked, fixed probabilities, hc = 0 (uniform unmasking branch), mid-trajectory step
+    eng.bind(torch.tensor([64] * 16))
+    eng.set_molecule_ids(None)
+    N, U = eng.N, eng.U
+    T = cfg.cat_temperature
+    p_e = torch.tensor([0.1, 0.2, 0.3, 0.4])
+    p_a = torch.softmax(torch.linspace(-1, 1, cfg.n_atom_types), 0)
+    temper = lambda p: (p ** T / (p ** T).sum())                            # the kernel applies softmax(log(.)/T): feed p^T so that it samples from p
+    plan = make_step_plan(250, cfg.stochasticity, 0.0, T, philox_seed=4242)
+    for s_idx, last in ((len(plan.scalars) - 1, True), (100, False)):
+        sc = plan.scalars[s_idx]
+        state = eng.prior_state(torch.zeros(N, 3))
+        dst = {'x': torch.zeros(N, 3, device='cuda:0'), 'a': temper(p_a).repeat(N, 1).contiguous().cuda(),
+               'c': torch.full((N, cfg.n_charges), 1.0 / cfg.n_charges, device='cuda:0'), 'e': temper(p_e).repeat(U, 1).contiguous().cuda()}
+        st_, d_ = eng._state_struct(state), eng._dst_struct(dst)
+        smp = {'a1': torch.zeros(N, dtype=torch.int32, device='cuda:0'), 'c1': torch.zeros(N, dtype=torch.int32, device='cuda:0'),
+               'e1': torch.zeros(U, dtype=torch.int32, device='cuda:0')}
+        from flowmol_amd._lib import fm_sampled
+        sm = fm_sampled(); sm.a1, sm.c1, sm.e1 = (C.c_void_p(smp[k].data_ptr()) for k in ('a1', 'c1', 'e1'))
+        with eng._dev():
+            eng._check(eng.lib.fm_ctmc_step(eng._ctx, eng._stream(), C.byref(st_), C.byref(d_), None, C.byref(sc), C.byref(sm)), 'fm_ctmc_step')
+        eng.synchronize()
+        fe = torch.bincount(smp['e1'].cpu().long(), minlength=4).float() / U         # the Exp(1) race = a categorical sample of p
+        fa = torch.bincount(smp['a1'].cpu().long(), minlength=cfg.n_atom_types).float() / N
+        assert torch.allclose(fe, p_e, atol=4 * math.sqrt(0.25 / U) + 1e-3), fe
+        assert torch.allclose(fa, p_a, atol=4 * math.sqrt(0.25 / N) + 1e-3), fa
+        e_t = state['e_t'].cpu().long()
+        if last:
+            assert (e_t != cfg.n_bond_types).all()
+        else:                                                                          # U(0,1) thresholds: unmasked share = p_unmask (then re-masking with p_mask)
+            pu, pm = sc.unmask_prob[2], sc.mask_prob[2]
+            share = float((e_t != cfg.n_bond_types).float().mean())
+            assert abs(share - pu) < 4 * math.sqrt(pu * (1 - pu) / U) + 2e-3, (share, pu, pm)
+
+
+def test_c5_full_size_trajectory_properties():
+    """BASELINE configs[4] at FULL size: geom_full_kekulized model, 128 molecules with sizes randint(5, 61, seed 0), n_timesteps = 500, with the
+    trajectory sink on (--xt_traj / --ep_traj).  Size-independent properties: finite, no mask tokens in the result, frame 0 = the prior
+    (masked tokens, the centred draw), last frame = the result, every endpoint frame COM-free, the frames' footprint within the compact-format
+    budget (indices + fp32 coordinates instead of float one-hots over directed edges)."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('geom_ctmc').cuda().eval()
+    n_atoms = torch.randint(5, 61, (128,), generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(31)
+    torch.cuda.reset_peak_memory_stats()
+    mols = model.sample(n_atoms, n_timesteps=500, xt_traj=True, ep_traj=True)
+    peak = torch.cuda.max_memory_allocated()
+    cfg = model.cfg
+    assert len(mols) == 128
+    frame_bytes = 0
+    for m, n in zip(mols, n_atoms.tolist()):
+        tf = m.traj_frames
+        u = n * (n - 1) // 2
+        assert tf['x'].shape == (500, n, 3) and tf['x_1_pred'].shape == (499, n, 3) and tf['e'].shape == (500, u) and tf['e_1_pred'].shape == (499, u)
+        assert torch.isfinite(tf['x']).all() and torch.isfinite(tf['x_1_pred']).all()
+        assert (tf['a'][0] == cfg.n_atom_types).all() and (tf['c'][0] == cfg.n_charges).all() and (tf['e'][0] == cfg.n_bond_types).all()
+        assert float(tf['x'][0].mean(0).abs().max()) < 2e-6                                  # the centred prior
+        assert torch.equal(tf['x'][-1], m.x_1) and torch.equal(tf['a'][-1].long(), m.a_1) and torch.equal(tf['e'][-1].long(), m.e_1)
+        assert (m.a_1 != cfg.n_atom_types).all() and (m.c_1 != cfg.n_charges).all() and (m.e_1 != cfg.n_bond_types).all()
+        assert float(tf['x_1_pred'].mean(1).abs().max()) < 1e-4
+        frame_bytes += sum(v.numel() * v.element_size() for v in tf.values())
+    N, U = int(n_atoms.sum()), int((n_atoms * (n_atoms - 1) // 2).sum())
+    compact = 2 * 500 * (N * (12 + 8) + U * 4)                     # x fp32 + a, c, e int32, state + endpoint frames
+    reference_format = 2 * 500 * 4 * (N * (3 + cfg.n_atom_types + 1 + cfg.n_charges + 1) + 2 * U * (cfg.n_bond_types + 1))
+    _report('c5_full_size', {'frame_bytes': frame_bytes, 'reference_format_bytes': reference_format, 'peak_device_bytes': int(peak),
+                             'integrate_s': model.last_timing['integrate'], 'package_s': model.last_timing.get('package')})
+    assert frame_bytes <= compact and frame_bytes < reference_format / 2
+    assert peak < 8 << 30
+    blocks = mols[3].traj_mol_blocks()
+    assert len(blocks) == 500 and blocks[0].count('Se') == int(n_atoms[3])                    # frame 0: every atom still masked

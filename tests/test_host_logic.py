@@ -335,3 +335,119 @@ def test_trajectory_blocks_batched_path_equals_per_frame_path():
             for a, b in zip(ref, got):
                 if a != b:          # an atom line whose 4th decimal rounds the other way
                     assert a[30:] == b[30:] and all(abs(float(a[i:i + 10]) - float(b[i:i + 10])) <= 1.01e-4 for i in (0, 10, 20)), (a, b)
+
+
+def _stub_rdkit(monkeypatch):
+    """A minimal stand-in for the three RDKit classes build_rdkit_mol touches, so the RDKit branch of the boundary can run in an
+    image without RDKit: records atoms (symbol, formal charge), bonds and conformer positions."""
+    import sys
+    import types
+
+    class Atom:
+        def __init__(self, sym): self.sym, self.chg = sym, 0
+        def SetFormalCharge(self, q): self.chg = q
+
+    class Mol:
+        def __init__(self): self.atoms, self.bonds, self.conf = [], [], None
+        def AddAtom(self, a): self.atoms.append(a)
+        def AddBond(self, s, d, t): self.bonds.append((s, d, t))
+        def GetMol(self): return self
+        def GetNumAtoms(self): return len(self.atoms)
+        def AddConformer(self, c): self.conf = c
+
+    class Conformer:
+        def __init__(self, n): self.pos = [None] * n
+        def SetAtomPosition(self, i, p): self.pos[i] = p
+
+    chem = types.ModuleType('rdkit.Chem')
+    chem.Atom, chem.RWMol, chem.Conformer = Atom, Mol, Conformer
+    chem.rdchem = types.SimpleNamespace(BondType=types.SimpleNamespace(SINGLE=1, DOUBLE=2, TRIPLE=3, AROMATIC=4))
+    geom = types.ModuleType('rdkit.Geometry')
+    geom.Point3D = lambda x, y, z: (x, y, z)
+    rd = types.ModuleType('rdkit')
+    rd.Chem, rd.Geometry = chem, geom
+    for k, v in (('rdkit', rd), ('rdkit.Chem', chem), ('rdkit.Geometry', geom)):
+        monkeypatch.setitem(sys.modules, k, v)
+
+
+def test_traj_mols_follow_the_reference_build_switches(monkeypatch):
+    """SampledMolecule.traj_mols / .ep_traj_mols (reference molecule_builder.py:76-84,156-214; read by test.py:235,251): present only when the
+    molecule carries frames and the matching build switch is on; one RDKit molecule per frame with fake atoms shown and positions aligned
+    to the final frame; without RDKit a clear error that names the RDKit-free equivalent."""
+    from flowmol_amd.molecule import rigid_alignment
+    torch.manual_seed(1)
+    n, T = 7, 6
+    amap = ['C', 'H', 'N', 'O', 'F']
+    fr = {'x': torch.randn(T, n, 3) * 2, 'a': torch.randint(0, 7, (T, n), dtype=torch.int32), 'c': torch.randint(0, 6, (T, n), dtype=torch.int32),
+          'e': (torch.randint(0, 5, (T, n * (n - 1) // 2), dtype=torch.int32) * (torch.rand(T, n * (n - 1) // 2) < 0.4)).int()}
+    fr.update({k + '_1_pred': v[1:] for k, v in fr.items()})
+    last = (fr['x'][-1], fr['a'][-1].clamp(max=5), fr['c'][-1], fr['e'][-1].clamp(max=3))
+    plain = SampledMolecule(*last, amap, fake_atoms=True)
+    for attr in ('traj_mols', 'ep_traj_mols'):
+        assert not hasattr(plain, attr)                                        # no frames -> the reference never sets the attribute
+    only_xt = SampledMolecule(*last, amap, fake_atoms=True, traj_frames=fr, build_ep_traj=False)
+    assert not hasattr(only_xt, 'ep_traj_mols')
+    m = SampledMolecule(*last, amap, fake_atoms=True, traj_frames=fr)
+    try:
+        import rdkit       # noqa: F401
+        have = True
+    except Exception:
+        have = False
+    if not have:
+        with pytest.raises(ImportError, match='traj_mol_blocks'):
+            m.traj_mols
+        _stub_rdkit(monkeypatch)
+        assert only_xt.traj_mols is not None
+        for ep, attr in ((False, 'traj_mols'), (True, 'ep_traj_mols')):
+            mols = getattr(m, attr)
+            key = 'x_1_pred' if ep else 'x'
+            assert len(mols) == fr[key].shape[0] and getattr(m, attr) is mols             # built once
+            for f, mol in enumerate(mols):
+                pos, sym, chg, bt, bs, bd = m.frame_moldata(f, ep_traj=ep)
+                assert [a.sym for a in mol.atoms] == sym and [a.chg for a in mol.atoms] == [int(q) for q in chg]     # fake atoms shown (Sn), masked atoms Se
+                assert [(s, d, t) for s, d, t in mol.bonds] == [(int(s), int(d), int(t)) for s, d, t in zip(bs, bd, bt)]
+                want = rigid_alignment(pos, fr[key][-1])
+                assert torch.allclose(torch.tensor(mol.conf.pos), want, atol=1e-6)
+        unaligned = SampledMolecule(*last, amap, fake_atoms=True, traj_frames=fr, align_traj=False)
+        assert torch.allclose(torch.tensor(unaligned.traj_mols[0].conf.pos), fr['x'][0], atol=1e-6)
+    else:
+        assert len(m.traj_mols) <= T and len(m.ep_traj_mols) <= T - 1
+
+
+def test_lightning_shaped_checkpoint_is_read_without_lightning(tmp_path, monkeypatch):
+    """load_pretrained on a checkpoint shaped like a real Lightning file (hyper_parameters an AttributeDict of a package this image lacks,
+    pathlib.PosixPath data files, Lightning's bookkeeping keys, `vector_field.` prefixed weights): the resulting config equals the preset's."""
+    import pickle
+    from parity_util import write_lightning_shaped_checkpoint
+    cfg = presets.flowmol3()
+    sd = weights.synth_state_dict(cfg, 0)
+    path = write_lightning_shaped_checkpoint(tmp_path, 'flowmol3', cfg, sd)
+    with pytest.raises((ModuleNotFoundError, AttributeError, pickle.UnpicklingError)):
+        torch.load(str(path), map_location='cpu', weights_only=False)          # the stock unpickler needs pytorch_lightning: the file really is Lightning-shaped
+    hp, sd2 = read_checkpoint(path)
+    assert type(hp) is dict and str(hp['n_atoms_hist_file']).endswith('geom_full_kekulized/train_data_n_atoms_histogram.pt')
+    monkeypatch.setenv('FLOWMOL_MODELS_DIR', str(tmp_path))
+    model = load_pretrained('flowmol3')
+    assert model.cfg.to_dict() == cfg.to_dict()
+    assert model.cfg.n_atoms_hist == 'geom_full_kekulized' and model.fake_atoms and model.default_n_timesteps == 250
+    assert all(torch.equal(model._sd['vector_field.' + k], v) for k, v in sd.items())
+
+
+def test_bench_flop_model_reproduces_the_survey_counts():
+    """bench.py's reference FLOP model, derived from the model dimensions, against SURVEY.md section 8a/8d: flowmol3 2.437 M MAC per directed
+    edge and 3.25 M per node (1.0844e10 FLOP at n = 47), geom_full_kekulized model 3.590e6 n(n-1) + 4.39e6 n FLOP (7.968e9 at n = 47),
+    conv message 312,251 MAC per edge."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location('bench_mod', Path(__file__).resolve().parent.parent / 'bench.py')
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pe, pn = bench.reference_macs(presets.flowmol3())
+    assert round(pe) == 2437218 and pn == 3249692
+    assert abs(bench.network_flops(47, presets.flowmol3()) / 1.0844e10 - 1) < 1e-4
+    pe, pn = bench.reference_macs(presets.geom_ctmc())
+    assert abs(2 * pe / 3.590e6 - 1) < 1e-3 and abs(2 * pn / 4.39e6 - 1) < 2e-3
+    assert abs(bench.network_flops(47, presets.geom_ctmc()) / 7.968e9 - 1) < 1e-4
+    assert bench.conv_message_flops_per_edge(32) == 2 * 312251
+    info = bench.host_cpu_info()
+    assert info['logical_cpus'] >= 1

@@ -24,7 +24,7 @@ def _onehots(cfg, batch, a, c, eu):
     return F.one_hot(a, cfg.n_atom_types + 1).float(), F.one_hot(c, cfg.n_charges + 1).float(), e
 
 
-@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants'])      # arch_variants: n_recycles=2, message_norm='mean', no distance in EdgeUpdate, shared updater
+@pytest.mark.parametrize('name', ['flowmol3', 'geom_ctmc', 'qm9', 'dev', 'arch_variants', 'geom_arom', 'flowmol3_arom'])      # *_arom: explicit aromaticity, 5 bond types (geom_full_aromatic.yaml / geom_5_aromatic.yaml); arch_variants: n_recycles=2, message_norm='mean', no distance in EdgeUpdate, shared updater
 def test_forward_matches_reference(golden_dir, name):
     cfg = presets.PRESETS[name]()
     g = _load(golden_dir, f'forward_{name}.npz')
@@ -69,7 +69,8 @@ def test_modules_match_reference(golden_dir, name):
 
 @pytest.mark.parametrize('fname,name', [('integrate_flowmol3_F7.npz', 'flowmol3'),
                                         ('integrate_qm9_C1.npz', 'qm9'),
-                                        ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc')])
+                                        ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc'),
+                                        ('integrate_geom_arom_T16.npz', 'geom_arom'), ('integrate_flowmol3_arom_T12.npz', 'flowmol3_arom')])
 def test_integrate_matches_reference(golden_dir, fname, name):
     """Free-running trajectory with the reference's recorded noise: categorical outcomes bit-exact,
     coordinates to 1e-5 (config C1 of BASELINE.json is the qm9 case)."""
@@ -289,3 +290,45 @@ def test_endpoint_parameterization_matches_reference(golden_dir):
     for k in 'xac':
         torch.testing.assert_close(out[f'{k}_1'], g[f'{k}_1'], **TOL)
     torch.testing.assert_close(out['e_1'][m], g['e_1_upper'], **TOL)
+
+
+LONG = [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc')]
+
+
+@pytest.mark.parametrize('tag,name', LONG)
+def test_long_horizon_reference_trajectory_first_steps(golden_dir, tag, name):
+    """The oracle free-running on the reference's default-protocol trajectories (250 / 500 steps; noise re-drawn from the stored seed in the
+    reference's order).  Here only the first 12 steps, every state and sampled token of every step against the reference's (the suite has to
+    finish in minutes); FM_LONG_ORACLE=1 runs the whole horizon, whose result is committed as profiles/r03_oracle_long_parity.jsonl
+    (tools/oracle_long_parity.py).  The full-length comparison that gates the product is the -m gpu test of the same fixtures."""
+    import os
+    from parity_util import oracle_long_golden
+    g = _load(golden_dir, f'long_{tag}.npz')
+    cfg = presets.PRESETS[name]()
+    sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), float(g['weight_scale']))
+    full = os.environ.get('FM_LONG_ORACLE') == '1'
+    res = oracle_long_golden(cpu_ref.OracleVF(cfg, sd), cfg, g, max_steps=None if full else 12)
+    assert res['first_divergent_step'] is None and res['state_token_diffs_all_steps'] == 0, res
+    assert res['x_norm_rel'] < 1e-5 and res['x1_norm_rel'] < 1e-5 and res['x_frames_rel'] < 1e-5, res
+    if full:
+        assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and res['x_rel'] < 1e-4, res
+    if float(g['weight_scale']) > 1:
+        assert res['mean_rel_move'] > 0.02, res            # the x2 weights really make the coordinates depend on the network
+
+
+def test_long_fixture_noise_is_the_seeded_redraw(golden_dir):
+    """The long fixtures store seeds instead of the noise tape: the fixture's first sampled tokens must follow from the seeded re-draw
+    (StepNoise.draw on torch's CPU generator) fed through the oracle's teacher-forced CTMC step -- i.e. the stored seed really is the
+    reference's stream (make_golden asserts the re-draw equals every recorded draw when the fixture is generated)."""
+    from flowmol_amd.engine import StepNoise
+    g = _load(golden_dir, 'long_geom_ctmc_mixed_T500.npz')
+    cfg = presets.geom_ctmc()
+    N = int(g['n_atoms'].sum()); U = int((g['n_atoms'] * (g['n_atoms'] - 1) // 2).sum())
+    torch.manual_seed(int(g['seed_noise']))
+    nz = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, False, 'cpu')
+    torch.manual_seed(int(g['seed_noise']))
+    rec = cpu_ref.TorchNoise()
+    assert torch.equal(nz.q_a, rec.exp_like(torch.empty(N, cfg.n_atom_types)))
+    assert g['traj.a'].shape == (int(g['T']), N) and g['traj.e1'].shape == (int(g['T']) - 1, U)
+    assert bool((g['traj.a'][0] == cfg.n_atom_types).all()) and not bool((g['traj.a'][-1] == cfg.n_atom_types).any())   # masked prior -> no mask left
+    assert torch.equal(g['traj.a'][-1].long(), g['a_1'].long()) and torch.equal(g['traj.e'][-1].long(), g['e_1_upper'].long())

@@ -12,9 +12,10 @@ from flowmol_amd import presets, weights                 # noqa: E402
 from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan   # noqa: E402
 
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 32, 128, 512]
+tuning = {a.split('=')[0]: int(a.split('=')[1]) for a in sys.argv[1:] if '=' in a}      # fm_config launch-tuning overrides, e.g. fuse_node=-1
 philox = 'philox' in sys.argv[1:]          # in-kernel noise: no torch RNG launches between the steps
 cfg = presets.flowmol3()
-eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0')
+eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', tuning=tuning)
 dev = eng.device
 for B in sizes:
     eng.bind(torch.full((B,), 47, dtype=torch.int64))
@@ -44,6 +45,5 @@ for B in sizes:
         if cnt:
             per_kernel[k] = round(ms / cnt * 1e3, 1)       # us per launch
     eng.profile(False)
-    import os
-    print(json.dumps({'mols': B, 'noise': 'philox' if philox else 'torch', 'fuse_node': os.environ.get('FM_FUSE_NODE', '1'), 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
+    print(json.dumps({'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
                       'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2), 'us_per_launch': per_kernel}))

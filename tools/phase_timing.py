@@ -6,7 +6,6 @@
 """
 import ctypes
 import json
-import os
 import sys
 from pathlib import Path
 
@@ -39,7 +38,7 @@ for _ in range(R):
     eng.forward(st, 0.3, prev=prev, out=out)
 eng.synchronize()
 raw.fm_tlog_read(buf, 0)
-tile = int(os.environ.get('FM_TILE_EDGE', '32'))
+tile = 32        # the automatic choice at this batch size
 ntiles = (eng.E + tile - 1) // tile * cfg.n_convs * R
 names = {0: 'meta+geom', 1: 'fill', 40: 'dbg', 41: 'aggregate'}
 for base, g_ in ((10, 'g0'), (20, 'g1'), (30, 'g2')):
