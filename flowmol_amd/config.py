@@ -143,9 +143,13 @@ class VFConfig:
 
     def validate(self) -> "VFConfig":
         # tiles are 256 scalar / 128 edge-feature columns wide; narrower models (configs/dev.yml: 64 / 64) are zero-padded at fm_create
-        if not (8 <= self.n_hidden_scalars <= 256 and 8 <= self.n_hidden_edge_feats <= 128) or self.rbf_dim != 32:
+        # ... and the LayerNorm statistics take the mean as sum * (1/n), which equals sum / n bit for bit only for a power-of-two n
+        # (fm_device.h: fm_row_stats); the shipped widths (256 / 128, dev.yml 64 / 64) are the tested ones
+        pow2 = lambda v: v >= 8 and (v & (v - 1)) == 0
+        if not (pow2(self.n_hidden_scalars) and self.n_hidden_scalars <= 256 and pow2(self.n_hidden_edge_feats) and self.n_hidden_edge_feats <= 128) \
+                or self.rbf_dim != 32:
             raise NotImplementedError(
-                f"HIP kernels hold up to S=256 scalars and F=128 edge features (R=32); got S={self.n_hidden_scalars} "
+                f"HIP kernels hold power-of-two widths up to S=256 scalars and F=128 edge features (R=32); got S={self.n_hidden_scalars} "
                 f"F={self.n_hidden_edge_feats} R={self.rbf_dim}")
         if self.n_vec_channels not in (16, 32):
             raise NotImplementedError(f"n_vec_channels must be 16 or 32, got {self.n_vec_channels}")
@@ -154,8 +158,9 @@ class VFConfig:
         if self.use_dst_feats:
             if self.dst_feat_msg_reduction_factor == 1:
                 raise NotImplementedError("use_dst_feats with dst_feat_msg_reduction_factor == 1 (no projection GVP) is not implemented")
-            if not (1 <= self.v_dst_feats <= 8 and 1 <= self.s_dst_feats <= 256):
-                raise NotImplementedError(f"destination-feature widths out of range: v={self.v_dst_feats} s={self.s_dst_feats}")
+            if self.v_dst_feats != self.n_vec_channels // 4 or not 1 <= self.s_dst_feats <= 256:
+                raise NotImplementedError(f"use_dst_feats is instantiated for dst_feat_msg_reduction_factor = 4 (v_dst_feats = n_vec_channels / 4, as in "
+                                          f"configs/dev.yml); got v={self.v_dst_feats} s={self.s_dst_feats} for {self.n_vec_channels} vector channels")
         if not 1 <= int(self.n_recycles) <= 64:
             raise ValueError(f"n_recycles must be 1..64, got {self.n_recycles}")
         if self.dfm_type not in ('campbell', 'gat'):

@@ -615,8 +615,9 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     // The kernels' tiles are 256 scalar / 128 edge-feature columns wide.  Narrower models (configs/dev.yml: 64 / 64) run on the
     // same tiles: weights, biases and LayerNorm affine parameters are zero-padded when they are repacked, so the extra columns
     // stay exactly 0 through every Linear / SiLU / residual, and LayerNorm takes its statistics over the REAL width only.
-    if (cfg->n_hidden_scalars < 8 || cfg->n_hidden_scalars > 256 || cfg->n_hidden_edge_feats < 8 || cfg->n_hidden_edge_feats > 128 || cfg->rbf_dim != 32)
-        return fail(nullptr, FM_ERR_INVALID, "fm_create: need 8 <= n_hidden_scalars <= 256, 8 <= n_hidden_edge_feats <= 128, rbf_dim == 32");
+    auto pow2 = [](int v) { return v >= 8 && (v & (v - 1)) == 0; };      // LayerNorm mean = sum * (1/n): exact division only for a power-of-two width
+    if (!pow2(cfg->n_hidden_scalars) || cfg->n_hidden_scalars > 256 || !pow2(cfg->n_hidden_edge_feats) || cfg->n_hidden_edge_feats > 128 || cfg->rbf_dim != 32)
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: need power-of-two widths 8 <= n_hidden_scalars <= 256, 8 <= n_hidden_edge_feats <= 128, and rbf_dim == 32");
     if (cfg->n_vec_channels != 16 && cfg->n_vec_channels != 32) return fail(nullptr, FM_ERR_INVALID, "fm_create: n_vec_channels must be 16 or 32");
     if (cfg->n_convs < 1 || cfg->n_convs > FM_MAX_CONVS) return fail(nullptr, FM_ERR_INVALID, "fm_create: bad n_convs");
     if (cfg->n_recycles < 0 || cfg->n_recycles > 64) return fail(nullptr, FM_ERR_INVALID, "fm_create: n_recycles must be 0..64");

@@ -440,6 +440,14 @@ class FlowMol:
             eng.remove_com(x0)          # per molecule, so centring after the row selection equals centring the full batch
         else:
             x0, a0, c0 = prior['x_0'], prior['a_0'], prior['c_0']
+            # the reference adapts a prior drawn with / without the fake-atom column to the model (flowmol.py:540-545)
+            if prior.get('fake_atoms', False) and not self.fake_atoms:
+                a0 = a0[:, 1:]
+            elif not prior.get('fake_atoms', False) and self.fake_atoms and a0.shape[-1] == cfg.n_atom_types - 1:
+                a0 = torch.cat([torch.zeros(a0.shape[0], 1, device=a0.device, dtype=a0.dtype), a0], dim=-1)
+            if a0.shape != (N, cfg.n_atom_types) or c0.shape != (N, cfg.n_charges) or tuple(x0.shape) != (N, 3):
+                raise ValueError(f"prior shapes x_0 {tuple(x0.shape)}, a_0 {tuple(a0.shape)}, c_0 {tuple(c0.shape)} do not fit the batch "
+                                 f"({N} atoms, {cfg.n_atom_types} atom types, {cfg.n_charges} charges)")
             e0 = prior['e_0']
             if e0.shape[0] == eng.E:          # directed edges, upper block first per molecule -> keep the upper halves
                 idx, off = [], 0

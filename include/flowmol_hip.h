@@ -27,7 +27,7 @@
  *     or the device.  fm_batch_bind / fm_set_molecule_ids copy their host arrays through the pinned
  *     staging buffer and wait (on an event) only for the copies of the PREVIOUS such call, which
  *     have completed long before in any realistic call sequence; they are setup calls and, because
- *     of that event wait, the only entry points that must stay outside a stream capture.
+ *     of that event wait, must stay outside a stream capture.
  *   - the library reads no environment variables; every switch is a field of fm_config.
  *   - a context is bound to the device current at fm_create and is not thread-safe.
  *   - categorical state is exchanged as int32 token indices (mask token = number of real categories);
@@ -67,8 +67,8 @@ typedef struct fm_config {
     int32_t n_charges;
     int32_t n_bond_types;
     int32_t n_vec_channels;       /* 16 or 32 */
-    int32_t n_hidden_scalars;     /* 8..256 (flowmol3: 256, configs/dev.yml: 64); narrower models run on zero-padded 256-column tiles */
-    int32_t n_hidden_edge_feats;  /* 8..128 (flowmol3: 128, dev.yml: 64) */
+    int32_t n_hidden_scalars;     /* power of two, 8..256 (flowmol3: 256, configs/dev.yml: 64); narrower models run on zero-padded 256-column tiles */
+    int32_t n_hidden_edge_feats;  /* power of two, 8..128 (flowmol3: 128, dev.yml: 64) */
     int32_t rbf_dim;              /* 32 */
     int32_t n_convs;
     int32_t n_updaters;
