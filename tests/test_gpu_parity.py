@@ -954,3 +954,56 @@ def test_c5_full_size_trajectory_properties():
     assert peak < 8 << 30
     blocks = mols[3].traj_mol_blocks()
     assert len(blocks) == 500 and blocks[0].count('Se') == int(n_atoms[3])                    # frame 0: every atom still masked
+
+
+def test_c3_full_batch_reproduces_reference_long_trajectory(golden_dir):
+    """BASELINE configs[2] at FULL size AND full horizon against the reference: a 1024 x 47-atom batch integrated for 250 steps in which
+    eight molecules -- placed at both ends of the batch, either side of XCD tile-chunk boundaries (127|128, 895|896) and mid-chunk -- carry the
+    prior and the per-step noise of tests/golden/long_flowmol3_47x8_T250.npz (the reference's own 8-molecule run), while the other 1016
+    molecules draw their own.  Molecules never interact, so those eight must reproduce the reference's trajectory: every state token of every
+    step, final coordinates within 1e-4 -- parity at the size and horizon the metric is quoted on, not only on an 8-molecule batch."""
+    from flowmol_amd.engine import IntegrationRun, StepNoise, make_step_plan
+    cfg, sd, eng, orc = engine_for('flowmol3')
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / 'long_flowmol3_47x8_T250.npz').items()}
+    T, n, B = int(g['T']), 47, 1024
+    u = n * (n - 1) // 2
+    slots = torch.tensor([0, 127, 128, 511, 600, 895, 896, 1023])
+    node_rows = (slots[:, None] * n + torch.arange(n)[None]).flatten().cuda()
+    pair_rows = (slots[:, None] * u + torch.arange(u)[None]).flatten().cuda()
+    eng.bind(torch.full((B,), n))
+    N, U = eng.N, eng.U
+    gen = torch.Generator(device='cuda:0').manual_seed(99)
+    x0 = torch.randn(N, 3, device='cuda:0', generator=gen)
+    eng.remove_com(x0)
+    x0[node_rows] = g['x_0'].cuda()
+    state = eng.prior_state(x0)
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    torch.manual_seed(int(g['seed_noise']))
+
+    def noise_for_step(i, last):
+        small = StepNoise.draw(8 * n, 8 * u, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, 'cpu')          # the reference's draws, from its seed
+        big = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, 'cuda:0', generator=gen)
+        for k in big.__slots__:
+            t = getattr(big, k)
+            if t is not None:
+                t[pair_rows if k.endswith('_e') else node_rows] = getattr(small, k).cuda()
+        return big
+    i32 = dict(dtype=torch.int32, device='cuda:0')
+    traj = {'x': torch.zeros(T - 1, N, 3, device='cuda:0'), 'a': torch.zeros(T - 1, N, **i32), 'c': torch.zeros(T - 1, N, **i32)}
+    run = IntegrationRun(eng, state, plan, noise_for_step, traj=traj)
+    run.run(0, T - 1, chunk=16)
+    eng.synchronize()
+    nr, pr = node_rows.cpu(), pair_rows.cpu()
+    res = {'a_flips': int((state['a_t'].cpu()[nr].long() != g['a_1'].long()).sum()), 'c_flips': int((state['c_t'].cpu()[nr].long() != g['c_1'].long()).sum()),
+           'e_flips': int((state['e_t'].cpu()[pr].long() != g['e_1_upper'].long()).sum()),
+           'x_rel': float((state['x_t'].cpu()[nr] - g['x_1']).abs().max() / g['x_1'].abs().max()),
+           'a_state_diffs_all_steps': int((traj['a'][:, node_rows].cpu().long() != g['traj.a'][1:].long()).sum()),
+           'c_state_diffs_all_steps': int((traj['c'][:, node_rows].cpu().long() != g['traj.c'][1:].long()).sum())}
+    st = int(g['traj.x_stride'])
+    got = traj['x'][st - 1::st][:, node_rows].cpu()
+    ref = g['traj.x'][1:]
+    res['x_frames_rel'] = float((got[:ref.shape[0]] - ref).abs().max() / ref.abs().max())
+    _report('c3_full_batch_long', res)
+    assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and res['a_state_diffs_all_steps'] == 0 and res['c_state_diffs_all_steps'] == 0, res
+    assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4, res
+    assert torch.isfinite(state['x_t']).all() and (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()
