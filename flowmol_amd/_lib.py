@@ -126,6 +126,13 @@ def load(path=None) -> C.CDLL:
         raise FlowMolHipError(
             f"{p} not found: the HIP extension has not been built.  Run `python -m flowmol_amd.build` "
             f"(needs hipcc; cross-compiles for gfx950 without a GPU).  There is no CPU fallback.")
+    if path is None:
+        # the in-tree library must be the build of the in-tree sources: a stale .so (sources edited, library not rebuilt) would
+        # silently test and benchmark old kernels.  The build stamp is the digest of csrc/ + the header + the flags.
+        from . import build as _build
+        if _build.STAMP.exists() and (_build.SRC / 'fm_engine.cpp').exists() and _build.STAMP.read_text().strip() != _build._digest():
+            raise FlowMolHipError(f"{p} is stale: flowmol_amd/csrc or include/flowmol_hip.h changed since it was built.  "
+                                  f"Run `python -m flowmol_amd.build`.")
     lib = C.CDLL(str(p))
     for name, (res, args) in _EXPORTS.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing

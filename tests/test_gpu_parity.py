@@ -929,8 +929,9 @@ def test_c5_full_size_trajectory_properties():
     n_atoms = torch.randint(5, 61, (128,), generator=torch.Generator().manual_seed(0))
     torch.manual_seed(31)
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()          # other tests' cached engines (workspaces of up to 2 GB each) stay allocated: budget the increase
     mols = model.sample(n_atoms, n_timesteps=500, xt_traj=True, ep_traj=True)
-    peak = torch.cuda.max_memory_allocated()
+    peak = torch.cuda.max_memory_allocated() - base
     cfg = model.cfg
     assert len(mols) == 128
     frame_bytes = 0
@@ -951,7 +952,7 @@ def test_c5_full_size_trajectory_properties():
     _report('c5_full_size', {'frame_bytes': frame_bytes, 'reference_format_bytes': reference_format, 'peak_device_bytes': int(peak),
                              'integrate_s': model.last_timing['integrate'], 'package_s': model.last_timing.get('package')})
     assert frame_bytes <= compact and frame_bytes < reference_format / 2
-    assert peak < 8 << 30
+    assert peak < 4 << 30                         # workspace + 0.37 GB of frames on the device + per-chunk noise
     blocks = mols[3].traj_mol_blocks()
     assert len(blocks) == 500 and blocks[0].count('Se') == int(n_atoms[3])                    # frame 0: every atom still masked
 
