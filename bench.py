@@ -374,6 +374,11 @@ def main():
     #      event-instrumented pass of 2 more steps AFTER the timed region (event pairs around every launch add ~1 % to
     #      the step, so the sum of these averages slightly exceeds ms_per_step)
     finite = bool(torch.isfinite(state['x_t']).all().item())
+    try:            # which build of the kernels produced this line: digest of csrc/ + header + flags (flowmol_amd/build.py), as in profiles/current_pmc.json
+        from flowmol_amd import build as fm_build
+        lib_digest = fm_build.STAMP.read_text().strip()[:16]
+    except Exception:
+        lib_digest = None
     eng.profile(True)
     advance(2)
     torch.cuda.synchronize(dev)
@@ -388,8 +393,8 @@ def main():
     # counters of the dominant kernel from the committed rocprofv3 PMC passes (same workload only); never measured by this run
     pmc = None
     try:
-        pj = json.loads((ROOT / 'profiles' / 'current_pmc.json').read_text())
-        if pj['mols_per_gpu'] == B and pj['n_atoms'] == n and pj['preset'] == args.preset and args.size_dist is None:
+        pj = json.loads((ROOT / 'profiles' / 'current_pmc.json').read_text()).get(args.workload)
+        if pj and pj['nodes_per_gpu'] == N and pj['directed_edges_per_gpu'] == E and args.size_dist is None and args.precision == 'f32' and world == 1:
             pmc = pj
     except Exception:
         pass
@@ -418,7 +423,7 @@ def main():
         traffic = pmc['hbm_bytes_per_launch'] if pmc else None
         roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
-                    'traffic_source': (f"committed profile {pmc['source']} (library of commit {pmc['commit']}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
+                    'traffic_source': (f"committed profile {pmc['source']} (library digest {pmc.get('library_digest')}; this run: {lib_digest}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
                                        f"rocprofv3 PMC with the gfx950 FETCH correction; not measured by this run") if pmc else None,
                     'algorithmic_bytes_per_launch': E * (512 + 8) + N * 4 * (256 + 3 * cfg.n_vec_channels) * 2,
                     'avg_launch_us': us,
@@ -429,7 +434,7 @@ def main():
                     'executed_tflops': ex_flops / (us * 1e-6) / 1e12,
                     'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
                     'mfma_busy_frac': pmc.get('mfma_busy_frac') if pmc else None,
-                    'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library of commit {pmc['commit']})"
+                    'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})"
                                          if pmc and pmc.get('mfma_busy_frac') else None),
                     'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
                             'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
@@ -449,7 +454,7 @@ def main():
                    'global_molecules': B * world, 'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'parallelism': f'molecule-shard x{world}',
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
                    'value_formula': 'global_molecules / (network_evaluations_per_sample * ms_per_step/1000)', 'network_evaluations_per_sample': evals, 'trajectory_sink': bool(wl['traj']), 'weights': 'synthetic by name (seed 0)',
-                   'finite': finite},
+                   'finite': finite, 'library_digest': lib_digest},
         'network_eval_ms': ms_per_step, 'per_rank_ms_per_step': per_rank_ms, 'final_gather_ms': gather_ms,
         'launches_per_step': launches_per_step,
         'whole_path': None if args.precision != 'f32' else {'algorithmic_tflops_per_gpu': alg_tf, 'executed_tflops_per_gpu': exe_tf,

@@ -58,10 +58,18 @@ print(json.dumps({'value': bench['value'], 'ms_per_step': bench['ms_per_step'], 
                   'mfma_busy_frac': busy / (gui / 8 * 1024), 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'],
                   'algorithmic_bytes_per_launch': traffic['algorithmic_bytes_per_launch']}, indent=1))
 if '--current' in sys.argv:
+    # profiles/current_pmc.json: {workload: counters of its dominant kernel}; bench.py quotes the entry of the workload it runs
     commit = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    mols = bench['config']['global_molecules'] // bench['n_gpus']
-    cur = {'preset': 'flowmol3', 'mols_per_gpu': mols, 'n_atoms': N // mols, 'commit': commit,
-           'kernel': k, 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'], 'source': f'profiles/{ptag}_traffic.json',
-           'mfma_busy_frac': busy / (gui / 8 * 1024), 'source_sq': f'profiles/{ptag}_pmc_sq.txt',
-           'note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs = 256 CUs x 4'}
-    (P / 'current_pmc.json').write_text(json.dumps(cur, indent=1) + '\n')
+    wl = {'main': 'c3'}.get(name, name)
+    path = P / 'current_pmc.json'
+    try:
+        allw = json.loads(path.read_text())
+        if 'kernel' in allw:          # the single-workload format of rounds 1-2
+            allw = {}
+    except Exception:
+        allw = {}
+    allw[wl] = {'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'collected_at_commit': commit, 'library_digest': bench['config'].get('library_digest'),
+                'kernel': k, 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'], 'source': f'profiles/{ptag}_traffic.json',
+                'mfma_busy_frac': busy / (gui / 8 * 1024), 'source_sq': f'profiles/{ptag}_pmc_sq.txt',
+                'note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs = 256 CUs x 4'}
+    path.write_text(json.dumps(allw, indent=1) + '\n')
