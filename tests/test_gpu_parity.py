@@ -765,15 +765,15 @@ def test_split_precision_c3_full_size_properties():
     assert out['x'].reshape(1024, 47, 3).mean(1).abs().max() < 1e-3
 
 
-@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('seed', list(range(16)))
 def test_forward_matches_oracle_on_random_batches(seed):
     """Seeded random batches (ragged sizes 1..90 with a degenerate / tile-edge size in every batch, random time, with / without a
     previous endpoint, every preset, both tile sizes): every stage and output of a network evaluation against the oracle."""
     rng = np.random.default_rng(1234 + seed)
-    name = ['flowmol3', 'geom_ctmc', 'dev', 'dev_narrow', 'arch_variants', 'qm9'][seed % 6]
+    name = ['flowmol3', 'geom_ctmc', 'dev', 'dev_narrow', 'arch_variants', 'qm9', 'geom_arom', 'flowmol3_arom'][seed % 8]
     tile = [16, 32][int(rng.integers(0, 2))]
     nmol = int(rng.integers(2, 9))
-    sizes = [int(v) for v in rng.integers(1, 91 if name in ('flowmol3', 'geom_ctmc') else 40, size=nmol)]
+    sizes = [int(v) for v in rng.integers(1, 91 if name in ('flowmol3', 'geom_ctmc', 'geom_arom', 'flowmol3_arom') else 40, size=nmol)]
     sizes[int(rng.integers(0, nmol))] = [1, 2, 17, 33][int(rng.integers(0, 4))]
     t = float(np.float32(rng.uniform(0.05, 0.95)))
     cfg, sd, eng, orc = engine_for(name, tile)
