@@ -143,11 +143,10 @@ def api_end_to_end(args, sizes, T, dev, traj=False):
             'breakdown_s': timing, 'note': 'FlowMol.sample() incl. packaging into SampledMolecule objects (no RDKit in this image)'}
 
 
-def _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, threads):
-    """Warm-up step (with the bootstrap evaluation) + `steps` timed integration steps of the CPU oracle."""
+def _cpu_steps(cfg, sd, n_atoms, steps, T, threads):
+    """Warm-up step (with the bootstrap evaluation) + `steps` timed integration steps of the CPU oracle on molecules of the given sizes."""
     from oracle import cpu_ref
     torch.set_num_threads(threads)
-    n_atoms = torch.full((B,), n_atoms_each, dtype=torch.int64)
     batch = cpu_ref.build_batch(n_atoms)
     orc = cpu_ref.OracleVF(cfg, sd)
     torch.manual_seed(1)
@@ -191,23 +190,25 @@ def host_cpu_info():
     return {'model': model, 'physical_cores': len(phys) or None, 'sockets': len({p for p, _ in phys}) or None, 'logical_cpus': os.cpu_count()}
 
 
-def cpu_baseline(cfg, sd, n_atoms_each, B, steps, T, evals):
+def cpu_baseline(cfg, sd, sizes, steps, T, evals):
     """Time the CPU oracle (the op-for-op restatement of the reference's PyTorch path, oracle/cpu_ref.py; bit-identical to the reference's
     own modules over whole trajectories, profiles/r03a_oracle_long_parity.jsonl) on this box's host cores on a bounded sample of the same
     workload.  The intra-op thread count is chosen by a probe AT THE BATCH SIZE THAT IS TIMED (2 steps per candidate): torch with one
     thread per logical CPU of a many-core host oversubscribes these operators badly, and the best count depends on the operand sizes."""
     ncpu = os.cpu_count() or 1
+    B = int(sizes.numel())
     cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu < 8 else set()))
     probe = {}
     for c in cands:          # ascending; stop once more threads are clearly slower (256 threads on the 2 x 64-core host: 190 s per step, r03a)
-        probe[c] = _cpu_steps(cfg, sd, n_atoms_each, B, 2, T, c)
+        probe[c] = _cpu_steps(cfg, sd, sizes, 2, T, c)
         if probe[c] > 1.5 * min(probe.values()):
             break
     best = min(probe, key=probe.get)
-    per_step = _cpu_steps(cfg, sd, n_atoms_each, B, steps, T, best)
+    per_step = _cpu_steps(cfg, sd, sizes, steps, T, best)
+    desc = f'{B} molecules x {int(sizes[0])} atoms' if bool((sizes == sizes[0]).all()) else f'the first {B} molecules of the workload ({int(sizes.min())}-{int(sizes.max())} atoms, mean {float(sizes.double().mean()):.1f})'
     host = host_cpu_info()
     return {'value': B / (evals * per_step), 'unit': 'molecules/s', 'cores': best, 'kind': 'port', 'host': host,
-            'sample': f'{B} molecules x {n_atoms_each} atoms, {steps} timed integration steps after 1 warm-up step '
+            'sample': f'{desc}, {steps} timed integration steps after 1 warm-up step '
                       f'({per_step * 1e3:.0f} ms/step) with {best} torch threads (best of {sorted(probe)}, each probed with 2 steps of the same {B}-molecule batch; '
                       f"host: {host['model']}, {host['physical_cores']} physical cores / {ncpu} logical CPUs), extrapolated linearly to {evals} network evaluations per sample",
             'ms_per_step': per_step * 1e3, 'thread_probe_ms_per_step': {str(k): v * 1e3 for k, v in probe.items()}}
@@ -471,7 +472,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_api_e2e:
         out['api_end_to_end'] = api_end_to_end(args, all_sizes, T, dev, wl['traj'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, sd, n or int(all_sizes.double().mean().round()), args.cpu_mols, args.cpu_steps, T, evals)
+        out['cpu_baseline'] = cpu_baseline(cfg, sd, all_sizes[:args.cpu_mols].clone(), args.cpu_steps, T, evals)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
