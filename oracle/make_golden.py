@@ -542,6 +542,11 @@ LONG_CASES = {       # tag: (preset, sizes, T, weight scale, prior seed, noise s
     # only moves the result by ~1e-6 (x2.5 and above are chaotic: the reference disagrees with ITSELF under such a perturbation)
     'flowmol3_mixed_T250_w2': ('flowmol3', [5, 33, 60, 90], 250, 2.0, 33, 34),
     'geom_ctmc_mixed_T500': ('geom_ctmc', [5, 17, 8, 30, 44, 60], 500, 1.0, 35, 36),
+    # 64 molecules with sizes drawn from the shipped GEOM-drugs histogram (torch.multinomial, seed 64: 19..97 atoms, mean 47.3): 9.3 M tempered
+    # categorical decisions per modality set over the 249 steps -- the flip-rate bound of the f32 kernels and of the opt-in split precision
+    'flowmol3_geom64_T250': ('flowmol3', [43, 44, 54, 41, 68, 40, 52, 58, 28, 45, 19, 46, 34, 42, 65, 46, 39, 56, 50, 53, 53, 75, 31, 51, 40, 35, 48, 52, 53,
+                                          51, 33, 41, 57, 44, 51, 57, 97, 53, 24, 36, 42, 66, 46, 47, 37, 61, 36, 57, 41, 33, 32, 65, 55, 50, 38, 47, 46, 51,
+                                          45, 39, 42, 49, 53, 47], 250, 1.0, 37, 38),
 }
 LONG_X_STRIDE = 10
 

@@ -454,13 +454,23 @@ def oracle_long_golden(orc, cfg, g, max_steps=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def write_lightning_shaped_checkpoint(root, model_name, cfg, sd, n_atoms_hist='geom_full_kekulized'):
+def hparams_from_yaml(yaml_name='flowmol3.yml'):
+    """``hyper_parameters`` of a checkpoint trained from one of the reference's shipped YAMLs, as derived mechanically by
+    oracle/make_hparams_fixture.py (model_from_config's mapping, load.py:13-49, plus FlowMol.__init__'s defaults) -- NOT from a preset."""
+    import json
+    import pathlib
+    fx = json.loads((pathlib.Path(__file__).resolve().parent / 'golden' / 'hparams_from_yaml.json').read_text())
+    return json.loads(json.dumps(fx[yaml_name]['hyper_parameters']))        # deep copy
+
+
+def write_lightning_shaped_checkpoint(root, model_name, sd, yaml_name='flowmol3.yml'):
     """<root>/<model_name>/checkpoints/last.ckpt + config.yaml shaped like the files the reference's load_pretrained reads
     (flowmol/__init__.py:30-56, trained_models/readme.md): a Lightning checkpoint whose ``hyper_parameters`` is an instance of
     pytorch_lightning's AttributeDict (a class this image does not have), holding the kwargs of the reference's FlowMol.__init__
-    (flowmol.py:29-55) as model_from_config passes them -- the two data files as pathlib.PosixPath objects -- next to Lightning's
-    bookkeeping keys, and a state dict with the ``vector_field.`` prefix.  The AttributeDict class exists only while the file is
-    written, so reading it exercises the Lightning-free unpickler."""
+    (flowmol.py:29-55) as model_from_config passes them for the shipped YAML ``yaml_name`` (tests/golden/hparams_from_yaml.json, derived
+    from /root/reference/configs by oracle/make_hparams_fixture.py -- not from the preset the loaded model is then compared with) -- the
+    two data files as pathlib.PosixPath objects -- next to Lightning's bookkeeping keys, and a state dict with the ``vector_field.``
+    prefix.  The AttributeDict class exists only while the file is written, so reading it exercises the Lightning-free unpickler."""
     import pathlib
     import sys
     import types
@@ -475,24 +485,9 @@ def write_lightning_shaped_checkpoint(root, model_name, cfg, sd, n_atoms_hist='g
     sys.modules['pytorch_lightning'] = types.ModuleType('pytorch_lightning')
     sys.modules['pytorch_lightning.utilities'] = types.ModuleType('pytorch_lightning.utilities')
     sys.modules[mod.__name__] = mod
-    data = pathlib.PosixPath('data') / n_atoms_hist
-    vf = dict(self_conditioning=cfg.self_conditioning, stochasticity=cfg.stochasticity, high_confidence_threshold=cfg.high_confidence_threshold,
-              n_vec_channels=cfg.n_vec_channels, update_edge_w_distance=cfg.update_edge_w_distance, n_hidden_scalars=cfg.n_hidden_scalars,
-              n_hidden_edge_feats=cfg.n_hidden_edge_feats, s_message_dim=None, v_message_dim=None, n_expansion_gvps=3, attention=False, n_heads=32,
-              n_recycles=cfg.n_recycles, separate_mol_updaters=cfg.separate_mol_updaters, n_molecule_updates=cfg.n_molecule_updates,
-              convs_per_update=cfg.convs_per_update, n_cp_feats=cfg.n_cp_feats, n_message_gvps=3, n_update_gvps=3, message_norm=cfg.message_norm,
-              rbf_dmax=int(cfg.rbf_dmax), rbf_dim=cfg.rbf_dim, time_embedding_dim=cfg.time_embedding_dim, a_token_dim=cfg.a_token_dim,
-              c_token_dim=cfg.c_token_dim, e_token_dim=cfg.e_token_dim)
-    hp = AttributeDict(
-        atom_type_map=list(cfg.atom_type_map), n_atoms_hist_file=data / 'train_data_n_atoms_histogram.pt',
-        marginal_dists_file=data / 'train_data_marginal_dists.pt', n_atom_charges=cfg.n_charges, sample_interval=0.2, n_mols_to_sample=128,
-        time_scaled_loss=True, exclude_charges=False, weight_ae=False, target_blur=0.0, parameterization='ctmc',
-        total_loss_weights={'x': 3.0, 'a': 0.4, 'c': 1.0, 'e': 2.0}, lr_scheduler_config={'base_lr': 1e-4, 'warmup_length': 1.0},
-        interpolant_scheduler_config={'schedule_type': {k: 'linear' for k in 'xace'}}, vector_field_config=vf,
-        prior_config={'x': {'align': True, 'type': 'centered-normal', 'kwargs': {'std': 1.0}},
-                      **{k: {'align': False, 'type': 'ctmc', 'kwargs': {}} for k in 'ace'}},
-        default_n_timesteps=250, ema_weight=0.999, fake_atom_p=0.3 if cfg.fake_atoms else 0.0, fake_atom_std=1.0, distort_p=0.2, distort_t=0.5,
-        explicit_aromaticity=cfg.explicit_aromaticity)
+    hp = AttributeDict(hparams_from_yaml(yaml_name))
+    for k in ('n_atoms_hist_file', 'marginal_dists_file'):           # model_from_config passes pathlib paths (load.py:23-25)
+        hp[k] = pathlib.PosixPath(hp[k])
     ck = {'epoch': 19, 'global_step': 1234567, 'pytorch-lightning_version': '2.1.3',
           'state_dict': {'vector_field.' + k: v for k, v in sd.items()}, 'loops': {'fit_loop': {'epoch_progress': {'total': {'ready': 20}}}},
           'callbacks': {"ModelCheckpoint{'monitor': 'val_total_loss'}": {'best_model_score': torch.tensor(1.5), 'dirpath': '/net/runs/flowmol3/checkpoints'}},

@@ -813,7 +813,7 @@ def test_load_pretrained_lightning_shaped_checkpoint_on_gpu(tmp_path, monkeypatc
     import flowmol_amd as flowmol
     from parity_util import write_lightning_shaped_checkpoint
     cfg = presets.flowmol3()
-    write_lightning_shaped_checkpoint(tmp_path, 'flowmol3', cfg, weights.synth_state_dict(cfg, 0))
+    write_lightning_shaped_checkpoint(tmp_path, 'flowmol3', weights.synth_state_dict(cfg, 0), 'flowmol3.yml')
     monkeypatch.setenv('FLOWMOL_MODELS_DIR', str(tmp_path))
     model = flowmol.load_pretrained('flowmol3').cuda().eval()
     torch.manual_seed(7)

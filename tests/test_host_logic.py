@@ -421,7 +421,7 @@ def test_lightning_shaped_checkpoint_is_read_without_lightning(tmp_path, monkeyp
     from parity_util import write_lightning_shaped_checkpoint
     cfg = presets.flowmol3()
     sd = weights.synth_state_dict(cfg, 0)
-    path = write_lightning_shaped_checkpoint(tmp_path, 'flowmol3', cfg, sd)
+    path = write_lightning_shaped_checkpoint(tmp_path, 'flowmol3', sd, 'flowmol3.yml')      # hyper_parameters derived from the reference's YAML, not from `cfg`
     with pytest.raises((ModuleNotFoundError, AttributeError, pickle.UnpicklingError)):
         torch.load(str(path), map_location='cpu', weights_only=False)          # the stock unpickler needs pytorch_lightning: the file really is Lightning-shaped
     hp, sd2 = read_checkpoint(path)
@@ -431,6 +431,30 @@ def test_lightning_shaped_checkpoint_is_read_without_lightning(tmp_path, monkeyp
     assert model.cfg.to_dict() == cfg.to_dict()
     assert model.cfg.n_atoms_hist == 'geom_full_kekulized' and model.fake_atoms and model.default_n_timesteps == 250
     assert all(torch.equal(model._sd['vector_field.' + k], v) for k, v in sd.items())
+
+
+YAML_PRESETS = {'flowmol3.yml': 'flowmol3', 'dev.yml': 'dev', 'geom_full_kekulized.yaml': 'geom_ctmc', 'geom_5_kekulized.yaml': 'geom_ctmc',
+                'geom_full_aromatic.yaml': 'geom_arom', 'geom_5_aromatic.yaml': 'geom_arom'}
+
+
+@pytest.mark.parametrize('yaml_name', sorted(YAML_PRESETS))
+def test_presets_equal_the_hyper_parameters_derived_from_the_shipped_yamls(yaml_name):
+    """Non-circular pin of the presets: tests/golden/hparams_from_yaml.json holds, for each of the reference's six shipped
+    YAMLs, the FlowMol(...) keyword arguments exactly as model_from_config builds them (flowmol/model_utils/load.py:13-49) completed with
+    FlowMol.__init__'s defaults (flowmol.py:29-55) -- generated in the build container by oracle/make_hparams_fixture.py from
+    /root/reference/configs.  Each passes check_reference_hparams, and from_reference_hparams of it equals the preset that claims to be that
+    YAML in every field except the name of the size histogram (dataset variant) and cosine_params the linear schedules never read."""
+    from parity_util import hparams_from_yaml
+    from flowmol_amd.model import check_reference_hparams
+    hp = hparams_from_yaml(yaml_name)
+    check_reference_hparams(hp)
+    got = from_reference_hparams(hp).to_dict()
+    want = presets.PRESETS[YAML_PRESETS[yaml_name]]().to_dict()
+    diff = {k for k in got if got[k] != want[k]}
+    assert diff <= {'n_atoms_hist', 'cosine_params'}, {k: (got[k], want[k]) for k in diff}
+    assert all(v == 'linear' for v in got['schedule_type'].values())          # ... which is why cosine_params is dead
+    if yaml_name == 'flowmol3.yml':
+        assert not diff
 
 
 def test_bench_flop_model_reproduces_the_survey_counts():
