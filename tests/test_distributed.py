@@ -31,7 +31,9 @@ def _worker(rank, world, port, n_atoms, q):
         as_.append(torch.full((n,), i % 11, dtype=torch.int32))
         cs.append(torch.full((n,), i % 6, dtype=torch.int32))
         es.append(torch.full((u,), i % 5, dtype=torch.int32))
-    local = {'x': torch.cat(xs), 'a': torch.cat(as_), 'c': torch.cat(cs), 'e': torch.cat(es)}
+    i32 = dict(dtype=torch.int32)
+    local = ({'x': torch.cat(xs), 'a': torch.cat(as_), 'c': torch.cat(cs), 'e': torch.cat(es)} if xs else
+             {'x': torch.zeros(0, 3), 'a': torch.zeros(0, **i32), 'c': torch.zeros(0, **i32), 'e': torch.zeros(0, **i32)})      # a rank that owns nothing
     full = gather_results(local, n_atoms, parts)
     ok = True
     noff = poff = 0
@@ -48,14 +50,17 @@ def _worker(rank, world, port, n_atoms, q):
 import pytest
 
 
-@pytest.mark.parametrize('sizes', [[5, 47, 12, 30, 8, 64, 3, 21, 47],
-                                   [3, 2]])      # packed payloads of 45 and 29 bytes: slot size must be padded for the fp32 view
-def test_shard_and_gather_world2(sizes):
+@pytest.mark.parametrize('sizes,world', [([5, 47, 12, 30, 8, 64, 3, 21, 47], 2),
+                                         ([3, 2], 2),      # packed payloads of 45 and 29 bytes: slot size must be padded for the fp32 view
+                                         ([5, 47, 12, 30, 8, 64, 3, 21, 47], 3),      # more than two ranks, parts of unequal length
+                                         ([9, 4, 33, 17, 2, 61, 47, 5, 12, 3, 26], 8),      # the node's rank count
+                                         ([7, 3], 4)])                                # two ranks own nothing: empty payloads
+def test_shard_and_gather(sizes, world):
     n_atoms = torch.tensor(sizes)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_atoms, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_atoms, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -144,19 +149,20 @@ def test_cli_under_two_ranks_writes_once(tmp_path, emu_lib_path):
     assert out.read_text().count('$$$$') == 5
 
 
-@pytest.mark.parametrize('preset', ['qm9', 'endpoint_small'])
-def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path, preset):
-    """Parity mode of the sharded path: with every rank drawing the full batch's noise from the same seed, two ranks
+@pytest.mark.parametrize('preset,world', [('qm9', 2), ('endpoint_small', 2), ('qm9', 3), ('qm9', 5)])
+def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path, preset, world):
+    """Parity mode of the sharded path: with every rank drawing the full batch's noise from the same seed, the ranks
     reproduce the single-process sample(n_atoms): identical tokens, coordinates to summation order (molecules are
     independent: SURVEY.md §8e).  For an endpoint-parameterised model the only randomness is the priors, drawn for the full
-    batch on every rank and sliced."""
+    batch on every rank and sliced.  Three ranks: parts of unequal length; five ranks for four molecules: one rank owns nothing
+    and still takes part in the gather."""
     import flowmol_amd as flowmol
     from flowmol_amd import _lib
     sizes = [4, 6, 3, 5]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, sizes, q, 'replicated', preset)) for r in range(2)]
+    procs = [ctx.Process(target=_sample_worker, args=(r, world, port, sizes, q, 'replicated', preset)) for r in range(world)]
     for p in procs:
         p.start()
     res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=300) for _ in procs)}
@@ -165,7 +171,7 @@ def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path,
     model = flowmol.FlowMol.from_preset(preset, _engine_lib=_lib.load(emu_lib_path)).to('cpu')
     torch.manual_seed(100)
     single, _ = model.sample(torch.tensor(sizes), n_timesteps=3, return_tensors=True)
-    for r in range(2):
+    for r in range(world):
         for k in 'ace':
             assert torch.equal(res[r][k], single[k].to(res[r][k].dtype))
         torch.testing.assert_close(res[r]['x'], single['x'], rtol=1e-5, atol=1e-5)    # tile alignment changes the summation order

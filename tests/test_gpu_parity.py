@@ -362,6 +362,86 @@ def test_shards_with_replicated_noise_equal_the_full_batch():
         torch.testing.assert_close(part['x'], full['x'][nidx], rtol=1e-5, atol=1e-5)
 
 
+def _gloo_rank_on_shared_gpu(rank, world, port, sizes, T, seed, q):
+    """One of `world` processes sharing the box's single GPU: its own HIP context, engine and workspace; process group over gloo
+    (RCCL refuses two ranks on one device), the data path's one collective on device tensors."""
+    import os
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import flowmol_amd as flowmol
+        from flowmol_amd import shard
+        model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+        n_atoms = torch.tensor(sizes)
+        out = {}
+        for mode in ('replicated', 'philox'):
+            torch.manual_seed(seed)
+            full, _ = model.sample_distributed(n_atoms, n_timesteps=T, return_tensors=True, noise=mode)
+            out[mode] = {k: v.numpy().copy() for k, v in full.items()}
+        mine = n_atoms[shard.partition_lpt(n_atoms, world)[rank]]
+        q.put((rank, out, int(mine.numel()), int(mine.sum() * 14 + (mine * (mine - 1) // 2).sum())))
+    except Exception as e:          # the parent must not wait for its timeout
+        q.put((rank, repr(e), 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_process_group_on_one_gpu_equals_single_process_sample():
+    """BASELINE configs[3]'s process layout as far as one GPU allows (VERDICT r3 #1b): EIGHT ranks (one process each, gloo process group,
+    all on this box's one MI355X) run FlowMol.sample_distributed on a 512-molecule job with sizes drawn from the shipped GEOM-drugs
+    histogram: LPT parts of unequal length, packed payloads of odd sizes, one all-gather.  noise='replicated' must reproduce the
+    single-process sample() of the same seed (tokens identical, coordinates to float summation order); noise='philox' -- what a
+    throughput run uses -- must reproduce the single-process Philox sample token for token (per-molecule streams keyed by the original
+    molecule index).  What stays untested after this is only the RCCL/xGMI transport between eight devices."""
+    import socket
+    import torch.multiprocessing as mp
+    import flowmol_amd as flowmol
+    from flowmol_amd.model import load_n_atoms_hist
+    from flowmol_amd import shard
+    world, T, seed = 8, 8, 41
+    vals, counts = load_n_atoms_hist('geom_full_kekulized')
+    n_atoms = vals[torch.multinomial(counts.double(), 64 * world, replacement=True, generator=torch.Generator().manual_seed(4))]
+    parts = shard.partition_lpt(n_atoms, world)
+    assert len({len(p_) for p_ in parts}) > 1                                  # unequal shard lengths
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    single = {}
+    torch.manual_seed(seed)
+    single['replicated'], _ = model.sample(n_atoms, n_timesteps=T, return_tensors=True)
+    torch.manual_seed(seed)
+    single['philox'], _ = model.sample(n_atoms, n_timesteps=T, return_tensors=True, rng='philox')
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_rank_on_shared_gpu, args=(r, world, port, n_atoms.tolist(), T, seed, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    try:
+        got = [q.get(timeout=900) for _ in procs]
+    finally:
+        for p_ in procs:
+            p_.join(timeout=120)
+            if p_.is_alive():
+                p_.kill()
+    errs = [g_ for g_ in got if isinstance(g_[1], str)]
+    assert not errs, errs
+    res = {r: d for r, d, _, _ in got}
+    payloads = sorted(pb for _, _, _, pb in got)
+    rep = {'ranks': world, 'molecules': int(n_atoms.numel()), 'molecules_per_rank': sorted(m for _, _, m, _ in got), 'payload_bytes_min_max': [payloads[0], payloads[-1]]}
+    for mode in ('replicated', 'philox'):
+        for r in range(1, world):
+            for k in 'xace':
+                assert np.array_equal(res[0][mode][k], res[r][mode][k]), (mode, r, k)          # every rank holds the same gathered batch
+        full = {k: torch.from_numpy(v) for k, v in res[0][mode].items()}
+        for k in 'ace':
+            assert torch.equal(full[k], single[mode][k]), (mode, k, int((full[k] != single[mode][k]).sum()))
+        rep[f'{mode}_x_max_abs_diff'] = float((full['x'] - single[mode]['x']).abs().max())
+        torch.testing.assert_close(full['x'], single[mode]['x'], rtol=1e-5, atol=1e-5)
+    _report('eight_ranks_one_gpu', rep)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # round 2: edge cases by construction, bench-size parity, packaging / CLI content, RCCL
 # ----------------------------------------------------------------------------------------------------------------------
@@ -417,14 +497,22 @@ def test_misc_campbell_fixture_through_the_kernel(golden_dir):
         assert torch.equal(smp['a1'].cpu().long(), g[f'ctmc.{case}.x1']), case
 
 
-def test_c3_size_forward_matches_oracle_on_selected_molecules():
-    """BASELINE configs[2] at FULL batch size (1024 molecules x 47 atoms: 48,128 nodes, 2.2 M directed edges): one network
-    evaluation at t = 0.5 with a previous endpoint; molecules 0, 127 | 128 (either side of the first XCD tile-chunk boundary:
-    69,184 tiles / 8 XCDs = 8,648 tiles = 128 molecules), 600 and 1023 are compared with the oracle run on each molecule ALONE,
-    per stage (node state after every conv, positions after every update, the last edge features) and on the outputs --
+@pytest.mark.parametrize('B,mols', [
+    (1024, (0, 127, 128, 600, 1023)),
+    # BASELINE configs[3]'s WHOLE job bound on one GPU (VERDICT r3 #1a): 8192 molecules = 385,024 nodes, 17.7 M directed edges, ef = 9.07 GB
+    # (13.3 GB workspace) -- the first oracle comparison past 4 GiB of edge state: the far end of the batch (molecule 8191's ef rows start
+    # 9.06 GB into the buffer), both sides of the middle (4095 | 4096), an XCD tile-chunk boundary (553,472 tiles / 8 = 1024 molecules) and
+    # the first molecule whose ef rows lie beyond 2^32 bytes (3880).
+    (8192, (0, 1023, 1024, 3879, 3880, 4095, 4096, 8191)),
+])
+def test_full_size_forward_matches_oracle_on_selected_molecules(B, mols):
+    """BASELINE configs[2] at FULL batch size (1024 molecules x 47 atoms: 48,128 nodes, 2.2 M directed edges) and configs[3]'s 8192-molecule
+    job on ONE GPU: one network evaluation at t = 0.5 with a previous endpoint; the listed molecules (1024: 0, 127 | 128 = either side of the
+    first XCD tile-chunk boundary, 69,184 tiles / 8 XCDs = 8,648 tiles = 128 molecules, 600 and 1023) are compared with the oracle run on each
+    molecule ALONE, per stage (node state after every conv, positions after every update, the last edge features) and on the outputs --
     norm-wise like the small-batch tests and element-wise (atol + rtol) on the outputs."""
     cfg, sd, eng, orc = engine_for('flowmol3')
-    B, n = 1024, 47
+    n = 47
     u = n * (n - 1) // 2
     n_atoms = torch.full((B,), n)
     eng.bind(n_atoms)
@@ -454,7 +542,9 @@ def test_c3_size_forward_matches_oracle_on_selected_molecules():
     # internal (destination-major) index of the reference's edge (src, dst) inside one molecule
     src, dst = batch1.src, batch1.dst
     internal = dst * (n - 1) + (src - (src > dst).long())
-    for m in (0, 127, 128, 600, 1023):
+    if B == 8192:
+        assert E * 512 > 2 ** 33 and eng.workspace_bytes > 12 << 30
+    for m in mols:
         ns_, ps_ = slice(m * n, (m + 1) * n), slice(m * u, (m + 1) * u)
         a1h, c1h, e1h = onehots(cfg, batch1, a[ns_], c[ns_], eu[ps_])
         orc.taps = {}
@@ -478,9 +568,12 @@ def test_c3_size_forward_matches_oracle_on_selected_molecules():
         got = out['e'][ps_].cpu()
         worst['out.e'] = max(worst.get('out.e', 0.0), float((got - ref['e']).abs().max() / ref['e'].abs().max()))
         torch.testing.assert_close(got, ref['e'], rtol=2e-4, atol=2e-6)
-    _report('c3_size_forward', worst)
+    _report('c3_size_forward' if B == 1024 else f'c4_whole_job_forward[{B}x{n}]', {**worst, 'ef_bytes': E * 512, 'workspace_bytes': eng.workspace_bytes})
     bad = {k: v for k, v in worst.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
     assert not bad, worst
+    if B == 8192:       # release the 13 GB of taps (the cached engine keeps its 13 GB workspace for the next 8192-molecule test)
+        del bufs, out, state
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [5, 9, 12, 3, 2], 0.5, True), ('flowmol3', [70, 2, 47, 130], 0.3, True),
@@ -957,18 +1050,27 @@ def test_c5_full_size_trajectory_properties():
     assert len(blocks) == 500 and blocks[0].count('Se') == int(n_atoms[3])                    # frame 0: every atom still masked
 
 
-def test_c3_full_batch_reproduces_reference_long_trajectory(golden_dir):
+@pytest.mark.parametrize('B,slots,n_steps', [
+    (1024, (0, 127, 128, 511, 600, 895, 896, 1023), None),
+    # BASELINE configs[3]'s whole 8192-molecule job bound on ONE GPU (VERDICT r3 #1a): the reference's eight molecules sit at both ends, either
+    # side of the middle, either side of XCD tile-chunk boundaries (1024 molecules per chunk) and beyond 2^32 bytes of edge state; the first
+    # 26 integration steps (bootstrap + 25 self-conditioned evaluations, 0.55 s each) against the reference's trajectory, every token of every step
+    (8192, (0, 1023, 1024, 3880, 4095, 4096, 7168, 8191), 26),
+])
+def test_full_batch_reproduces_reference_long_trajectory(golden_dir, B, slots, n_steps):
     """BASELINE configs[2] at FULL size AND full horizon against the reference: a 1024 x 47-atom batch integrated for 250 steps in which
     eight molecules -- placed at both ends of the batch, either side of XCD tile-chunk boundaries (127|128, 895|896) and mid-chunk -- carry the
     prior and the per-step noise of tests/golden/long_flowmol3_47x8_T250.npz (the reference's own 8-molecule run), while the other 1016
     molecules draw their own.  Molecules never interact, so those eight must reproduce the reference's trajectory: every state token of every
-    step, final coordinates within 1e-4 -- parity at the size and horizon the metric is quoted on, not only on an 8-molecule batch."""
+    step, final coordinates within 1e-4 -- parity at the size and horizon the metric is quoted on, not only on an 8-molecule batch.
+    The 8192-molecule case is configs[3]'s job on one GPU, over the first ``n_steps`` steps of the same trajectory."""
     from flowmol_amd.engine import IntegrationRun, StepNoise, make_step_plan
     cfg, sd, eng, orc = engine_for('flowmol3')
     g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / 'long_flowmol3_47x8_T250.npz').items()}
-    T, n, B = int(g['T']), 47, 1024
+    T, n = int(g['T']), 47
+    K = T - 1 if n_steps is None else n_steps            # integration steps run here
     u = n * (n - 1) // 2
-    slots = torch.tensor([0, 127, 128, 511, 600, 895, 896, 1023])
+    slots = torch.tensor(slots)
     node_rows = (slots[:, None] * n + torch.arange(n)[None]).flatten().cuda()
     pair_rows = (slots[:, None] * u + torch.arange(u)[None]).flatten().cuda()
     eng.bind(torch.full((B,), n))
@@ -990,24 +1092,34 @@ def test_c3_full_batch_reproduces_reference_long_trajectory(golden_dir):
                 t[pair_rows if k.endswith('_e') else node_rows] = getattr(small, k).cuda()
         return big
     i32 = dict(dtype=torch.int32, device='cuda:0')
-    traj = {'x': torch.zeros(T - 1, N, 3, device='cuda:0'), 'a': torch.zeros(T - 1, N, **i32), 'c': torch.zeros(T - 1, N, **i32)}
+    traj = {'x': torch.zeros(K, N, 3, device='cuda:0'), 'a': torch.zeros(K, N, **i32), 'c': torch.zeros(K, N, **i32), 'e': torch.zeros(K, U, **i32)}
     run = IntegrationRun(eng, state, plan, noise_for_step, traj=traj)
-    run.run(0, T - 1, chunk=16)
+    run.run(0, K, chunk=16)
     eng.synchronize()
     nr, pr = node_rows.cpu(), pair_rows.cpu()
-    res = {'a_flips': int((state['a_t'].cpu()[nr].long() != g['a_1'].long()).sum()), 'c_flips': int((state['c_t'].cpu()[nr].long() != g['c_1'].long()).sum()),
-           'e_flips': int((state['e_t'].cpu()[pr].long() != g['e_1_upper'].long()).sum()),
-           'x_rel': float((state['x_t'].cpu()[nr] - g['x_1']).abs().max() / g['x_1'].abs().max()),
-           'a_state_diffs_all_steps': int((traj['a'][:, node_rows].cpu().long() != g['traj.a'][1:].long()).sum()),
-           'c_state_diffs_all_steps': int((traj['c'][:, node_rows].cpu().long() != g['traj.c'][1:].long()).sum())}
+    res = {'steps': K,
+           'a_state_diffs_all_steps': int((traj['a'][:, node_rows].cpu().long() != g['traj.a'][1:K + 1].long()).sum()),
+           'c_state_diffs_all_steps': int((traj['c'][:, node_rows].cpu().long() != g['traj.c'][1:K + 1].long()).sum()),
+           'e_state_diffs_all_steps': int((traj['e'][:, pair_rows].cpu().long() != g['traj.e'][1:K + 1].long()).sum())}
     st = int(g['traj.x_stride'])
     got = traj['x'][st - 1::st][:, node_rows].cpu()
-    ref = g['traj.x'][1:]
+    ref = g['traj.x'][1:1 + got.shape[0]]
     res['x_frames_rel'] = float((got[:ref.shape[0]] - ref).abs().max() / ref.abs().max())
-    _report('c3_full_batch_long', res)
-    assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and res['a_state_diffs_all_steps'] == 0 and res['c_state_diffs_all_steps'] == 0, res
-    assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4, res
-    assert torch.isfinite(state['x_t']).all() and (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()
+    norms = traj['x'][:, node_rows].reshape(K, 8, n * 3).norm(dim=2).cpu()              # (K, 8): per-molecule coordinate norm after every step
+    res['x_norm_rel'] = float(((norms - g['traj.x_norm'][1:K + 1]).abs() / g['traj.x_norm'][1:K + 1]).max())
+    if K == T - 1:
+        res.update({'a_flips': int((state['a_t'].cpu()[nr].long() != g['a_1'].long()).sum()), 'c_flips': int((state['c_t'].cpu()[nr].long() != g['c_1'].long()).sum()),
+                    'e_flips': int((state['e_t'].cpu()[pr].long() != g['e_1_upper'].long()).sum()),
+                    'x_rel': float((state['x_t'].cpu()[nr] - g['x_1']).abs().max() / g['x_1'].abs().max())})
+    _report('c3_full_batch_long' if B == 1024 else f'c4_whole_job_long[{B}x{n},{K} steps]', res)
+    assert res['a_state_diffs_all_steps'] == 0 and res['c_state_diffs_all_steps'] == 0 and res['e_state_diffs_all_steps'] == 0, res
+    assert res['x_frames_rel'] < 1e-4 and res['x_norm_rel'] < 1e-4, res
+    assert torch.isfinite(state['x_t']).all()
+    if K == T - 1:
+        assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and res['x_rel'] < 1e-4, res
+        assert (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()
+    del traj
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc')])
