@@ -190,28 +190,297 @@ def host_cpu_info():
     return {'model': model, 'physical_cores': len(phys) or None, 'sockets': len({p for p, _ in phys}) or None, 'logical_cpus': os.cpu_count()}
 
 
-def cpu_baseline(cfg, sd, sizes, steps, T, evals):
+def _cost_sample(all_sizes, k):
+    """k molecules of the workload whose mean cost n(n-1) represents it (ADVICE r3: the first k molecules of a ragged workload can be
+    20 % off): every (B/k)-th molecule of the list sorted by size, mid-quantiles.  Fixed-size workloads: the first k."""
+    B = int(all_sizes.numel())
+    k = min(k, B)
+    if bool((all_sizes == all_sizes[0]).all()):
+        return all_sizes[:k].clone()
+    order = torch.argsort(all_sizes, stable=True)
+    pick = ((torch.arange(k, dtype=torch.float64) + 0.5) * B / k).long().clamp_(max=B - 1)
+    return all_sizes[order[pick]].clone()
+
+
+def cpu_baseline(cfg, sd, all_sizes, cpu_mols, steps, T, evals, ref_batch=128, ref_steps=2):
     """Time the CPU oracle (the op-for-op restatement of the reference's PyTorch path, oracle/cpu_ref.py; bit-identical to the reference's
-    own modules over whole trajectories, profiles/r03a_oracle_long_parity.jsonl) on this box's host cores on a bounded sample of the same
-    workload.  The intra-op thread count is chosen by a probe AT THE BATCH SIZE THAT IS TIMED (2 steps per candidate): torch with one
-    thread per logical CPU of a many-core host oversubscribes these operators badly, and the best count depends on the operand sizes."""
+    own modules over whole trajectories, profiles/r03a_oracle_long_parity.jsonl) on this box's host cores on bounded samples of the same
+    workload: (a) `cpu_mols` molecules (16: the sample of rounds 1-3) and (b) the reference's own batch size, test.py:30
+    `--max_batch_size 128` -- the headline `value` is (b), the rate a user of the reference's CPU path would see.  The intra-op thread
+    count is chosen by a probe AT THE BATCH SIZE THAT IS TIMED: torch with one thread per logical CPU of a many-core host oversubscribes
+    these operators badly, and the best count depends on the operand sizes.  Ragged workloads: a cost-representative quantile sample,
+    and the rate is rescaled by the sample's mean n(n-1) over the workload's."""
     ncpu = os.cpu_count() or 1
-    B = int(sizes.numel())
-    cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu < 8 else set()))
-    probe = {}
-    for c in cands:          # ascending; stop once more threads are clearly slower (256 threads on the 2 x 64-core host: 190 s per step, r03a)
-        probe[c] = _cpu_steps(cfg, sd, sizes, 2, T, c)
-        if probe[c] > 1.5 * min(probe.values()):
-            break
-    best = min(probe, key=probe.get)
-    per_step = _cpu_steps(cfg, sd, sizes, steps, T, best)
-    desc = f'{B} molecules x {int(sizes[0])} atoms' if bool((sizes == sizes[0]).all()) else f'the first {B} molecules of the workload ({int(sizes.min())}-{int(sizes.max())} atoms, mean {float(sizes.double().mean()):.1f})'
     host = host_cpu_info()
-    return {'value': B / (evals * per_step), 'unit': 'molecules/s', 'cores': best, 'kind': 'port', 'host': host,
-            'sample': f'{desc}, {steps} timed integration steps after 1 warm-up step '
-                      f'({per_step * 1e3:.0f} ms/step) with {best} torch threads (best of {sorted(probe)}, each probed with 2 steps of the same {B}-molecule batch; '
-                      f"host: {host['model']}, {host['physical_cores']} physical cores / {ncpu} logical CPUs), extrapolated linearly to {evals} network evaluations per sample",
-            'ms_per_step': per_step * 1e3, 'thread_probe_ms_per_step': {str(k): v * 1e3 for k, v in probe.items()}}
+    phys = host.get('physical_cores') or ncpu
+    cost_all = float((all_sizes * (all_sizes - 1)).double().mean())
+
+    def describe(sizes):
+        B = int(sizes.numel())
+        if bool((sizes == sizes[0]).all()):
+            return f'{B} molecules x {int(sizes[0])} atoms'
+        return f'a size-quantile sample of {B} molecules of the workload ({int(sizes.min())}-{int(sizes.max())} atoms, mean {float(sizes.double().mean()):.1f})'
+
+    def one(sizes, cands, probe_steps, timed_steps):
+        probe = {}
+        for c in cands:          # ascending; stop once more threads are clearly slower (256 threads on the 2 x 64-core host: 190 s per step, r03a)
+            probe[c] = _cpu_steps(cfg, sd, sizes, probe_steps, T, c)
+            if probe[c] > 1.5 * min(probe.values()):
+                break
+        best = min(probe, key=probe.get)
+        per_step = _cpu_steps(cfg, sd, sizes, timed_steps, T, best) if timed_steps else probe[best]
+        B = int(sizes.numel())
+        ratio = float((sizes * (sizes - 1)).double().mean()) / cost_all            # 1 for fixed-size workloads
+        return {'value': B / (evals * per_step) * ratio, 'molecules': B, 'cores': best, 'ms_per_step': per_step * 1e3,
+                'sample_cost_over_workload_cost': ratio, 'thread_probe_ms_per_step': {str(k): v * 1e3 for k, v in probe.items()},
+                'sample': f'{describe(sizes)}, {timed_steps or probe_steps} timed integration steps after 1 warm-up step ({per_step * 1e3:.0f} ms/step) with {best} torch threads '
+                          f'(best of {sorted(probe)}, each probed with {probe_steps} step(s) of the same batch)'}
+    small = one(_cost_sample(all_sizes, cpu_mols), sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu < 8 else set())), 2, steps)
+    out = dict(small)
+    big = None
+    if ref_batch and int(all_sizes.numel()) >= ref_batch and ref_batch > cpu_mols:
+        # the reference's protocol batches 128 molecules (test.py:30); larger operands pay for more threads, so the probe goes up to the
+        # physical core count.  Probe steps double as the timed steps (2 per candidate after a warm-up step).
+        cands = sorted({c for c in (small['cores'], 32, 64, phys) if small['cores'] <= c <= min(phys, ncpu)})
+        big = one(_cost_sample(all_sizes, ref_batch), cands, ref_steps, 0)
+        out = dict(big)
+    out.update({'unit': 'molecules/s', 'kind': 'port', 'host': host,
+                'sample': out['sample'] + f"; host: {host['model']}, {host['physical_cores']} physical cores / {ncpu} logical CPUs; extrapolated linearly to {evals} network evaluations per sample"
+                          + ('' if out['sample_cost_over_workload_cost'] == 1 else '; rate rescaled by the sample\'s mean n(n-1) over the workload\'s'),
+                'at_16_molecules': small if big is not None else None,
+                'batch_note': ('value = the reference protocol\'s batch of 128 molecules (test.py:30 --max_batch_size); at_16_molecules = the sample of rounds 1-3'
+                               if big is not None else f'{small["molecules"]}-molecule sample')})
+    return out
+
+
+WORKLOADS = {'c3': dict(preset='flowmol3', mols=1024, n=47, T=250, traj=False, label='BASELINE.json configs[2]; configs[3] at 8 GPUs'),
+             'c2': dict(preset='qm9', mols=256, n=18, T=100, traj=False, label='BASELINE.json configs[1]'),
+             'c5': dict(preset='geom_ctmc', mols=128, n=None, T=500, traj=True, label='BASELINE.json configs[4], trajectory sink on (--xt_traj / --ep_traj)')}
+KERNEL_NAMES = ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head', 'node_head', 'sc',
+                'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step', 'pair_slab')
+
+
+def job_sizes(world, B, n, size_dist):
+    """The job's molecules: ONE global list (world * B molecules) dealt to the ranks.  Fixed-size workloads give every rank B molecules;
+    ragged workloads (--size-dist, c5) are sharded by cost with shard.partition_lpt, exactly as FlowMol.sample_distributed does, so a
+    multi-GPU run shows the real load imbalance of the size distribution (max over ranks is what is timed)."""
+    from flowmol_amd import shard
+    if size_dist is not None:
+        from flowmol_amd.model import load_n_atoms_hist
+        vals, counts = load_n_atoms_hist(size_dist)
+        all_sizes = vals[torch.multinomial(counts.double(), B * world, replacement=True, generator=torch.Generator().manual_seed(1000))]
+    elif n is None:          # c5: 128 molecules per GPU, randint(5, 61) with seed 0 (SURVEY.md section 8d)
+        all_sizes = torch.randint(5, 61, (B * world,), generator=torch.Generator().manual_seed(0))
+    else:
+        all_sizes = torch.full((B * world,), n, dtype=torch.int64)
+    ragged = bool((all_sizes != all_sizes[0]).any())
+    parts = shard.partition_lpt(all_sizes, world) if (ragged and world > 1) else [torch.arange(r * B, (r + 1) * B) for r in range(world)]
+    return all_sizes, parts, ragged
+
+
+class Leg:
+    """One workload bound on this rank's engine: a real trajectory advanced in windows of steps."""
+
+    def __init__(self, eng, cfg, n_atoms, T, traj, rank, dev):
+        from flowmol_amd.engine import IntegrationRun, StepNoise, make_step_plan
+        self.eng, self.cfg, self.dev, self.rank = eng, cfg, dev, rank
+        eng.bind(n_atoms)
+        self.N, self.U, self.E = eng.N, eng.U, eng.E
+        N, U = self.N, self.U
+        self.plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+        self.n_plan = len(self.plan.scalars)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(2 + rank)
+        self.traj = None
+        if traj:          # c5: the per-step frames go to the trajectory sink during the timed steps (compact format: fp32 x + int32 tokens)
+            i32 = dict(dtype=torch.int32, device=dev)
+            n_plan = self.n_plan
+            self.traj = {'x': torch.empty(n_plan, N, 3, device=dev), 'a': torch.empty(n_plan, N, **i32), 'c': torch.empty(n_plan, N, **i32), 'e': torch.empty(n_plan, U, **i32),
+                         'x1': torch.empty(n_plan, N, 3, device=dev), 'a1': torch.empty(n_plan, N, **i32), 'c1': torch.empty(n_plan, N, **i32), 'e1': torch.empty(n_plan, U, **i32)}
+        self.state = self.fresh_state()
+        self.run = IntegrationRun(eng, self.state, self.plan,
+                                  lambda i, last: StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, generator=gen), traj=self.traj)
+        self.pos = 0
+
+    def fresh_state(self):
+        g0 = torch.Generator(device=self.dev)
+        g0.manual_seed(1 + self.rank)
+        x0 = torch.randn(self.N, 3, device=self.dev, generator=g0)
+        self.eng.remove_com(x0)
+        return self.eng.prior_state(x0)
+
+    def advance(self, k):
+        """k consecutive steps of the trajectory; a new trajectory starts from the prior when one ends."""
+        while k > 0:
+            if self.pos >= self.n_plan:
+                self.state = self.fresh_state()
+                self.run.reset(self.state)
+                self.pos = 0
+            m = min(k, self.n_plan - self.pos)
+            self.run.run(self.pos, self.pos + m, chunk=16)
+            self.pos += m
+            k -= m
+
+    def kernel_times(self, steps=2):
+        """Per-kernel averages from a separate HIP-event-instrumented pass (events on the launch stream).  Every profiled step also times an
+        EMPTY kernel ('event_overhead'): what an event pair adds to a launch.  avg_us = raw pair time - that overhead, which makes the
+        figure comparable with rocprofv3's kernel durations also for the sub-millisecond kernels of small batches (VERDICT r3 weak #9)."""
+        eng = self.eng
+        eng.profile(True)
+        self.advance(steps)
+        torch.cuda.synchronize(self.dev)
+        ms, cnt = eng.profile_get('event_overhead')
+        ovh = ms * 1e3 / cnt if cnt else 0.0
+        kern = {}
+        for k in KERNEL_NAMES:
+            ms, cnt = eng.profile_get(k)
+            if cnt:
+                raw = ms * 1e3 / cnt
+                kern[k] = {'avg_us': max(raw - ovh, 0.0), 'raw_event_pair_us': raw, 'launches_per_step': cnt / steps}
+        eng.profile(False)
+        return kern, ovh
+
+
+def message_roofline(cfg, E, N, us, pmc=None, lib_digest=None):
+    """Roofline object of the dominant kernel (fm_k_edge_message) for one launch of E edges taking `us` microseconds."""
+    ex = executed_macs(cfg)
+    flops = conv_message_flops_per_edge(cfg.n_vec_channels) * E
+    ex_flops = 2 * ex['edge_message_per_edge'] * E
+    ach = flops / (us * 1e-6) / 1e12
+    stale = bool(pmc) and pmc.get('library_digest') != lib_digest
+    traffic = pmc['hbm_bytes_per_launch'] if (pmc and not stale) else None
+    busy = pmc.get('mfma_busy_frac') if (pmc and not stale) else None
+    return {'bound': 'mfma', 'kernel': 'fm_k_edge_message', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
+            'traffic_source': (f"committed profile {pmc['source']} (library digest {pmc.get('library_digest')} = this run's): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
+                               f"rocprofv3 PMC with the gfx950 FETCH correction; not measured by this run") if traffic else
+                              (f"committed counters were measured on library digest {pmc.get('library_digest')}, this run is {lib_digest}: not quoted" if stale else None),
+            'algorithmic_bytes_per_launch': E * (512 + 8) + N * 4 * (256 + 3 * cfg.n_vec_channels) * 2,
+            'avg_launch_us': us,
+            'hbm_gb_per_s': (traffic / (us * 1e-6) / 1e9) if traffic else None,
+            'hbm_frac_of_8tb_per_s': (traffic / (us * 1e-6) / 8e12) if traffic else None,
+            'algorithmic_flop_per_launch': flops,
+            'executed_flop_per_launch': ex_flops,
+            'executed_tflops': ex_flops / (us * 1e-6) / 1e12,
+            'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
+            'mfma_busy_frac': busy,
+            'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})" if busy else None),
+            'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
+                    'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
+                    f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
+                    'avg_launch_us = HIP-event pair on the launch stream minus the measured pair overhead (an empty kernel timed the same way in the same pass); '
+                    'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
+
+
+def load_pmc(workload, N, E, ok):
+    try:
+        pj = json.loads((ROOT / 'profiles' / 'current_pmc.json').read_text()).get(workload)
+        if pj and pj['nodes_per_gpu'] == N and pj['directed_edges_per_gpu'] == E and ok:
+            return pj
+    except Exception:
+        pass
+    return None
+
+
+def secondary_legs(engines, dev, lib_digest, steps):
+    """The rest of BASELINE.json's metric in the same driver-run line (VERDICT r3 #2): GEOM-drugs size distribution, configs[1] (C2),
+    configs[4] (C5, trajectory sink on) and the per-step latency at 1 / 8 / 32 / 128 molecules -- each a bounded window of a real trajectory
+    on one GPU, with its own ms_per_step, molecules/s and the roofline of its dominant kernel."""
+    from flowmol_amd import presets, weights
+    from flowmol_amd.engine import Engine
+
+    def engine(preset):
+        if preset not in engines:
+            cfg = presets.PRESETS[preset]()
+            engines[preset] = (cfg, Engine(cfg, weights.synth_state_dict(cfg, 0), device=dev, precision='f32'))
+        return engines[preset]
+
+    def leg(name, preset, sizes, T, traj, label, k_steps, warm=3):
+        cfg, eng = engine(preset)
+        L = Leg(eng, cfg, sizes, T, traj, 0, dev)
+        L.advance(warm)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        L.advance(k_steps)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) * 1e3 / k_steps
+        kern, ovh = L.kernel_times(2)
+        evals = T if cfg.self_conditioning else T - 1
+        B = int(sizes.numel())
+        o = {'workload': label, 'molecules': B, 'nodes': L.N, 'directed_edges': L.E, 'n_timesteps': T, 'steps': k_steps, 'warmup': warm, 'ms_per_step': ms,
+             'value': B / (evals * ms / 1e3), 'unit': f'molecules/s at {T} timesteps', 'network_evaluations_per_sample': evals, 'trajectory_sink': bool(traj),
+             'finite': bool(torch.isfinite(L.state['x_t']).all().item()), 'event_pair_overhead_us': ovh,
+             'kernels_us': {k: round(v['avg_us'], 1) for k, v in kern.items()}, 'launches_per_step': sum(v['launches_per_step'] for v in kern.values())}
+        if 'edge_message' in kern:
+            r = message_roofline(cfg, L.E, L.N, kern['edge_message']['avg_us'], load_pmc(name, L.N, L.E, True), lib_digest)
+            o['roofline'] = {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us', 'executed_frac', 'mfma_busy_frac')}
+            o['dominant_kernel_share_of_step'] = kern['edge_message']['avg_us'] * kern['edge_message']['launches_per_step'] / (ms * 1e3)
+        del L
+        return o
+    out = {}
+    sd_sizes, _, _ = job_sizes(1, 1024, None, 'geom_full_kekulized')
+    out['geom_size_dist'] = leg('geom_size_dist', 'flowmol3', sd_sizes, 250, False,
+                                f'flowmol3 model, 1024 molecules with sizes ~ the shipped GEOM-drugs histogram (seed 1000: mean {float(sd_sizes.double().mean()):.1f}, max {int(sd_sizes.max())} atoms), n_timesteps=250 '
+                                '(the metric\'s "GEOM-drugs size dist"; reference flowmol.py:461-471)', steps)
+    out['c2'] = leg('c2', 'qm9', torch.full((256,), 18, dtype=torch.int64), 100, False, 'qm9 model, 256 molecules x 18 atoms, n_timesteps=100 (BASELINE.json configs[1])', 4 * steps)
+    c5_sizes, _, _ = job_sizes(1, 128, None, None)
+    out['c5'] = leg('c5', 'geom_ctmc', c5_sizes, 500, True, 'geom_ctmc model, 128 molecules with sizes randint(5, 61, seed 0), n_timesteps=500, trajectory sink on (BASELINE.json configs[4])', 4 * steps)
+    sweep = []
+    for B in (1, 8, 32, 128):
+        o = leg(f'latency_{B}', 'flowmol3', torch.full((B,), 47, dtype=torch.int64), 250, False, f'flowmol3 model, {B} molecule(s) x 47 atoms: per-step network-evaluation latency', 64, warm=8)
+        sweep.append({k: o[k] for k in ('molecules', 'ms_per_step', 'value', 'steps', 'launches_per_step', 'kernels_us', 'event_pair_overhead_us', 'workload')
+                      } | {'roofline': o.get('roofline')})
+    out['latency_sweep'] = sweep
+    out['note'] = ('secondary legs of the same run (rank 0, one GPU): windows of real trajectories after the headline leg; ms_per_step = wall clock over `steps` consecutive '
+                   'integration steps between device synchronisations; value = molecules / (network evaluations per sample x ms_per_step)')
+    return out
+
+
+def bind_rank_to_gpu_socket(dev_index):
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node (8 ranks enqueue ~22 launches per 66 ms step each; a rank whose
+    thread migrates to the other socket pays for every descriptor write).  Best effort: returns what was found / done."""
+    info = {'device_index': dev_index, 'numa_node': None, 'cpus_bound': None}
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = f'{getattr(p, "pci_domain_id", 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        info['pci'] = bdf
+        node = int(Path(f'/sys/bus/pci/devices/{bdf}/numa_node').read_text())
+        info['numa_node'] = node
+        if node >= 0:
+            cpus = set()
+            for part in Path(f'/sys/devices/system/node/node{node}/cpulist').read_text().strip().split(','):
+                a, _, b = part.partition('-')
+                cpus.update(range(int(a), int(b or a) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                info['cpus_bound'] = len(cpus)
+    except Exception as e:          # containers without /sys, devices without a NUMA entry: run unpinned
+        info['note'] = f'not pinned: {type(e).__name__}'
+    return info
+
+
+def dry_run(args):
+    """`bench.py --gpus N --dry-run`: the N-rank plan without touching a GPU -- molecules and cost per rank, payload bytes of the one
+    all-gather, the device each rank would take and the launch line."""
+    world = args.gpus
+    all_sizes, parts, ragged = job_sizes(world, args.mols_per_gpu, args.n_atoms, args.size_dist)
+    cost = (all_sizes * (all_sizes - 1)).double()
+    plan = []
+    for r, p_ in enumerate(parts):
+        nr = all_sizes[p_]
+        N, U = int(nr.sum()), int((nr * (nr - 1) // 2).sum())
+        plan.append({'rank': r, 'device': f'cuda:{r} (LOCAL_RANK)', 'molecules': int(len(p_)), 'nodes': N, 'directed_edges': 2 * U, 'cost': float(cost[p_].sum()),
+                     'gather_payload_bytes': N * 14 + U, 'ef_bytes': 2 * U * 512})
+    costs = torch.tensor([p_['cost'] for p_ in plan])
+    slot = (max(p_['gather_payload_bytes'] for p_ in plan) + 15) // 16 * 16
+    out = {'dry_run': True, 'n_gpus': world, 'workload': args.workload, 'global_molecules': int(all_sizes.numel()), 'ragged': ragged,
+           'shard_cost_max_over_mean': float(costs.max() / costs.mean()), 'all_gather_slot_bytes': slot, 'all_gather_total_bytes': slot * world,
+           'ranks': plan, 'gpus_visible_here': torch.cuda.device_count(),
+           'launch': f'python -m torch.distributed.run --nnodes=1 --nproc-per-node {world} --master-addr 127.0.0.1 --master-port P bench.py --gpus {world} --steps {args.steps} --warmup {args.warmup}',
+           'backend': 'nccl (RCCL over xGMI); one process per GPU; no collective during integration, ONE all_gather_into_tensor at the end',
+           'parity_check_for_the_first_multi_gpu_run': "FlowMol.sample_distributed(n_atoms, noise='replicated') on N ranks == sample(n_atoms) on one (tests/test_gpu_parity.py::test_eight_rank_process_group_on_one_gpu_equals_single_process_sample runs it with 8 gloo ranks on one GPU)"}
+    print(json.dumps(out))
 
 
 def main():
@@ -232,16 +501,20 @@ def main():
                     help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
                          "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) -- a separately reported mode")
     ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (size distribution, C2, C5, latency sweep) of the default one-GPU run')
+    ap.add_argument('--secondary-steps', type=int, default=10, help='timed steps of the size-distribution leg (C2 / C5: 4x, latency sweep: 64)')
+    ap.add_argument('--dry-run', action='store_true', help='print the N-rank plan (molecules, cost, payload bytes, devices per rank) as one JSON line without touching a GPU')
     ap.add_argument('--cpu-mols', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=8)
+    ap.add_argument('--cpu-ref-batch', type=int, default=128, help="CPU baseline at the reference protocol's batch size (test.py:30); 0 = only the --cpu-mols sample")
     args = ap.parse_args()
-    wl = {'c3': dict(preset='flowmol3', mols=1024, n=47, T=250, traj=False, label='BASELINE.json configs[2]; configs[3] at 8 GPUs'),
-          'c2': dict(preset='qm9', mols=256, n=18, T=100, traj=False, label='BASELINE.json configs[1]'),
-          'c5': dict(preset='geom_ctmc', mols=128, n=None, T=500, traj=True, label='BASELINE.json configs[4], trajectory sink on (--xt_traj / --ep_traj)')}[args.workload]
+    wl = WORKLOADS[args.workload]
     args.preset = args.preset or wl['preset']
     args.mols_per_gpu = args.mols_per_gpu or wl['mols']
     args.n_atoms = args.n_atoms or wl['n']
     args.timesteps = args.timesteps or wl['T']
+    if args.dry_run:
+        return dry_run(args)
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         _self_launch(args)                 # never returns
@@ -258,6 +531,7 @@ def main():
     dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
+    affinity = bind_rank_to_gpu_socket(dev_index) if world > 1 else {'device_index': dev_index, 'note': 'single rank: not pinned'}
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -269,72 +543,25 @@ def main():
         world = dist.get_world_size()
 
     from flowmol_amd import presets, weights, shard
-    from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan
+    from flowmol_amd.engine import Engine
 
     cfg = presets.PRESETS[args.preset]()
     sd = weights.synth_state_dict(cfg, 0)
     eng = Engine(cfg, sd, device=dev, precision=args.precision)
     B, n, T = args.mols_per_gpu, args.n_atoms, args.timesteps
-    # ---- the job's molecules: ONE global list (world * B molecules) dealt to the ranks.  Fixed-size workloads give every rank B molecules;
-    #      ragged workloads (--size-dist, c5) are sharded by cost with shard.partition_lpt, exactly as FlowMol.sample_distributed does, so a
-    #      multi-GPU run shows the real load imbalance of the size distribution (max over ranks is what is timed).
-    if args.size_dist is not None:
-        from flowmol_amd.model import load_n_atoms_hist
-        vals, counts = load_n_atoms_hist(args.size_dist)
-        all_sizes = vals[torch.multinomial(counts.double(), B * world, replacement=True, generator=torch.Generator().manual_seed(1000))]
-    elif n is None:          # c5: 128 molecules per GPU, randint(5, 61) with seed 0
-        all_sizes = torch.randint(5, 61, (B * world,), generator=torch.Generator().manual_seed(0))
-    else:
-        all_sizes = torch.full((B * world,), n, dtype=torch.int64)
-    ragged = bool((all_sizes != all_sizes[0]).any())
-    parts = shard.partition_lpt(all_sizes, world) if (ragged and world > 1) else [torch.arange(r * B, (r + 1) * B) for r in range(world)]
+    all_sizes, parts, ragged = job_sizes(world, B, n, args.size_dist)
     n_atoms = all_sizes[parts[rank]]
     cost = (all_sizes * (all_sizes - 1)).double()
     shard_cost = torch.tensor([float(cost[p_].sum()) for p_ in parts])
-    eng.bind(n_atoms)
-    N, U, E = eng.N, eng.U, eng.E
-    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
-    n_plan = len(plan.scalars)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(2 + rank)
-
-    def fresh_state():
-        g0 = torch.Generator(device=dev)
-        g0.manual_seed(1 + rank)
-        x0 = torch.randn(N, 3, device=dev, generator=g0)
-        eng.remove_com(x0)
-        return eng.prior_state(x0)
-
-    def noise_for_step(i, last):
-        return StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, dev, generator=gen)
-
-    traj = None
-    if wl['traj']:          # c5: the per-step frames go to the trajectory sink during the timed steps (compact format: fp32 x + int32 tokens)
-        i32 = dict(dtype=torch.int32, device=dev)
-        traj = {'x': torch.empty(n_plan, N, 3, device=dev), 'a': torch.empty(n_plan, N, **i32), 'c': torch.empty(n_plan, N, **i32), 'e': torch.empty(n_plan, U, **i32),
-                'x1': torch.empty(n_plan, N, 3, device=dev), 'a1': torch.empty(n_plan, N, **i32), 'c1': torch.empty(n_plan, N, **i32), 'e1': torch.empty(n_plan, U, **i32)}
-    state = fresh_state()
-    run = IntegrationRun(eng, state, plan, noise_for_step, traj=traj)
-    pos = 0
-
-    def advance(k):
-        """k consecutive steps of the trajectory; a new trajectory starts from the prior when one ends."""
-        nonlocal pos, state
-        while k > 0:
-            if pos >= n_plan:
-                state = fresh_state()
-                run.reset(state)
-                pos = 0
-            m = min(k, n_plan - pos)
-            run.run(pos, pos + m, chunk=16)
-            pos += m
-            k -= m
+    leg = Leg(eng, cfg, n_atoms, T, wl['traj'], rank, dev)
+    N, U, E = leg.N, leg.U, leg.E
 
     def gather_all():
         """The single collective of the sampling path: packed results over RCCL/xGMI, every rank gets the whole batch."""
-        return shard.gather_results({'x': state['x_t'], 'a': state['a_t'], 'c': state['c_t'], 'e': state['e_t']}, all_sizes, parts)
+        st = leg.state
+        return shard.gather_results({'x': st['x_t'], 'a': st['a_t'], 'c': st['c_t'], 'e': st['e_t']}, all_sizes, parts)
 
-    advance(args.warmup)
+    leg.advance(args.warmup)
     if world > 1:
         gather_all()             # untimed warm-up of the collective (communicator setup, first-use kernel loads)
     torch.cuda.synchronize(dev)
@@ -342,7 +569,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    advance(args.steps)
+    leg.advance(args.steps)
     gather_ms = None
     if world > 1:   # inside the timed region: the job is not done until every rank holds the results
         torch.cuda.synchronize(dev)
@@ -357,6 +584,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     per_rank_ms = [own_elapsed * 1e3 / args.steps]
+    rank_info = [{'rank': rank, 'device': torch.cuda.get_device_name(dev_index), **affinity}]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -367,38 +595,25 @@ def main():
         every = flat.view(world, 2)
         per_rank_ms = every[:, 0].tolist()
         gather_ms = float(every[:, 1].max())
+        infos = [None] * world
+        dist.all_gather_object(infos, rank_info[0])
+        rank_info = infos
     ms_per_step = elapsed * 1e3 / args.steps
     evals = T if cfg.self_conditioning else T - 1      # network evaluations per sample: T-1 steps (+ the bootstrap evaluation of self-conditioned models)
     mols_per_s = B * world / (evals * ms_per_step / 1e3)
 
     # ---- per-kernel timing (HIP events on the launch stream) for the roofline of the dominant kernel: a separate
-    #      event-instrumented pass of 2 more steps AFTER the timed region (event pairs around every launch add ~1 % to
-    #      the step, so the sum of these averages slightly exceeds ms_per_step)
-    finite = bool(torch.isfinite(state['x_t']).all().item())
+    #      event-instrumented pass of 2 more steps AFTER the timed region
+    finite = bool(torch.isfinite(leg.state['x_t']).all().item())
     try:            # which build of the kernels produced this line: digest of csrc/ + header + flags (flowmol_amd/build.py), as in profiles/current_pmc.json
         from flowmol_amd import build as fm_build
         lib_digest = fm_build.STAMP.read_text().strip()[:16]
     except Exception:
         lib_digest = None
-    eng.profile(True)
-    advance(2)
-    torch.cuda.synchronize(dev)
-    kern = {}
-    for k in ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node',
-              'edge_head', 'node_head', 'sc', 'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step'):
-        ms, cnt = eng.profile_get(k)
-        if cnt:
-            kern[k] = {'avg_us': ms * 1e3 / cnt, 'launches_per_step': cnt / 2}
-    eng.profile(False)
+    kern, ev_overhead = leg.kernel_times(2)
     launches_per_step = sum(v['launches_per_step'] for v in kern.values())
-    # counters of the dominant kernel from the committed rocprofv3 PMC passes (same workload only); never measured by this run
-    pmc = None
-    try:
-        pj = json.loads((ROOT / 'profiles' / 'current_pmc.json').read_text()).get(args.workload)
-        if pj and pj['nodes_per_gpu'] == N and pj['directed_edges_per_gpu'] == E and args.size_dist is None and args.precision == 'f32' and world == 1:
-            pmc = pj
-    except Exception:
-        pass
+    # counters of the dominant kernel from the committed rocprofv3 PMC passes (same workload AND same library digest only); never measured by this run
+    pmc = load_pmc(args.workload, N, E, args.size_dist is None and args.precision == 'f32' and world == 1)
     ex = executed_macs(cfg)
     roofline = None
     if 'edge_message' in kern and args.precision == 'bf16x3':
@@ -417,34 +632,15 @@ def main():
                             'kernel is bound by the L1/L2 weight stream, the f32 vector-path GEMMs and VALU, not by the bf16 pipe. f32_equivalent_tflops = the reference '
                             'FLOP count of the op / launch time (exceeds the f32 peak because the work is not done in f32).'}
     elif 'edge_message' in kern:
-        us = kern['edge_message']['avg_us']
-        flops = conv_message_flops_per_edge(cfg.n_vec_channels) * E
-        ex_flops = 2 * ex['edge_message_per_edge'] * E
-        ach = flops / (us * 1e-6) / 1e12
-        traffic = pmc['hbm_bytes_per_launch'] if pmc else None
-        roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
-                    'traffic_source': (f"committed profile {pmc['source']} (library digest {pmc.get('library_digest')}; this run: {lib_digest}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
-                                       f"rocprofv3 PMC with the gfx950 FETCH correction; not measured by this run") if pmc else None,
-                    'algorithmic_bytes_per_launch': E * (512 + 8) + N * 4 * (256 + 3 * cfg.n_vec_channels) * 2,
-                    'avg_launch_us': us,
-                    'hbm_gb_per_s': (traffic / (us * 1e-6) / 1e9) if traffic else None,
-                    'hbm_frac_of_8tb_per_s': (traffic / (us * 1e-6) / 8e12) if traffic else None,
-                    'algorithmic_flop_per_launch': flops,
-                    'executed_flop_per_launch': ex_flops,
-                    'executed_tflops': ex_flops / (us * 1e-6) / 1e12,
-                    'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
-                    'mfma_busy_frac': pmc.get('mfma_busy_frac') if pmc else None,
-                    'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})"
-                                         if pmc and pmc.get('mfma_busy_frac') else None),
-                    'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
-                            'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
-                            f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
-                            'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
+        roofline = message_roofline(cfg, E, N, kern['edge_message']['avg_us'], pmc, lib_digest)
     n_list = n_atoms.tolist()
     evals_per_s = mols_per_s / world * evals / B                      # network evaluations of this rank's batch per second
     alg_tf = sum(network_flops(int(k), cfg) for k in n_list) * evals_per_s / 1e12
     exe_tf = 2 * (ex['per_edge'] * E + ex['per_node'] * N) * evals_per_s / 1e12
+    try:
+        rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = None
     out = {
         'metric': (f'molecules/sec at {T} timesteps ' + ('(GEOM-drugs-sized graphs)' if args.workload == 'c3' else f'[secondary workload {args.workload}]')) + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -455,7 +651,8 @@ def main():
                    'global_molecules': B * world, 'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'parallelism': f'molecule-shard x{world}',
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
                    'value_formula': 'global_molecules / (network_evaluations_per_sample * ms_per_step/1000)', 'network_evaluations_per_sample': evals, 'trajectory_sink': bool(wl['traj']), 'weights': 'synthetic by name (seed 0)',
-                   'finite': finite, 'library_digest': lib_digest},
+                   'finite': finite, 'library_digest': lib_digest,
+                   'process_group': {'size': world, 'backend': (dist.get_backend() if world > 1 else None), 'rccl_version': rccl, 'ranks': rank_info}},
         'network_eval_ms': ms_per_step, 'per_rank_ms_per_step': per_rank_ms, 'final_gather_ms': gather_ms,
         'launches_per_step': launches_per_step,
         'whole_path': None if args.precision != 'f32' else {'algorithmic_tflops_per_gpu': alg_tf, 'executed_tflops_per_gpu': exe_tf,
@@ -465,14 +662,17 @@ def main():
                                'the kernels issue (per-source terms hoisted to per-node GEMMs, few-input embeddings tabulated); only executed_frac is a '
                                'fraction of the f32 peak -- the algorithmic rate may exceed the peak because fewer FLOPs are executed'},
         'kernels': kern,
-        'kernels_note': 'per-kernel averages come from a separate HIP-event-instrumented pass of 2 steps after the timed region',
+        'kernels_note': f'per-kernel averages come from a separate HIP-event-instrumented pass of 2 steps after the timed region; avg_us = event pair minus the pair overhead measured in the same pass on an empty kernel ({ev_overhead:.1f} us)',
     }
     if roofline:
         out['roofline'] = roofline
+    if rank == 0 and world == 1 and args.workload == 'c3' and args.precision == 'f32' and args.size_dist is None and not args.no_secondary:
+        del leg
+        out['secondary'] = secondary_legs({args.preset: (cfg, eng)}, dev, lib_digest, args.secondary_steps)
     if rank == 0 and world == 1 and not args.no_api_e2e:
         out['api_end_to_end'] = api_end_to_end(args, all_sizes, T, dev, wl['traj'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, sd, all_sizes[:args.cpu_mols].clone(), args.cpu_steps, T, evals)
+        out['cpu_baseline'] = cpu_baseline(cfg, sd, all_sizes, args.cpu_mols, args.cpu_steps, T, evals, ref_batch=args.cpu_ref_batch)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -130,9 +130,17 @@ def load(path=None) -> C.CDLL:
         # the in-tree library must be the build of the in-tree sources: a stale .so (sources edited, library not rebuilt) would
         # silently test and benchmark old kernels.  The build stamp is the digest of csrc/ + the header + the flags.
         from . import build as _build
-        if _build.STAMP.exists() and (_build.SRC / 'fm_engine.cpp').exists() and _build.STAMP.read_text().strip() != _build._digest():
-            raise FlowMolHipError(f"{p} is stale: flowmol_amd/csrc or include/flowmol_hip.h changed since it was built.  "
-                                  f"Run `python -m flowmol_amd.build`.")
+        if (_build.SRC / 'fm_engine.cpp').exists():          # a source tree (an installed copy without csrc/ has nothing to be stale against)
+            try:
+                digest = _build._digest()
+            except OSError as e:      # e.g. csrc/ present but include/flowmol_hip.h missing: cannot tell -- say so instead of a raw FileNotFoundError
+                raise FlowMolHipError(f"cannot verify that {p} matches the sources ({e}); restore include/flowmol_hip.h or rebuild with `python -m flowmol_amd.build`") from e
+            if not _build.STAMP.exists():
+                import warnings
+                warnings.warn(f"{p} has no build stamp ({_build.STAMP.name}): it cannot be checked against flowmol_amd/csrc; rebuild with `python -m flowmol_amd.build`", RuntimeWarning)
+            elif _build.STAMP.read_text().strip() != digest:
+                raise FlowMolHipError(f"{p} is stale: flowmol_amd/csrc or include/flowmol_hip.h changed since it was built.  "
+                                      f"Run `python -m flowmol_amd.build`.")
     lib = C.CDLL(str(p))
     for name, (res, args) in _EXPORTS.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is missing

@@ -91,6 +91,7 @@ struct fm_ctx {
     // ---- taps / profiling
     std::map<std::string, void*> taps;
     bool prof = false;
+    std::vector<hipEvent_t> ev_pool;          // recycled timing events: creating a pair per launch made the host the bottleneck of a profiled step
     std::vector<ProfEvent> prof_events;
     std::vector<std::string> prof_names;
     std::map<std::string, std::pair<double, int64_t>> prof_acc;
@@ -281,7 +282,8 @@ struct Launch {
         ProfEvent pe{};
         if (c->prof) {
             pe.kid = kid_of(c, name);
-            (void)hipEventCreate(&pe.a); (void)hipEventCreate(&pe.b);
+            auto take = [&](hipEvent_t& e) { if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); };
+            take(pe.a); take(pe.b);
             (void)hipEventRecord(pe.a, st);
         }
         hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
@@ -340,11 +342,11 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     // Node- and pair-side MLPs with the same inputs share one launch while the batch is small (two launches less per step where launches
     // are what a step costs).  The shared launch allocates the LARGER tile's LDS (node tiles: 147 KB -> one workgroup per CU) for every
     // workgroup, so once the pair tiles alone fill the chip they run as a launch of their own at two workgroups per CU
-    // (profiles/r02n: 1.16 -> 0.94 ms and 0.83 -> 0.68 ms per step at 1024 molecules).  FM_PAIR_MLPS=0|1 forces either.
+    // (profiles/r02n: 1.16 -> 0.94 ms and 0.83 -> 0.68 ms per step at 1024 molecules).  fm_config.pair_mlps = 1 | -1 forces either (0 = this rule).
     const int mlp_tiles = (N + FM_TM - 1) / FM_TM + (U + FM_TM - 1) / FM_TM;
     const bool pair_mlps = c->fuse_node && (c->pair_mlps_forced >= 0 ? c->pair_mlps_forced != 0 : mlp_tiles <= c->n_cus);
     // 16-row MLP tiles while even those do not fill the chip (4 per CU fit in LDS): a tile's two dependent GEMMs are matrix-pipe time on one CU,
-    // so a quarter of the rows is a quarter of the latency (FM_MLP_SMALL_TILES=0|1 forces either)
+    // so a quarter of the rows is a quarter of the latency (fm_config.mlp_small_tiles = 1 | -1 forces either, 0 = this rule)
     const bool small_node = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (N + 15) / 16 <= 4 * c->n_cus;      // decided per side: the node side
     const bool small_pair = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (U + 15) / 16 <= 4 * c->n_cus;      // stays small ~25x longer than the pair side
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
@@ -395,7 +397,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const dim3 blk(FM_THREADS);
     const dim3 gn((N + FM_TM - 1) / FM_TM), ge((E + FM_TM - 1) / FM_TM);     // 64-row kernels
     const dim3 gnt((N + TN - 1) / TN), get((E + TE - 1) / TE);              // GVP kernels
-    // FM_FUSE_NODE=0 (read at fm_create) keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own
+    // fm_config.fuse_node = -1 keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own (0 / 1 = fused)
     const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
     const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
     for (int it = 0; it < n_pass; ++it) {
@@ -556,9 +558,15 @@ int forward_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const float* 
     return evaluate_dispatch(c, st, state, prev, remove_com, out, true);
 }
 
+__global__ void fm_k_noop() {}
+
 int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* dst, const fm_step_noise* nz,
               const fm_step_scalars* sc, const fm_sampled* smp, const float* x_raw = nullptr) {
     Launch L{c, st};
+    // profiling only: an event pair around an empty kernel, once per step.  Its elapsed time is what a pair adds to every profiled launch
+    // (event signalling + the dispatch that cannot overlap the previous kernel's tail); fm_profile_get("event_overhead") lets the caller
+    // subtract it, which matters for the sub-millisecond kernels of small batches (HIP events vs rocprofv3: +12 % on a 350 us kernel).
+    if (c->prof) L("event_overhead", fm_k_noop, dim3(1), dim3(64), 0);
     const FmBatch& b = c->b;
     struct Mod { int rows, K; const float* p; const int* mol; int* xt; int* x1; const float *q, *u1, *u2; };
     static const fm_step_noise no_noise{};
@@ -910,6 +918,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
 int fm_destroy(fm_ctx* c) {
     if (!c) return FM_OK;
     for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->arena) (void)hipFree(c->arena);
     if (c->stage_ev) { (void)hipEventSynchronize(c->stage_ev); (void)hipEventDestroy(c->stage_ev); }
     if (c->stage) (void)hipHostFree(c->stage);
@@ -977,7 +986,12 @@ int fm_workspace_bytes(fm_ctx* c, const int32_t* n_atoms, int B, size_t* bytes) 
 
 // Pinned staging for `n_ints` int32 about to be copied to the device on a stream: waits (host-side) only for the copies of the PREVIOUS
 // use of the staging buffer, never for the stream.
-static int stage_acquire(fm_ctx* c, size_t n_ints) {
+static int stage_acquire(fm_ctx* c, hipStream_t st, size_t n_ints) {
+    {   // setup calls wait on an event and (re)allocate pinned memory: both are illegal while the stream is being captured
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(c, FM_ERR_STATE, "fm_batch_bind / fm_set_molecule_ids are setup calls and must stay outside a stream capture");
+    }
     if (!c->stage_ev) FM_HIP(c, hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming));
     if (c->stage_busy) { FM_HIP(c, hipEventSynchronize(c->stage_ev)); c->stage_busy = false; }
     if (c->stage_cap < n_ints) {
@@ -1004,17 +1018,20 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     if ((uintptr_t)workspace % 256) return fail(c, FM_ERR_INVALID, "fm_batch_bind: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
-    rc = stage_acquire(c, 3 * (size_t)(B + 1) + (size_t)B);
+    rc = stage_acquire(c, st, 3 * (size_t)(B + 1) + (size_t)B);
     if (rc) return rc;
     int32_t* no = c->stage; int32_t* eo = no + (B + 1); int32_t* po = eo + (B + 1); int32_t* ids = po + (B + 1);
     no[0] = eo[0] = po[0] = 0;
     for (int i = 0; i < B; ++i) { const int n = n_atoms[i]; no[i + 1] = no[i] + n; eo[i + 1] = eo[i] + n * (n - 1); po[i + 1] = po[i] + n * (n - 1) / 2; ids[i] = i; }
-    FM_HIP(c, hipMemcpyAsync(base + w.off_mol_node, no, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
-    FM_HIP(c, hipMemcpyAsync(base + w.off_mol_edge, eo, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
-    FM_HIP(c, hipMemcpyAsync(base + w.off_mol_pair, po, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
-    FM_HIP(c, hipMemcpyAsync(base + w.off_gid, ids, (size_t)B * 4, hipMemcpyHostToDevice, st));
-    rc = stage_release(c, st);
-    if (rc) return rc;
+    {   // a copy that fails after earlier ones were enqueued must not leave the staging buffer unguarded: the event is recorded either way
+        hipError_t e_ = hipMemcpyAsync(base + w.off_mol_node, no, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
+        if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_mol_edge, eo, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
+        if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_mol_pair, po, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
+        if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_gid, ids, (size_t)B * 4, hipMemcpyHostToDevice, st);
+        rc = stage_release(c, st);
+        if (e_ != hipSuccess) return fail(c, FM_ERR_HIP, "fm_batch_bind: descriptor copy failed: %s", hipGetErrorString(e_));
+        if (rc) return rc;
+    }
     FmBatch& b = c->b;
     b.B = B; b.N = w.N; b.E = w.E; b.U = w.U; b.P = w.P;
     b.mol_node_off = (const int*)(base + w.off_mol_node); b.mol_edge_off = (const int*)(base + w.off_mol_edge); b.mol_pair_off = (const int*)(base + w.off_mol_pair);
@@ -1051,11 +1068,13 @@ int fm_remove_com(fm_ctx* c, void* stream, float* x) {
 int fm_set_molecule_ids(fm_ctx* c, void* stream, const int32_t* ids_host) {
     if (!c) return fail(c, FM_ERR_INVALID, "fm_set_molecule_ids: null context");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_set_molecule_ids: no batch bound");
-    int rc = stage_acquire(c, (size_t)c->b.B);
+    int rc = stage_acquire(c, (hipStream_t)stream, (size_t)c->b.B);
     if (rc) return rc;
     for (int i = 0; i < c->b.B; ++i) c->stage[i] = ids_host ? ids_host[i] : i;
-    FM_HIP(c, hipMemcpyAsync(c->mol_gid, c->stage, (size_t)c->b.B * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
-    return stage_release(c, (hipStream_t)stream);
+    const hipError_t e_ = hipMemcpyAsync(c->mol_gid, c->stage, (size_t)c->b.B * 4, hipMemcpyHostToDevice, (hipStream_t)stream);
+    rc = stage_release(c, (hipStream_t)stream);
+    if (e_ != hipSuccess) return fail(c, FM_ERR_HIP, "fm_set_molecule_ids: copy failed: %s", hipGetErrorString(e_));
+    return rc;
 }
 
 int fm_prior_philox(fm_ctx* c, void* stream, uint64_t seed, float* x0) {
@@ -1207,7 +1226,7 @@ int fm_profile_enable(fm_ctx* c, int on) {
     if (!c) return FM_ERR_INVALID;
     c->prof = on != 0;
     if (on) {
-        for (auto& pe : c->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+        for (auto& pe : c->prof_events) { c->ev_pool.push_back(pe.a); c->ev_pool.push_back(pe.b); }
         c->prof_events.clear(); c->prof_acc.clear();
     }
     return FM_OK;
@@ -1221,7 +1240,7 @@ int fm_profile_get(fm_ctx* c, const char* kernel, double* total_ms, int64_t* lau
         FM_HIP(c, hipEventElapsedTime(&ms, pe.a, pe.b));
         auto& acc = c->prof_acc[c->prof_names[pe.kid]];
         acc.first += ms; acc.second += 1;
-        (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b);
+        c->ev_pool.push_back(pe.a); c->ev_pool.push_back(pe.b);
     }
     c->prof_events.clear();
     auto it = c->prof_acc.find(kernel);

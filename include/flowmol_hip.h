@@ -254,7 +254,9 @@ int fm_stability(fm_ctx* ctx, void* stream, const fm_state* state, const uint32_
                  int fake_atom_token, int explicit_aromaticity, int32_t* out);
 
 /* per-kernel timing of the last fm_forward / fm_integrate when enabled (HIP events on `stream`):
- * fm_profile_enable(ctx, 1); ... ; fm_profile_get(ctx, "edge_message", &total_ms, &launches) */
+ * fm_profile_enable(ctx, 1); ... ; fm_profile_get(ctx, "edge_message", &total_ms, &launches).
+ * While profiling, every CTMC step also times an EMPTY kernel under the name "event_overhead": what an event pair adds to a launch
+ * (subtract its average from the other kernels' averages to compare with rocprofv3 kernel durations). */
 int fm_profile_enable(fm_ctx* ctx, int on);
 int fm_profile_get(fm_ctx* ctx, const char* kernel, double* total_ms, int64_t* launches);
 

@@ -475,3 +475,33 @@ def test_bench_flop_model_reproduces_the_survey_counts():
     assert bench.conv_message_flops_per_edge(32) == 2 * 312251
     info = bench.host_cpu_info()
     assert info['logical_cpus'] >= 1
+
+
+def test_bench_dry_run_plan_and_cost_sample():
+    """`bench.py --gpus 8 --dry-run` prints the 8-rank plan of BASELINE configs[3] as one JSON line without touching a GPU (this container has
+    none): 1024 molecules and the same cost per rank, payload bytes of the one all-gather; with the GEOM size distribution the LPT deal is
+    balanced to ppm.  The CPU-baseline sample of a ragged workload is cost-representative, not its first molecules."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    line = subprocess.run([sys.executable, str(root / 'bench.py'), '--gpus', '8', '--dry-run'], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    assert d['dry_run'] and d['n_gpus'] == 8 and d['global_molecules'] == 8192 and len(d['ranks']) == 8
+    assert all(r['molecules'] == 1024 and r['directed_edges'] == 1024 * 47 * 46 and r['gather_payload_bytes'] == 1024 * (47 * 14 + 1081) for r in d['ranks'])
+    assert d['all_gather_total_bytes'] == 8 * d['all_gather_slot_bytes'] and d['all_gather_slot_bytes'] % 16 == 0
+    spec = importlib.util.spec_from_file_location('bench_mod2', root / 'bench.py')
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    all_sizes, parts, ragged = bench.job_sizes(8, 1024, None, 'geom_full_kekulized')
+    cost = (all_sizes * (all_sizes - 1)).double()
+    per_rank = torch.tensor([float(cost[p].sum()) for p in parts])
+    assert ragged and sorted(torch.cat(parts).tolist()) == list(range(8192)) and float(per_rank.max() / per_rank.mean()) < 1.0001
+    c5, _, _ = bench.job_sizes(1, 128, None, None)
+    sample = bench._cost_sample(c5, 16)
+    ratio = float((sample * (sample - 1)).double().mean() / (c5 * (c5 - 1)).double().mean())
+    first = float((c5[:16] * (c5[:16] - 1)).double().mean() / (c5 * (c5 - 1)).double().mean())
+    assert abs(ratio - 1) < 0.06 < abs(first - 1)                  # the first 16 molecules of c5 cost 23 % more than the workload's mean
+    assert torch.equal(bench._cost_sample(torch.full((64,), 47), 16), torch.full((16,), 47))
