@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FM_ABI_VERSION = 5
+FM_ABI_VERSION = 6
 FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
 FM_NOISE_TENSORS, FM_NOISE_PHILOX = 0, 1
 FM_PREC_F32, FM_PREC_BF16X3 = 0, 1
@@ -33,11 +33,11 @@ class fm_config(C.Structure):
         ('n_recycles', C.c_int32), ('edge_update_no_distance', C.c_int32),
         # ABI 5: launch-tuning overrides, 0 = automatic (see include/flowmol_hip.h)
         ('tile_edge', C.c_int32), ('tile_node', C.c_int32), ('tile_edge_update', C.c_int32), ('xcd_swizzle', C.c_int32),
-        ('fuse_node', C.c_int32), ('pair_mlps', C.c_int32), ('mlp_small_tiles', C.c_int32),
+        ('fuse_node', C.c_int32), ('pair_mlps', C.c_int32), ('mlp_small_tiles', C.c_int32), ('pair_slab', C.c_int32),
     ]
 
 
-TUNING_FIELDS = ('tile_edge', 'tile_node', 'tile_edge_update', 'xcd_swizzle', 'fuse_node', 'pair_mlps', 'mlp_small_tiles')
+TUNING_FIELDS = ('tile_edge', 'tile_node', 'tile_edge_update', 'xcd_swizzle', 'fuse_node', 'pair_mlps', 'mlp_small_tiles', 'pair_slab')
 
 
 class fm_tensor_desc(C.Structure):

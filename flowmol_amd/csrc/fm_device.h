@@ -445,7 +445,9 @@ struct FmGvpTile {
 // SP = 1 (split precision, edge message only): X is NOT an f32 tile but the two bf16 planes XH = (u16*)X, XL = XH + TM*FM_LDP; the
 // scalar GEMM and the gate GEMM run on v_mfma_f32_16x16x32_bf16 with hi/lo operands; with LAST the f32 scalar output is kept in
 // registers and written as a plain f32 [TM][FM_LDX] tile over the (then dead) planes for the aggregation.  G must then alias Vh + TM*FM_LDG.
-template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false>
+// PQ (FIRST only): the [rbf | ef] slab of the scalar linear arrives inside `pre` (per-pair table, fm_k_pair_slab): X holds only the hidden-vector
+// norms sh at columns [0, KU0) and the scalar GEMM has K = KU0.
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
     typedef FmGvpTile<V, TM, HX> T;
@@ -456,7 +458,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int NTW = 16 / NW;                         // column tiles of the scalar GEMM per wave (16 tiles = 256 columns)
     constexpr int H = FIRST ? T::H0 : V;                 // hidden vector channels
     constexpr int KUC = FIRST ? T::KU0 : T::KU;          // K of this GVP's Wu GEMM = width of [hidden | cp | pad] in Vh and of sh in X
-    constexpr int SOFF = FIRST ? 160 : 256;              // where sh goes in X
+    static_assert(!PQ || (FIRST && !SP), "PQ is a variant of the first f32 edge GVP");
+    constexpr int SOFF = PQ ? 0 : (FIRST ? 160 : 256);   // where sh goes in X
     constexpr int K8S = (SOFF + KUC) / 8;
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
     constexpr int CPSRC = FIRST ? T::KU0 : V;            // where the 8 Vcp channels sit in Vh

@@ -33,6 +33,8 @@ struct MlpW { const float2* W1; const float* b1; const float2* W2; const float* 
 
 struct ConvW {
     const float2* Wps; const float2* Wpv; const float* w0;
+    const float2* Ws_slab = nullptr;   // pair-slab convolutions: [rbf | ef] rows of GVP0's scalar linear (K = 160), for fm_k_pair_slab
+    const float2* Ws_sh = nullptr;     //                         and its remaining rows, the hidden-vector norms (K = KU0)
     const void* Wps_sp = nullptr;      // split precision
     FmGvpW dproj{}; const float2* Wsd = nullptr; const float2* Wpvd = nullptr;     // use_dst_feats: projection GVP + hoisted destination terms
     FmGvpW msg[3]; FmGvpW upd[3];
@@ -61,6 +63,8 @@ struct fm_ctx {
     int pair_mlps_forced = -1;      // fm_config.pair_mlps
     int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
+    int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (fm_config.pair_slab = -1: 0)
+    float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
@@ -260,10 +264,11 @@ size_t lds_gvp_sp(int V, int TM) {       // split-precision edge message: bf16 p
 }
 size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
     size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, HX) + 4) + TM * FM_LDG;
-    return fl * 4 + (with_meta ? (size_t)TM * 9 * 4 : 0);
+    return fl * 4 + (with_meta ? (size_t)TM * 9 * 4 + 64 : 0);      // + one slot for the tile's smallest pair id (PQ instances)
 }
 size_t lds_mlp(int ldx, int ldh, int tm = FM_TM) { return ((size_t)tm * ldx + (size_t)tm * ldh) * 4 + 5 * (size_t)tm * 4; }
 size_t lds_proj(int V, int tm = FM_TM) { return ((size_t)tm * 260 + 3 * (size_t)tm * (V + 4)) * 4; }
+size_t lds_pair_slab(int TM) { return (size_t)TM * 164 * 4 + (size_t)TM * 2 * 4; }
 size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
 size_t lds_edge_upd_sp(int TM) { return (size_t)TM * 132 * 4 + (size_t)TM * 176 * 2 * 2 + TM * 3 * 4; }
 
@@ -400,6 +405,17 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     // fm_config.fuse_node = -1 keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own (0 / 1 = fused)
     const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
     const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
+    // Convolutions before the first molecule update (first pass only): the [rbf | ef] slab of their first scalar linear once per unordered
+    // pair, both convolutions in one launch (fm_k_pair_slab); positions are still the input positions, edge features the embedding / SC output.
+    const int n_pq = (HX == 0 && U > 0) ? c->n_pq : 0;
+    if (n_pq > 0) {
+        FmPairSlabArgs ps{};
+        ps.b = b; ps.x = x_t; ps.ef = c->ef; ps.W0 = c->conv[0].Ws_slab; ps.Q0 = c->Q[0];
+        if (n_pq > 1) { ps.W1 = c->conv[1].Ws_slab; ps.Q1 = c->Q[1]; }
+        ps.rbf_mu_step = c->rbf_mu_step; ps.rbf_inv_sigma = c->rbf_inv_sigma;
+        if (small_pair) L("pair_slab", fm_k_pair_slab<16>, dim3((U + 15) / 16), blk, lds_pair_slab(16), ps);
+        else L("pair_slab", fm_k_pair_slab<64>, dim3((U + 63) / 64), blk, lds_pair_slab(64), ps);
+    }
     for (int it = 0; it < n_pass; ++it) {
         const int i = it % cf.n_convs;
         const ConvW& cw = c->conv[i];
@@ -428,6 +444,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
         if constexpr (HX == 0) {
             if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
+            else if (it < n_pq) {
+                m.Q = c->Q[it]; m.g0.Ws = cw.Ws_sh;          // GVP0's scalar GEMM: K = KU0 (hidden-vector norms); the rest arrives through Q
+                L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0, 1>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
+            }
             else L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
         } else {
             L("edge_message", fm_k_edge_message<V, TE, 512, HX, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, HX), m);
@@ -773,6 +793,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             if (k < 32) return S + k;
             if (k < 160) return k - 32 < F ? S + 32 + (k - 32) : -1;
             return k < 160 + H0 + 4 ? S + 32 + F + SD + (k - 160) : -1; });
+        pack_linear(B, cw.Ws_slab, Ws, S, kin0, 160, 256, [&](int k) { return k < 32 ? S + k : (k - 32 < F ? S + 32 + (k - 32) : -1); });
+        pack_linear(B, cw.Ws_sh, Ws, S, kin0, KU0, 256, [&](int k) { return k < H0 + 4 ? S + 32 + F + SD + k : -1; });
         pad_vec(B, g0.bs, bs, S, 256);
         pack_linear(B, g0.Wg, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
         pad_vec(B, g0.bg, bg, V, V);
@@ -877,6 +899,15 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     c->xcd_swizzle = cfg->xcd_swizzle >= 0; c->fuse_node = cfg->fuse_node >= 0;
     c->pair_mlps_forced = cfg->pair_mlps == 0 ? -1 : (cfg->pair_mlps > 0);
     c->small_mlp_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles > 0);
+    // pair-slab hoist: the convolutions that run before any molecule update see pair-symmetric edge features and distances
+    c->n_pq = 0;
+    if (cfg->pair_slab >= 0 && HX == 0 && cfg->precision == FM_PREC_F32)
+        for (int i = 0; i < cfg->n_convs && i < 2; ++i) {
+            bool clean = true;
+            for (int j = 0; j < i; ++j) clean &= cfg->update_after[j] < 0;
+            if (!clean) break;
+            c->n_pq = i + 1;
+        }
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
     if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
         (void)hipFree(c->arena); delete c;
@@ -887,7 +918,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cus = prop.multiProcessorCount;
     }
-#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false, 0>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true, 0>, lds_gvp(V_, T_, false)); \
+#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_edge_message<V_, T_, 512, 0, 0, 1>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false, 0>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true, 0>, lds_gvp(V_, T_, false)); \
     set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
     FM_SET(32, 16) FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 16) FM_SET(16, 32) FM_SET(16, 64)
 #undef FM_SET
@@ -901,7 +932,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
-    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
+    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32)); set_lds(fm_k_pair_slab<64>, lds_pair_slab(64)); set_lds(fm_k_pair_slab<16>, lds_pair_slab(16));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
@@ -931,7 +962,7 @@ struct WsLayout {
     int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_Psd, off_PVd, off_stab, off_bx, off_ba,
-        off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, total;
+        off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, off_Q0, off_Q1, total;
 };
 
 static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
@@ -971,6 +1002,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.off_tap_s = take((size_t)N * 256 * 4); w.off_tap_v = take((size_t)N * 3 * V * 4);
     w.off_gid = take((size_t)B * 4);
     w.off_sa1 = take((size_t)N * 4); w.off_sc1 = take((size_t)N * 4); w.off_se1 = take((size_t)w.U * 4);
+    w.off_Q0 = take(c->n_pq > 0 ? (size_t)w.U * 256 * 4 : 0); w.off_Q1 = take(c->n_pq > 1 ? (size_t)w.U * 256 * 4 : 0);
     w.total = o;
     return FM_OK;
 }
@@ -1048,6 +1080,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     c->tap_s = (float*)(base + w.off_tap_s); c->tap_v = (float*)(base + w.off_tap_v);
     c->mol_gid = (int*)(base + w.off_gid);
     c->sa1 = (int32_t*)(base + w.off_sa1); c->sc1 = (int32_t*)(base + w.off_sc1); c->se1 = (int32_t*)(base + w.off_se1);
+    c->Q[0] = (float*)(base + w.off_Q0); c->Q[1] = (float*)(base + w.off_Q1);
     c->n_tiles_e = (w.E + FM_TM - 1) / FM_TM; c->n_tiles_n = (w.N + FM_TM - 1) / FM_TM; c->n_tiles_u = (w.U + FM_TM - 1) / FM_TM;
     Launch L{c, st};
     const int work = w.E > w.N ? w.E : w.N;

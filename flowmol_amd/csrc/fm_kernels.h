@@ -483,6 +483,69 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_dst_proj(FmDstProjArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pair-symmetric part of the first edge GVP's scalar linear, for the convolutions that run BEFORE the first EdgeUpdate /
+// NodePositionUpdate (vector_field.py:320-326: convs 0 and 1 of every shipped schedule): until then the edge features of the two
+// directed edges of a pair are identical (token-table rows or the self-conditioning layer's output written to both triangles,
+// self_conditioning.py:78-81; dense pair embeddings likewise) and so is rbf(d), so the K = 160 slab [rbf(d) | ef] x Ws[rbf|ef rows]
+// of GVP0's scalar GEMM is the same vector for both directions.  It is computed here once per UNORDERED pair (Q: (U,256)) and
+// gathered by the edge-message kernel like the hoisted Ps[src]: 40,960 of 248,064 executed MAC per edge leave the edge kernel
+// for 20,480 here.  One launch serves both convolutions (same input rows, two weight slabs).
+// ------------------------------------------------------------------------------------------------
+struct FmPairSlabArgs {
+    FmBatch b;
+    const float* x;            // (N,3) positions (unchanged until the first NodePositionUpdate)
+    const float* ef;           // (E,128), pair-symmetric at this point
+    const float2* W0; float* Q0;
+    const float2* W1; float* Q1;     // null: only one convolution precedes the first update
+    float rbf_mu_step, rbf_inv_sigma;
+};
+
+template <int TM>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_pair_slab(FmPairSlabArgs a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int LDX = 164, MT = TM / 16;          // 164/4 = 41 odd
+    float* X = lds;                                  // [TM][164]: rbf(32) | ef(128)
+    int* m_e = reinterpret_cast<int*>(X + TM * LDX); // [TM] upper edge of the pair, -1 = no row
+    float* m_d = reinterpret_cast<float*>(m_e + TM);
+    const int tid = threadIdx.x, p0 = blockIdx.x * TM;
+    if (tid < TM) {
+        const int p = p0 + tid;
+        int ea = -1; float d = 0.f;
+        if (p < a.b.U) {
+            ea = a.b.p_e0[p];
+            const int i = a.b.e_src[ea], j = a.b.e_dst[ea];
+            d = fm_norm3(a.x[i * 3] - a.x[j * 3], a.x[i * 3 + 1] - a.x[j * 3 + 1], a.x[i * 3 + 2] - a.x[j * 3 + 2]) + 1e-8f;
+        }
+        m_e[tid] = ea; m_d[tid] = d;
+    }
+    __syncthreads();
+    {
+        constexpr int NQ = TM * 32 / FM_THREADS;
+        float4 q[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+            const int ea = m_e[r];
+            q[k] = ea >= 0 ? reinterpret_cast<const float4*>(a.ef)[(size_t)ea * 32 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<float4*>(X + r * LDX + 32 + 4 * c4) = q[k];
+            X[r * LDX + c4] = fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma);
+        }
+    }
+    __syncthreads();
+    fm_block_gemm<MT, 2>(X, LDX, MT, 20, a.W0, 16, [&](int row, int col, float v) {
+        if (p0 + row < a.b.U) a.Q0[(size_t)(p0 + row) * 256 + col] = v;
+    });
+    if (a.Q1)
+        fm_block_gemm<MT, 2>(X, LDX, MT, 20, a.W1, 16, [&](int row, int col, float v) {
+            if (p0 + row < a.b.U) a.Q1[(size_t)(p0 + row) * 256 + col] = v;
+        });
+}
+
+// ------------------------------------------------------------------------------------------------
 // fused GVPConv edge message + aggregation  (reference gvp.py:476-492, 523-543)
 //   per directed edge j->i: GVP0([s_j|rbf|ef], [xhat_ji|v_j]) -> GVP1 -> GVP2, summed over j per destination i.
 //   Output: per (destination, piece) partial sums; a destination's in-edges are contiguous in the
@@ -502,13 +565,18 @@ struct FmMsgArgs {
     float* part_v;            // (N, P, 3, V)
     float rbf_mu_step, rbf_inv_sigma;
     float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
+    const float* Q;           // (U,256) PQ instances: the pair-symmetric [rbf | ef] slab of GVP0's scalar linear (fm_k_pair_slab)
     int xcd_chunk;            // > 0: workgroup b handles tile (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk); 0: tile = b
 };
 
 // SP = 1: opt-in split-precision instance (fm_device.h "bf16x3"): the scalar tile is two bf16 planes (TM * FM_LDP * 4 bytes, 4.6 KB more
 // than the f32 tile) and the gate buffer lives inside Vh (dead whenever gates exist), so that two workgroups still share a CU.
-template <int V, int TM, int NTH, int HX, int SP>
+// PQ = 1: instance for the convolutions before the first molecule update: the [rbf | ef] slab of GVP0's scalar linear comes from the per-pair
+// table Q (fm_k_pair_slab) like the hoisted Ps[src]; the tile neither loads ef nor evaluates the 32 radial basis functions, and GVP0's scalar
+// GEMM shrinks from K = 200 to K = 40 (the hidden-vector norms).
+template <int V, int TM, int NTH, int HX, int SP, int PQ = 0>
 __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
+    static_assert(!(PQ && (SP || HX)), "the pair-slab instance exists for f32 models without destination features");
     typedef FmGvpTile<V, TM, HX> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
@@ -530,15 +598,26 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     if (e0 >= a.b.E) return;          // padding workgroups of the chunked grid (uniform exit, before any barrier)
     FM_MARK_DECL
     // (A) the edge-feature rows depend only on the tile index: request them before anything else (HBM latency)
-    constexpr int NEF = TM * 32 / NTH;
+    constexpr int NEF = PQ ? 1 : TM * 32 / NTH;
     float4 efv[NEF];
-    {
+    if constexpr (!PQ) {
         const int left = a.b.E - e0;                         // rows of this tile that exist (ragged last tile: the range check zero-fills)
         const auto rs = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
 #pragma unroll
         for (int k = 0; k < NEF; ++k) efv[k] = (FM_ABLATE & 16) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fm_buf_f32x4(rs, tid * 16 + k * NTH * 16, 0);
     }
     // (B) endpoints and geometry of the tile's edges
+    if (PQ && tid < 64) {
+        // PQ: byte offsets of the rows' pairs in Q, relative to the tile's smallest pair id (a wave-wide min: the tile's pairs lie within a few
+        // molecules, so the relative offsets stay far below the 31-bit limit of a buffer offset however large the batch's Q table is)
+        const int e = e0 + tid;
+        const int pr = (tid < TM && e < a.b.E) ? a.b.e_pair[e] : 0x7fffffff;
+        int mn = pr;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+        if (tid < TM) m_doff[tid] = pr != 0x7fffffff ? (pr - mn) * 1024 : FM_BUF_OOB;
+        if (tid == 0) m_doff[TM] = mn;
+    }
     if (tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1, piece = 0;
@@ -553,7 +632,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
             gx = dx * inv_d; gy = dy * inv_d; gz = dz * inv_d;
         }
         m_src[tid] = s; m_dst[tid] = d; m_piece[tid] = piece;
-        m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB; m_doff[tid] = d >= 0 ? d * 1024 : FM_BUF_OOB;
+        m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB;
+        if (!PQ) m_doff[tid] = d >= 0 ? d * 1024 : FM_BUF_OOB;
         m_geo[4 * tid] = gx; m_geo[4 * tid + 1] = gy; m_geo[4 * tid + 2] = gz; m_geo[4 * tid + 3] = dist;
     }
     __syncthreads();
@@ -565,6 +645,12 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     if (!(FM_ABLATE & 16)) fm_gather_pre<TM, NTH, false>(pre, a.Ps, a.b.N, m_soff);
     else { for (auto& p1 : pre) for (auto& p2 : p1) for (auto& p3 : p2) p3 = 0.25f; }
     if (HX > 0) fm_gather_pre<TM, NTH, true>(pre, a.Psd, a.b.N, m_doff);      // + the destination node's hoisted scalar term
+    float preq[PQ ? TM / 16 : 1][PQ ? 1024 / NTH : 1][4];
+    if constexpr (PQ) {      // the pair's slab row, requested right behind Ps[src]; summed into `pre` after the fill below (VMEM returns in order:
+                             // once the fill's own gathers have arrived these have too, so the sum waits for nothing)
+        const int pmin = __builtin_amdgcn_readfirstlane(m_doff[TM]);
+        fm_gather_pre<TM, NTH, false>(preq, a.Q + (size_t)pmin * 256, 0x7fffffff / 1024, m_doff);
+    }
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):
     //     a branchy load-use-store loop serialises one L2 round trip per iteration (profiles/r01d: 37k cycles here).
@@ -614,7 +700,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
             fm_split_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
             fm_split_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
         }
-    } else {
+    } else if constexpr (!PQ) {
     for (int idx = tid; idx < TM * 32; idx += NTH) {
         const int r = idx >> 5, k = idx & 31;
         X[r * FM_LDX + k] = fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma);      // rows without an edge hold finite junk that is never aggregated
@@ -625,9 +711,17 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         *reinterpret_cast<float4*>(X + r * FM_LDX + 32 + 4 * c4) = efv[k];   // ds_write_b128 (16-B aligned)
     }
     }
+    if constexpr (PQ) {
+#pragma unroll
+        for (int i = 0; i < TM / 16; ++i)
+#pragma unroll
+            for (int j = 0; j < 1024 / NTH; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[i][j][r] += preq[i][j][r];
+    }
     __syncthreads();
     FM_MARK(1);
-    fm_gvp_core<V, V, true, true, TM, NTH, HX, SP, false>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
+    fm_gvp_core<V, V, true, true, TM, NTH, HX, SP, false, PQ != 0>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(10));
     fm_gvp_core<V, V, false, true, TM, NTH, HX, SP, false>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(20));
     fm_gvp_core<V, V, false, true, TM, NTH, HX, SP, true>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(30));
 

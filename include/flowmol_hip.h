@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 5
+#define FM_ABI_VERSION 6
 #define FM_MAX_CONVS 16
 
 typedef enum fm_status {
@@ -104,6 +104,9 @@ typedef struct fm_config {
     int32_t fuse_node;            /* 0 / 1 = node_update also runs the next conv's projections + NodePositionUpdate | -1 = separate launches */
     int32_t pair_mlps;            /* node-side and pair-side MLPs of a stage in ONE launch: 0 = while the pair tiles do not fill the chip | 1 always | -1 never */
     int32_t mlp_small_tiles;      /* 16-row tiles for the MLP kernels: 0 = while they do not fill the chip | 1 always | -1 never */
+    /* --- ABI 6 */
+    int32_t pair_slab;            /* [rbf | ef] slab of the first edge GVP once per unordered pair for the convolutions before the first molecule
+                                   * update (pair-symmetric inputs; f32 models without destination features): 0 / 1 = on | -1 = off */
 } fm_config;
 
 enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1 };

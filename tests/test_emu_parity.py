@@ -412,3 +412,30 @@ def test_mlp_tile_sizes_on_emulation(emu_lib, small):
         errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor([5, 18, 2, 1]), 0.5, True, taps=False)
         bad = {k: v for k, v in errs.items() if not v < 1e-5}
         assert not bad, (small, pair, bad)
+
+
+@pytest.mark.parametrize('name,sizes,prev', [('flowmol3', [5, 18, 2, 1], True), ('geom_ctmc', [6, 3, 9], False), ('arch_variants', [5, 9, 1, 4], True),
+                                             ('dev_narrow', [5, 3], True)])
+def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
+    """The convolutions before the first molecule update take the [rbf | ef] slab of their first scalar linear from a per-pair table
+    (fm_k_pair_slab + the PQ instances of fm_k_edge_message; fm_config.pair_slab, ABI 6) instead of recomputing it for both directed edges of
+    every pair: both code paths against the oracle on every stage, the switch really selects another launch sequence, and the two paths agree
+    to summation order.  arch_variants: n_recycles = 2 -- only the first pass is eligible."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    outs, counts = {}, {}
+    for flag in (-1, 1):
+        eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning={'pair_slab': flag})
+        errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), 0.5, prev)
+        bad = {k: v for k, v in errs.items() if not v < 2e-5}
+        assert not bad, (flag, bad)
+        eng.profile(True)
+        forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), 0.5, prev, taps=False)
+        counts[flag] = eng.profile_get('pair_slab')[1]
+        eng.profile(False)
+        outs[flag] = {k: v.clone() for k, v in out.items()}
+    assert counts[-1] == 0 and counts[1] >= 1, counts
+    for k in 'xace':
+        torch.testing.assert_close(outs[1][k], outs[-1][k], rtol=1e-4, atol=2e-6)
+    assert any(not torch.equal(outs[1][k], outs[-1][k]) for k in 'xace')          # another summation order, not the same arithmetic
