@@ -91,18 +91,29 @@ def executed_macs(cfg):
         vop = max(16, vout)
         return (0 if first else 3 * V * (V + 16)) + 3 * (V + 8) * vop + ((R + F if first else S) + V + 8) * S + S * vop
     msg = gvp(True, V) + 2 * gvp(False, V)
-    n_upd = sum(1 for u in cfg.update_schedule() if u >= 0)
+    sched = cfg.update_schedule()
+    n_upd = sum(1 for u in sched if u >= 0)
+    # pair-slab hoist (fm_config.pair_slab, ABI 6): for the leading convolutions that run before any molecule update (at most two) the [rbf | ef]
+    # slab of GVP0's scalar linear is computed once per unordered pair (fm_k_pair_slab) and leaves the per-edge kernel
+    n_pq = 0
+    if not getattr(cfg, 'use_dst_feats', False):
+        for i in range(min(2, cfg.n_convs)):
+            if any(u >= 0 for u in sched[:i]):
+                break
+            n_pq = i + 1
+    slab = (R + F) * S
     eupd = (F + R) * F + F * F
     sc_e = (p8(cfg.n_bond_types + R) * F + F * F) / 2 if cfg.self_conditioning else 0          # per unordered pair
     head_e = (F * F + F * 16) / 2
-    per_edge = cfg.n_convs * msg + n_upd * eupd + sc_e + head_e
+    per_edge = cfg.n_convs * msg - n_pq * slab + n_pq * slab / 2 + n_upd * eupd + sc_e + head_e
     node_upd = 3 * gvp(False, V)
     pos = 2 * gvp(False, V) + gvp(False, 1)
     proj = S * S + 3 * V * (V + 16)
     sc_n = (p8(S + cfg.n_atom_types + cfg.n_charges + R) * S + S * S) if cfg.self_conditioning else 0
     head_n = S * S + S * p16(cfg.n_atom_types + cfg.n_charges)
     per_node = cfg.n_convs * (node_upd + proj) + n_upd * (pos + S * S) + sc_n + head_n
-    return {'edge_message_per_edge': msg, 'edge_update_per_edge': eupd, 'per_edge': per_edge, 'per_node': per_node}
+    return {'edge_message_per_edge': (cfg.n_convs * msg - n_pq * slab) / cfg.n_convs, 'edge_message_full_per_edge': msg, 'pair_slab_convs': n_pq,
+            'pair_slab_per_pair': n_pq * slab, 'edge_update_per_edge': eupd, 'per_edge': per_edge, 'per_node': per_node}
 
 
 def _free_port():
@@ -375,8 +386,9 @@ def message_roofline(cfg, E, N, us, pmc=None, lib_digest=None):
             'mfma_busy_frac': busy,
             'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})" if busy else None),
             'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
-                    'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
-                    f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
+                    'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms; '
+                    f"{ex['edge_message_full_per_edge']} MAC/edge, {ex['edge_message_full_per_edge'] - (cfg.rbf_dim + cfg.n_hidden_edge_feats) * cfg.n_hidden_scalars} in the {ex['pair_slab_convs']} pair-slab launches: "
+                    f"{ex['edge_message_per_edge']:.0f} on average over the step's launches, like avg_launch_us) / launch time / peak -- the matrix-pipe occupancy by construction; "
                     'avg_launch_us = HIP-event pair on the launch stream minus the measured pair overhead (an empty kernel timed the same way in the same pass); '
                     'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
 

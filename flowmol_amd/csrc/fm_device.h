@@ -2,9 +2,14 @@
 //
 // Everything here is written for 64-wide wavefronts and the f32-input matrix instruction
 // v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, 32-cycle issue per SIMD, the f32
-// vector rate).  A workgroup is 512 threads = 8 waves (2 per SIMD) working on a tile of TM = 64
-// rows (edges, nodes or pairs) whose activations stay in LDS between the fused stages; weights are
-// pre-packed on the host into MFMA B-fragment order and streamed from L2.
+// vector rate).  A workgroup is 512 threads = 8 waves (2 per SIMD) working on a tile of TM rows
+// (edges, nodes or pairs) whose activations stay in LDS between the fused stages; weights are
+// pre-packed on the host into MFMA B-fragment order and streamed from L2.  TM is a template
+// parameter of every kernel: the GVP kernels (edge message, node update) run 32-row tiles -- 77 KB
+// of LDS, TWO workgroups per CU, i.e. 4 waves per SIMD -- or 16-row tiles while a batch is too small
+// to give every CU a 32-row tile; EdgeUpdate runs 32-row tiles (4 workgroups per CU); the two-layer
+// MLPs and projections run 64- or 16-row tiles (FM_TM below is THEIR default).  64-row GVP tiles
+// (154 KB, one workgroup per CU) exist behind fm_config.tile_edge / tile_node for A/B runs only.
 //
 // Layout conventions
 //   * LDS activation tiles are row-major [row][ld] f32 with (ld/4) odd, so that the A-fragment read

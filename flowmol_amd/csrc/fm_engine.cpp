@@ -316,6 +316,7 @@ void fill_mlp(FmMlpArgs& a, const MlpW& w, int rows) {
     a.rows = rows; a.K1p = w.K1p; a.H = w.H; a.O = w.O;
     a.W1 = w.W1; a.b1 = w.b1; a.W2 = w.W2; a.b2 = w.b2;
     a.ldx = ld_for(w.K1p > w.O ? w.K1p : w.O); a.ldh = ld_for(w.H);
+    if (a.slabQ0 && a.ldh < 164) a.ldh = 164;      // SC_EDGE with the fused pair slab: the hidden tile later holds the K = 160 rows [rbf | ef]
 }
 template <int MODE>
 void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows, bool small_tiles = false) {
@@ -355,6 +356,9 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const bool small_node = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (N + 15) / 16 <= 4 * c->n_cus;      // decided per side: the node side
     const bool small_pair = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (U + 15) / 16 <= 4 * c->n_cus;      // stays small ~25x longer than the pair side
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
+    // pair-slab convolutions of this evaluation (first pass only; see fm_k_pair_slab)
+    const int n_pq = (HX == 0 && U > 0) ? c->n_pq : 0;
+    bool slab_done = false;
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -385,6 +389,11 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         e.prev_e = prev->e; e.prev_x = prev->x; e.x_t = state->x_t; e.T1 = c->T1; e.ef_tab = c->ef_tab;
         e.out = c->ef;
         e.p_e0 = b.p_e0; e.p_e1 = b.p_e1;
+        if (n_pq > 0) {      // the self-conditioning layer produces the edge features the first convolutions see: their pair slab in the same kernel
+            e.slabW0 = c->conv[0].Ws_slab; e.slabQ0 = c->Q[0];
+            if (n_pq > 1) { e.slabW1 = c->conv[1].Ws_slab; e.slabQ1 = c->Q[1]; }
+            slab_done = true;
+        }
         // one row per unordered pair, written to both directed edges; node and pair tiles share one launch
         if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U, small_mlp);
         else { launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N, small_node); launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U, small_pair); }
@@ -407,8 +416,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
     // Convolutions before the first molecule update (first pass only): the [rbf | ef] slab of their first scalar linear once per unordered
     // pair, both convolutions in one launch (fm_k_pair_slab); positions are still the input positions, edge features the embedding / SC output.
-    const int n_pq = (HX == 0 && U > 0) ? c->n_pq : 0;
-    if (n_pq > 0) {
+    if (n_pq > 0 && !slab_done) {      // bootstrap pass / models without self-conditioning / dense embeddings: a launch of its own
         FmPairSlabArgs ps{};
         ps.b = b; ps.x = x_t; ps.ef = c->ef; ps.W0 = c->conv[0].Ws_slab; ps.Q0 = c->Q[0];
         if (n_pq > 1) { ps.W1 = c->conv[1].Ws_slab; ps.Q1 = c->Q[1]; }

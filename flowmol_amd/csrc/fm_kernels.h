@@ -93,6 +93,9 @@ struct FmMlpArgs {
     const float* prev_e; const float* T1; const float* ef_tab;
     // TABLE with in == null: rows are the (a,c) token pairs, x = [emb_a[a] | emb_c[c] | temb] (or one-hots when emb_* are null)
     const float* emb_a; const float* emb_c; const float* temb; int ta, tc, tt;
+    // SC_EDGE with the pair-slab hoist fused (see fm_k_pair_slab): the tile's rows [rbf(d(x_t)) | ef] are rebuilt in Hb (ldh >= 164) after the
+    // epilogue and multiplied with the [rbf | ef] slabs of the first one or two convolutions' scalar linear -> Q0 / Q1 (U,256).  null = off
+    const float2* slabW0; float* slabQ0; const float2* slabW1; float* slabQ1;
     // TABLE, several tables in one launch (the embedding tables of a whole chunk of integration steps): workgroup b builds tile
     // b % tab_tiles of table b / tab_tiles, whose time embedding is temb + table * tt and whose rows start at out + table * tab_stride
     int tab_tiles; int tab_stride;
@@ -281,6 +284,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             }
         }
     } else if (MODE == FM_MLP_SC_EDGE) {
+        const bool slab = a.slabQ0 != nullptr;          // uniform
         if (grow < a.rows) {
             const int ea = meta[4 * TM + r], eb = meta[3 * TM + r], tok = meta[r];
             for (int c = sub * 4; c < 128; c += LPR * 4) {
@@ -289,7 +293,25 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
                 const float4 o = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
                 *reinterpret_cast<float4*>(a.out + (size_t)ea * 128 + c) = o;
                 *reinterpret_cast<float4*>(a.out + (size_t)eb * 128 + c) = o;
+                if (slab) *reinterpret_cast<float4*>(Hb + r * a.ldh + 32 + c) = o;      // the hidden layer is dead: its tile receives [rbf | ef]
             }
+        }
+        if (slab) {
+            // the new edge features are still on chip: the pair-symmetric slab of the first convolutions' scalar linear (fm_k_pair_slab) right here,
+            // instead of a kernel of its own that would gather the rows back from HBM
+            const float* dd = reinterpret_cast<const float*>(meta + TM);
+            for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
+                const int rr = idx >> 5, k = idx & 31;
+                Hb[rr * a.ldh + k] = fm_rbf(dd[2 * rr], k, a.rbf_mu_step, a.rbf_inv_sigma);      // rows beyond the batch: finite, never stored
+            }
+            __syncthreads();
+            fm_block_gemm<TM / 16, 2>(Hb, a.ldh, TM / 16, 20, a.slabW0, 16, [&](int row, int col, float v) {
+                if (row0 + row < a.rows) a.slabQ0[(size_t)(row0 + row) * 256 + col] = v;
+            });
+            if (a.slabQ1)
+                fm_block_gemm<TM / 16, 2>(Hb, a.ldh, TM / 16, 20, a.slabW1, 16, [&](int row, int col, float v) {
+                    if (row0 + row < a.rows) a.slabQ1[(size_t)(row0 + row) * 256 + col] = v;
+                });
         }
     } else {
         // softmax heads (vector_field.py:336-344,364-367): one lane per (row, head)

@@ -360,7 +360,7 @@ def long_report(g, traj, final):
     st = int(g['traj.x_stride'])
     ref_fr = g['traj.x'][1:]                                                     # frames st, 2 st, ... of the state trajectory (frame 0 = prior)
     got_fr = x[st - 1::st][:ref_fr.shape[0]]
-    res['x_frames_rel'] = float((got_fr - ref_fr).abs().max() / ref_fr.abs().max())
+    res['x_frames_rel'] = float((got_fr - ref_fr).abs().max() / ref_fr.abs().max()) if got_fr.numel() else 0.0     # fewer steps than the frame stride
     # how far the endpoint prediction is from the state: the coordinates' sensitivity to the network's arithmetic
     res['mean_rel_move'] = float(((x1 - x).flatten(1).norm(dim=1) / x.flatten(1).norm(dim=1))[: T - 2].mean())
     return res

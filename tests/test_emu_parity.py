@@ -414,8 +414,8 @@ def test_mlp_tile_sizes_on_emulation(emu_lib, small):
         assert not bad, (small, pair, bad)
 
 
-@pytest.mark.parametrize('name,sizes,prev', [('flowmol3', [5, 18, 2, 1], True), ('geom_ctmc', [6, 3, 9], False), ('arch_variants', [5, 9, 1, 4], True),
-                                             ('dev_narrow', [5, 3], True)])
+@pytest.mark.parametrize('name,sizes,prev', [('flowmol3', [5, 18, 2, 1], True), ('flowmol3', [5, 18, 2, 1], False), ('geom_ctmc', [6, 3, 9], False),
+                                             ('arch_variants', [5, 9, 1, 4], True), ('dev_narrow', [5, 3], True)])
 def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
     """The convolutions before the first molecule update take the [rbf | ef] slab of their first scalar linear from a per-pair table
     (fm_k_pair_slab + the PQ instances of fm_k_edge_message; fm_config.pair_slab, ABI 6) instead of recomputing it for both directed edges of
@@ -435,7 +435,9 @@ def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
         counts[flag] = eng.profile_get('pair_slab')[1]
         eng.profile(False)
         outs[flag] = {k: v.clone() for k, v in out.items()}
-    assert counts[-1] == 0 and counts[1] >= 1, counts
+    # self-conditioned evaluations compute the table inside the self-conditioning layer's kernel (no launch of its own); the bootstrap pass and
+    # models without self-conditioning launch fm_k_pair_slab
+    assert counts[-1] == 0 and (counts[1] == 0 if (prev and cfg.self_conditioning) else counts[1] >= 1), counts
     for k in 'xace':
         torch.testing.assert_close(outs[1][k], outs[-1][k], rtol=1e-4, atol=2e-6)
     assert any(not torch.equal(outs[1][k], outs[-1][k]) for k in 'xace')          # another summation order, not the same arithmetic

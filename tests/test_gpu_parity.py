@@ -83,6 +83,23 @@ def test_forward_matches_oracle(name, sizes, t, prev, tile):
         assert torch.allclose(out[k].sum(-1).cpu(), torch.ones(out[k].shape[0]), atol=1e-5)
 
 
+@pytest.mark.parametrize('tuning', [{'tile_edge': 64, 'tile_node': 64}, {'tile_edge_update': 64}, {'tile_edge': 64, 'tile_node': 64, 'tile_edge_update': 64, 'pair_slab': -1},
+                                    {'pair_slab': -1}, {'xcd_swizzle': -1, 'fuse_node': -1}])
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [70, 2, 47, 130], 0.3, True), ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False), ('flowmol3', [5, 9, 12, 3, 2], 0.0, False)])
+def test_forward_matches_oracle_under_every_accepted_tuning(name, sizes, t, prev, tuning):
+    """Every launch-tuning value fm_config accepts is parity-tested (VERDICT r3 hygiene #14): 64-row tiles of the GVP kernels and of EdgeUpdate
+    (accepted by fm_create, never chosen automatically), the pair-slab hoist switched off (ABI 6), and the unfused / unswizzled launch sequence."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = Engine(cfg, sd, device='cuda:0', precision='f32', tuning=tuning)
+    errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), t, prev)
+    _report(f'forward_tuning[{name},{sizes},{t},{tuning}]', errs)
+    bad = {k: v for k, v in errs.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
+    assert not bad, f'stages out of tolerance: {bad}'
+    eng.close()
+
+
 @pytest.mark.parametrize('fname,name', [('integrate_flowmol3_F7.npz', 'flowmol3'), ('integrate_qm9_C1.npz', 'qm9'),
                                         ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc'),
                                         ('integrate_geom_arom_T16.npz', 'geom_arom'), ('integrate_flowmol3_arom_T12.npz', 'flowmol3_arom')])
@@ -99,7 +116,8 @@ def test_integrate_matches_reference_golden(golden_dir, fname, name):
     assert (state['a_t'] != cfg.n_atom_types).all() and (state['e_t'] != cfg.n_bond_types).all()   # no mask tokens left
 
 
-@pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc')])
+@pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
+                                      ('flowmol3_geom64_T250', 'flowmol3')])
 def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
     """The product's DEFAULT protocol against the reference itself: free-running trajectories of the reference's own
     CTMCVectorField.integrate at n_timesteps = 250 (test.py:25, flowmol.py:46; 8 x 47 atoms, and a 5/33/60/90-atom batch with all weight
@@ -117,6 +135,7 @@ def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
     else:
         eng = Engine(cfg, weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale), device='cuda:0', precision='f32')
     res = integrate_long_golden(eng, cfg, g)
+    res['categorical_decisions'] = (int(g['T']) - 1) * int(2 * g['a_1'].numel() + g['e_1_upper'].numel())       # tempered argmax + unmask decisions: rows x steps
     _report(f'long[{tag}]', res)
     assert res['first_divergent_step'] is None and res['state_token_diffs_all_steps'] == 0, res
     assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0, res
@@ -1122,7 +1141,8 @@ def test_full_batch_reproduces_reference_long_trajectory(golden_dir, B, slots, n
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc')])
+@pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
+                                      ('flowmol3_geom64_T250', 'flowmol3')])
 def test_split_precision_long_horizon_flip_counts(golden_dir, tag, name):
     """The OPT-IN split precision on the reference's default-protocol trajectories: it is not f32 arithmetic, so token differences against the
     reference are COUNTED and reported (first divergent step, differing state tokens), not required to be zero; the run must stay finite, resolve
@@ -1134,6 +1154,7 @@ def test_split_precision_long_horizon_flip_counts(golden_dir, tag, name):
     scale = float(g['weight_scale'])
     eng = sp_engine_for(name)[2] if scale == 1 else Engine(cfg, weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale), device='cuda:0', precision='bf16x3')
     res = integrate_long_golden(eng, cfg, g)
+    res['categorical_decisions'] = (int(g['T']) - 1) * int(2 * g['a_1'].numel() + g['e_1_upper'].numel())
     _report(f'split_precision_long[{tag}]', res)
     n_tokens = int(g['a_1'].numel() + g['c_1'].numel() + g['e_1_upper'].numel())
     flips = res['a_flips'] + res['c_flips'] + res['e_flips']

@@ -292,7 +292,8 @@ def test_endpoint_parameterization_matches_reference(golden_dir):
     torch.testing.assert_close(out['e_1'][m], g['e_1_upper'], **TOL)
 
 
-LONG = [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc')]
+LONG = [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
+        ('flowmol3_geom64_T250', 'flowmol3')]       # 64 GEOM-sized molecules (r4): 3 steps here (1.3 s of oracle per evaluation)
 
 
 @pytest.mark.parametrize('tag,name', LONG)
@@ -307,7 +308,7 @@ def test_long_horizon_reference_trajectory_first_steps(golden_dir, tag, name):
     cfg = presets.PRESETS[name]()
     sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), float(g['weight_scale']))
     full = os.environ.get('FM_LONG_ORACLE') == '1'
-    res = oracle_long_golden(cpu_ref.OracleVF(cfg, sd), cfg, g, max_steps=None if full else 12)
+    res = oracle_long_golden(cpu_ref.OracleVF(cfg, sd), cfg, g, max_steps=None if full else (3 if int(g['n_atoms'].numel()) > 16 else 12))
     assert res['first_divergent_step'] is None and res['state_token_diffs_all_steps'] == 0, res
     assert res['x_norm_rel'] < 1e-5 and res['x1_norm_rel'] < 1e-5 and res['x_frames_rel'] < 1e-5, res
     if full:
