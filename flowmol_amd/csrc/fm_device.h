@@ -450,7 +450,7 @@ struct FmGvpTile {
 // SP = 1 (split precision, edge message only): X is NOT an f32 tile but the two bf16 planes XH = (u16*)X, XL = XH + TM*FM_LDP; the
 // scalar GEMM and the gate GEMM run on v_mfma_f32_16x16x32_bf16 with hi/lo operands; with LAST the f32 scalar output is kept in
 // registers and written as a plain f32 [TM][FM_LDX] tile over the (then dead) planes for the aggregation.  G must then alias Vh + TM*FM_LDG.
-// PQ (FIRST only): the [rbf | ef] slab of the scalar linear arrives inside `pre` (per-pair table, fm_k_pair_slab): X holds only the hidden-vector
+// PQ (FIRST only): the [rbf | ef] slab of the scalar linear arrives inside `pre` (per-pair table Q, FmMlpArgs::slabQ0): X holds only the hidden-vector
 // norms sh at columns [0, KU0) and the scalar GEMM has K = KU0.
 template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,

@@ -33,7 +33,7 @@ struct MlpW { const float2* W1; const float* b1; const float2* W2; const float* 
 
 struct ConvW {
     const float2* Wps; const float2* Wpv; const float* w0;
-    const float2* Ws_slab = nullptr;   // pair-slab convolutions: [rbf | ef] rows of GVP0's scalar linear (K = 160), for fm_k_pair_slab
+    const float2* Ws_slab = nullptr;   // pair-slab convolutions: [rbf | ef] rows of GVP0's scalar linear (K = 160), multiplied per pair in the SC_EDGE kernel
     const float2* Ws_sh = nullptr;     //                         and its remaining rows, the hidden-vector norms (K = KU0)
     const void* Wps_sp = nullptr;      // split precision
     FmGvpW dproj{}; const float2* Wsd = nullptr; const float2* Wpvd = nullptr;     // use_dst_feats: projection GVP + hoisted destination terms
@@ -63,7 +63,8 @@ struct fm_ctx {
     int pair_mlps_forced = -1;      // fm_config.pair_mlps
     int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
-    int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (fm_config.pair_slab = -1: 0)
+    int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (self-conditioned models; fm_config.pair_slab = -1: 0)
+    int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
@@ -268,7 +269,6 @@ size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
 }
 size_t lds_mlp(int ldx, int ldh, int tm = FM_TM) { return ((size_t)tm * ldx + (size_t)tm * ldh) * 4 + 5 * (size_t)tm * 4; }
 size_t lds_proj(int V, int tm = FM_TM) { return ((size_t)tm * 260 + 3 * (size_t)tm * (V + 4)) * 4; }
-size_t lds_pair_slab(int TM) { return (size_t)TM * 164 * 4 + (size_t)TM * 2 * 4; }
 size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
 size_t lds_edge_upd_sp(int TM) { return (size_t)TM * 132 * 4 + (size_t)TM * 176 * 2 * 2 + TM * 3 * 4; }
 
@@ -322,6 +322,10 @@ template <int MODE>
 void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int rows, bool small_tiles = false) {
     fill_mlp(a, w, rows);
     if (small_tiles) L(name, fm_k_mlp2<MODE, 16>, dim3((rows + 15) / 16), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh, 16), a);
+    else if (MODE == FM_MLP_SC_EDGE && a.slabQ0)
+        // with the pair slab the kernel is matrix-pipe work followed by 3 KB of row stores per pair: 32-row tiles (38 KB of LDS) put four
+        // independent workgroups on a CU instead of two, so that one's stores overlap the others' GEMMs
+        L(name, fm_k_mlp2<FM_MLP_SC_EDGE, 32>, dim3((rows + 31) / 32), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh, 32), a);
     else L(name, fm_k_mlp2<MODE>, dim3((rows + FM_TM - 1) / FM_TM), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
 }
 template <int MODE_A, int MODE_B>
@@ -356,9 +360,9 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const bool small_node = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (N + 15) / 16 <= 4 * c->n_cus;      // decided per side: the node side
     const bool small_pair = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (U + 15) / 16 <= 4 * c->n_cus;      // stays small ~25x longer than the pair side
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
-    // pair-slab convolutions of this evaluation (first pass only; see fm_k_pair_slab)
-    const int n_pq = (HX == 0 && U > 0) ? c->n_pq : 0;
-    bool slab_done = false;
+    // pair-slab convolutions of this evaluation (first pass only; FmMlpArgs::slabQ0): self-conditioned evaluations with at least four rounds of
+    // 32-row pair tiles (measured neutral on small batches: the table costs a kernel phase, the saving is matrix-pipe time they are not bound by)
+    const int n_pq = (HX == 0 && prev && !dense && (c->pq_forced ? U > 0 : (U + 31) / 32 >= 16 * c->n_cus)) ? c->n_pq : 0;
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -392,7 +396,6 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         if (n_pq > 0) {      // the self-conditioning layer produces the edge features the first convolutions see: their pair slab in the same kernel
             e.slabW0 = c->conv[0].Ws_slab; e.slabQ0 = c->Q[0];
             if (n_pq > 1) { e.slabW1 = c->conv[1].Ws_slab; e.slabQ1 = c->Q[1]; }
-            slab_done = true;
         }
         // one row per unordered pair, written to both directed edges; node and pair tiles share one launch
         if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U, small_mlp);
@@ -414,16 +417,6 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     // fm_config.fuse_node = -1 keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own (0 / 1 = fused)
     const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
     const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
-    // Convolutions before the first molecule update (first pass only): the [rbf | ef] slab of their first scalar linear once per unordered
-    // pair, both convolutions in one launch (fm_k_pair_slab); positions are still the input positions, edge features the embedding / SC output.
-    if (n_pq > 0 && !slab_done) {      // bootstrap pass / models without self-conditioning / dense embeddings: a launch of its own
-        FmPairSlabArgs ps{};
-        ps.b = b; ps.x = x_t; ps.ef = c->ef; ps.W0 = c->conv[0].Ws_slab; ps.Q0 = c->Q[0];
-        if (n_pq > 1) { ps.W1 = c->conv[1].Ws_slab; ps.Q1 = c->Q[1]; }
-        ps.rbf_mu_step = c->rbf_mu_step; ps.rbf_inv_sigma = c->rbf_inv_sigma;
-        if (small_pair) L("pair_slab", fm_k_pair_slab<16>, dim3((U + 15) / 16), blk, lds_pair_slab(16), ps);
-        else L("pair_slab", fm_k_pair_slab<64>, dim3((U + 63) / 64), blk, lds_pair_slab(64), ps);
-    }
     for (int it = 0; it < n_pass; ++it) {
         const int i = it % cf.n_convs;
         const ConvW& cw = c->conv[i];
@@ -909,7 +902,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     c->small_mlp_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles > 0);
     // pair-slab hoist: the convolutions that run before any molecule update see pair-symmetric edge features and distances
     c->n_pq = 0;
-    if (cfg->pair_slab >= 0 && HX == 0 && cfg->precision == FM_PREC_F32)
+    c->pq_forced = cfg->pair_slab > 0;
+    if (cfg->pair_slab >= 0 && HX == 0 && cfg->precision == FM_PREC_F32 && cfg->self_conditioning)
         for (int i = 0; i < cfg->n_convs && i < 2; ++i) {
             bool clean = true;
             for (int j = 0; j < i; ++j) clean &= cfg->update_after[j] < 0;
@@ -940,11 +934,11 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
-    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32)); set_lds(fm_k_pair_slab<64>, lds_pair_slab(64)); set_lds(fm_k_pair_slab<16>, lds_pair_slab(16));
+    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
-    set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max);
+    set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 32>, mlp_max);
     set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>, mlp_max);
     const size_t mlp_small = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260, 16);
     set_lds(fm_k_mlp2<FM_MLP_SC_NODE, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_TABLE, 16>, mlp_small);

@@ -93,8 +93,13 @@ struct FmMlpArgs {
     const float* prev_e; const float* T1; const float* ef_tab;
     // TABLE with in == null: rows are the (a,c) token pairs, x = [emb_a[a] | emb_c[c] | temb] (or one-hots when emb_* are null)
     const float* emb_a; const float* emb_c; const float* temb; int ta, tc, tt;
-    // SC_EDGE with the pair-slab hoist fused (see fm_k_pair_slab): the tile's rows [rbf(d(x_t)) | ef] are rebuilt in Hb (ldh >= 164) after the
-    // epilogue and multiplied with the [rbf | ef] slabs of the first one or two convolutions' scalar linear -> Q0 / Q1 (U,256).  null = off
+    // SC_EDGE with the pair-slab hoist.  The convolutions that run BEFORE the first EdgeUpdate / NodePositionUpdate (vector_field.py:320-326:
+    // convs 0 and 1 of every shipped schedule) see edge features that are identical for the two directed edges of a pair (this layer writes its
+    // output to both triangles, self_conditioning.py:78-81) and the same rbf(d), so the K = 160 slab [rbf(d) | ef] x Ws[rbf|ef rows] of their
+    // first scalar GEMM is the same vector for both directions.  It is computed HERE, once per unordered pair, while the new edge features are
+    // still on chip: the tile's rows [rbf(d(x_t)) | ef] are rebuilt in Hb (ldh >= 164) after the epilogue and multiplied with the slabs of the
+    // first one or two convolutions -> Q0 / Q1 (U,256), which the PQ instances of fm_k_edge_message gather like the hoisted Ps[src]:
+    // 40,960 of 248,064 executed MAC per edge leave the edge kernel for 20,480 per edge here.  null = off
     const float2* slabW0; float* slabQ0; const float2* slabW1; float* slabQ1;
     // TABLE, several tables in one launch (the embedding tables of a whole chunk of integration steps): workgroup b builds tile
     // b % tab_tiles of table b / tab_tiles, whose time embedding is temb + table * tt and whose rows start at out + table * tab_stride
@@ -297,7 +302,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             }
         }
         if (slab) {
-            // the new edge features are still on chip: the pair-symmetric slab of the first convolutions' scalar linear (fm_k_pair_slab) right here,
+            // the new edge features are still on chip: the pair-symmetric slab of the first convolutions' scalar linear right here,
             // instead of a kernel of its own that would gather the rows back from HBM
             const float* dd = reinterpret_cast<const float*>(meta + TM);
             for (int idx = tid; idx < TM * 32; idx += FM_THREADS) {
@@ -505,69 +510,6 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_dst_proj(FmDstProjArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pair-symmetric part of the first edge GVP's scalar linear, for the convolutions that run BEFORE the first EdgeUpdate /
-// NodePositionUpdate (vector_field.py:320-326: convs 0 and 1 of every shipped schedule): until then the edge features of the two
-// directed edges of a pair are identical (token-table rows or the self-conditioning layer's output written to both triangles,
-// self_conditioning.py:78-81; dense pair embeddings likewise) and so is rbf(d), so the K = 160 slab [rbf(d) | ef] x Ws[rbf|ef rows]
-// of GVP0's scalar GEMM is the same vector for both directions.  It is computed here once per UNORDERED pair (Q: (U,256)) and
-// gathered by the edge-message kernel like the hoisted Ps[src]: 40,960 of 248,064 executed MAC per edge leave the edge kernel
-// for 20,480 here.  One launch serves both convolutions (same input rows, two weight slabs).
-// ------------------------------------------------------------------------------------------------
-struct FmPairSlabArgs {
-    FmBatch b;
-    const float* x;            // (N,3) positions (unchanged until the first NodePositionUpdate)
-    const float* ef;           // (E,128), pair-symmetric at this point
-    const float2* W0; float* Q0;
-    const float2* W1; float* Q1;     // null: only one convolution precedes the first update
-    float rbf_mu_step, rbf_inv_sigma;
-};
-
-template <int TM>
-__global__ void __launch_bounds__(FM_THREADS) fm_k_pair_slab(FmPairSlabArgs a) {
-    HIP_DYNAMIC_SHARED(float, lds)
-    constexpr int LDX = 164, MT = TM / 16;          // 164/4 = 41 odd
-    float* X = lds;                                  // [TM][164]: rbf(32) | ef(128)
-    int* m_e = reinterpret_cast<int*>(X + TM * LDX); // [TM] upper edge of the pair, -1 = no row
-    float* m_d = reinterpret_cast<float*>(m_e + TM);
-    const int tid = threadIdx.x, p0 = blockIdx.x * TM;
-    if (tid < TM) {
-        const int p = p0 + tid;
-        int ea = -1; float d = 0.f;
-        if (p < a.b.U) {
-            ea = a.b.p_e0[p];
-            const int i = a.b.e_src[ea], j = a.b.e_dst[ea];
-            d = fm_norm3(a.x[i * 3] - a.x[j * 3], a.x[i * 3 + 1] - a.x[j * 3 + 1], a.x[i * 3 + 2] - a.x[j * 3 + 2]) + 1e-8f;
-        }
-        m_e[tid] = ea; m_d[tid] = d;
-    }
-    __syncthreads();
-    {
-        constexpr int NQ = TM * 32 / FM_THREADS;
-        float4 q[NQ];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
-            const int ea = m_e[r];
-            q[k] = ea >= 0 ? reinterpret_cast<const float4*>(a.ef)[(size_t)ea * 32 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
-            *reinterpret_cast<float4*>(X + r * LDX + 32 + 4 * c4) = q[k];
-            X[r * LDX + c4] = fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma);
-        }
-    }
-    __syncthreads();
-    fm_block_gemm<MT, 2>(X, LDX, MT, 20, a.W0, 16, [&](int row, int col, float v) {
-        if (p0 + row < a.b.U) a.Q0[(size_t)(p0 + row) * 256 + col] = v;
-    });
-    if (a.Q1)
-        fm_block_gemm<MT, 2>(X, LDX, MT, 20, a.W1, 16, [&](int row, int col, float v) {
-            if (p0 + row < a.b.U) a.Q1[(size_t)(p0 + row) * 256 + col] = v;
-        });
-}
-
-// ------------------------------------------------------------------------------------------------
 // fused GVPConv edge message + aggregation  (reference gvp.py:476-492, 523-543)
 //   per directed edge j->i: GVP0([s_j|rbf|ef], [xhat_ji|v_j]) -> GVP1 -> GVP2, summed over j per destination i.
 //   Output: per (destination, piece) partial sums; a destination's in-edges are contiguous in the
@@ -587,14 +529,14 @@ struct FmMsgArgs {
     float* part_v;            // (N, P, 3, V)
     float rbf_mu_step, rbf_inv_sigma;
     float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
-    const float* Q;           // (U,256) PQ instances: the pair-symmetric [rbf | ef] slab of GVP0's scalar linear (fm_k_pair_slab)
+    const float* Q;           // (U,256) PQ instances: the pair-symmetric [rbf | ef] slab of GVP0's scalar linear (FmMlpArgs::slabQ0, written by the SC_EDGE kernel)
     int xcd_chunk;            // > 0: workgroup b handles tile (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk); 0: tile = b
 };
 
 // SP = 1: opt-in split-precision instance (fm_device.h "bf16x3"): the scalar tile is two bf16 planes (TM * FM_LDP * 4 bytes, 4.6 KB more
 // than the f32 tile) and the gate buffer lives inside Vh (dead whenever gates exist), so that two workgroups still share a CU.
 // PQ = 1: instance for the convolutions before the first molecule update: the [rbf | ef] slab of GVP0's scalar linear comes from the per-pair
-// table Q (fm_k_pair_slab) like the hoisted Ps[src]; the tile neither loads ef nor evaluates the 32 radial basis functions, and GVP0's scalar
+// table Q (written by the self-conditioning edge kernel, FmMlpArgs::slabQ0) like the hoisted Ps[src]; the tile neither loads ef nor evaluates the 32 radial basis functions, and GVP0's scalar
 // GEMM shrinks from K = 200 to K = 40 (the hidden-vector norms).
 template <int V, int TM, int NTH, int HX, int SP, int PQ = 0>
 __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {

@@ -106,7 +106,8 @@ typedef struct fm_config {
     int32_t mlp_small_tiles;      /* 16-row tiles for the MLP kernels: 0 = while they do not fill the chip | 1 always | -1 never */
     /* --- ABI 6 */
     int32_t pair_slab;            /* [rbf | ef] slab of the first edge GVP once per unordered pair for the convolutions before the first molecule
-                                   * update (pair-symmetric inputs; f32 models without destination features): 0 / 1 = on | -1 = off */
+                                   * update (pair-symmetric inputs; self-conditioned f32 models without destination features): 0 = in evaluations
+                                   * whose pair tiles fill the chip | 1 = in every self-conditioned evaluation | -1 = off */
 } fm_config;
 
 enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1 };
