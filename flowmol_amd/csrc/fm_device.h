@@ -201,10 +201,22 @@ __device__ __forceinline__ void fm_frag_mma(f32x4 (&acc)[MT][NT], const float2 (
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
 }
 
+// only the first of a k-superstep's two MFMA passes: k-slots 8ks + {0, 2, 4, 6}.  For a LAST superstep whose odd slots are zero by construction
+// (fm_gvp_core lays the four cross-product norms out on the even slots of its last superstep) -- the all-zero second pass is not issued.
+template <int MT, int NT>
+__device__ __forceinline__ void fm_frag_mma_x(f32x4 (&acc)[MT][NT], const float2 (&a)[MT], const float2 (&b)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+}
+
 // Software-pipelined over k-supersteps: the A (LDS) and B (L2) fragments of step ks+1 are requested
 // before the MFMAs of step ks are issued, so one wave covers its own load latency (only 2 waves share
 // a SIMD).  Two named register sets, manually unrolled by 2 (no runtime-indexed register arrays).
-template <int MT, int NT>
+// TAILX: the odd k-slots of the LAST superstep are zero in A and in the packed weights -- its second MFMA pass is skipped (fm_frag_mma_x).
+template <int MT, int NT, bool TAILX = false>
 __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* A, int lda, int K8,
                                              const float2* __restrict__ Wp, int ntiles, int nt0, int lane) {
     const float* ap = A + (lane & 15) * lda + 2 * (lane >> 4);
@@ -228,12 +240,13 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
         __builtin_amdgcn_sched_barrier(0);
         if (ks + 4 < K8) fm_frag_load<MT, NT>(a1, b1, ap, lda, wp, wstep, ks + 4, lane);
         __builtin_amdgcn_sched_barrier(0);
-        fm_frag_mma<MT, NT>(acc, a2, b2);
+        if (TAILX && ks + 3 == K8) fm_frag_mma_x<MT, NT>(acc, a2, b2);
+        else fm_frag_mma<MT, NT>(acc, a2, b2);
         __builtin_amdgcn_sched_barrier(0);
     }
     // tail: K8 - ks in {0, 1, 2} steps are already loaded in (a0,b0), (a1,b1)
-    if (ks < K8) fm_frag_mma<MT, NT>(acc, a0, b0);
-    if (ks + 1 < K8) fm_frag_mma<MT, NT>(acc, a1, b1);
+    if (ks < K8) { if (TAILX && ks + 1 == K8) fm_frag_mma_x<MT, NT>(acc, a0, b0); else fm_frag_mma<MT, NT>(acc, a0, b0); }
+    if (ks + 1 < K8) { if (TAILX) fm_frag_mma_x<MT, NT>(acc, a1, b1); else fm_frag_mma<MT, NT>(acc, a1, b1); }
 }
 
 // Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
@@ -468,6 +481,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int K8S = (SOFF + KUC) / 8;
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
     constexpr int CPSRC = FIRST ? T::KU0 : V;            // where the 8 Vcp channels sit in Vh
+    // sh layout in X: [norms of the H hidden channels | the 4 cross-product norms | 0].  Non-first GVPs: H is a multiple of 8, so the last
+    // k-superstep of the scalar GEMM holds only the four cross-product norms -- laid out on its EVEN k-slots (H, H+2, H+4, H+6; zeros between,
+    // weights packed to match: pack_gvp) so that the superstep's second MFMA pass is all zero and is skipped (TAILX): 1 of 74 passes per GEMM.
+    constexpr int CPS = FIRST ? 1 : 2;                   // column stride of the cross-product norms
+    static_assert(FIRST || (H % 8 == 0 && KUC == H + 8), "the interleaved tail needs the cross-product norms alone in the last k-superstep");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // biases of this lane's accumulator columns, requested first: their L2 latency hides behind the vector phases
     float bias_s[NTW];
@@ -505,8 +523,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(0 * TM + r) * T::LDVH + H + p] = cx;
         Vh[(1 * TM + r) * T::LDVH + H + p] = cy;
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
-        if (SP) fm_split_store(XH, XL, r, SOFF + H + p, fm_norm3(cx, cy, cz));
-        else X[r * FM_LDX + SOFF + H + p] = fm_norm3(cx, cy, cz);
+        if (SP) fm_split_store(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
+        else X[r * FM_LDX + SOFF + H + CPS * p] = fm_norm3(cx, cy, cz);
     }
     // thread -> (row, 16-column group): no integer division by V+8 in the index math
     for (int r = tid >> 4; r < TM; r += NTH / 16) {
@@ -519,7 +537,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 const float vz = Vh[(2 * TM + r) * T::LDVH + c];
                 if (SP) fm_split_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
                 else X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
-            } else if (c >= H + 4 && c < KUC) {
+            } else if (FIRST ? (c >= H + 4 && c < KUC) : (c < KUC && ((c - H) & 1))) {      // K padding (first GVP) / the odd slots between the cross-product norms
                 if (SP) { XH[r * FM_LDP + SOFF + c] = 0; XL[r * FM_LDP + SOFF + c] = 0; }
                 else X[r * FM_LDX + SOFF + c] = 0.f;
             }
@@ -548,7 +566,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         }
         FM_MARKB(2);
         if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
-        else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
+        else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW, !FIRST>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);

@@ -244,13 +244,18 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vo
         if (n < V + 8) return Wcp[k * 8 + (n - V)];
         return 0.f; }));
     B.put(g.Wu, pack(V + 8, vop, [&](int k, int n) -> float { return (k < V + 4 && n < vout) ? Wu[k * vout + n] : 0.f; }));
-    // tile K order [s (256 columns, S real) | sh (V+4) | 0]; reference order [s (S) | sh (V+4)]
-    pack_linear(B, g.Ws, Ws, S, V + 4 + S, 256 + V + 8, 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : (k < 256 + V + 4 ? S + (k - 256) : -1); });
+    // tile K order [s (256 columns, S real) | norms of the V hidden channels | cp norm 0, 0, cp norm 1, 0, cp norm 2, 0, cp norm 3, 0]: the four
+    // cross-product norms sit on the even k-slots of the last k-superstep (fm_gvp_core: its all-zero second MFMA pass is skipped);
+    // reference order [s (S) | sh (V+4)]
+    auto kmap_s = [&](int k) { if (k < 256) return k < S ? k : -1;
+                               const int o = k - 256; if (o < V) return S + o;
+                               return ((o - V) & 1) ? -1 : S + V + (o - V) / 2; };
+    pack_linear(B, g.Ws, Ws, S, V + 4 + S, 256 + V + 8, 256, kmap_s);
     pad_vec(B, g.bs, bs, S, 256);
     pack_linear(B, g.Wg, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
     pad_vec(B, g.bg, bg, vout, vop);
     if (sp) {
-        pack_linear_sp(B, g.Ws_sp, Ws, S, V + 4 + S, 256 + V + 8, 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : (k < 256 + V + 4 ? S + (k - 256) : -1); });
+        pack_linear_sp(B, g.Ws_sp, Ws, S, V + 4 + S, 256 + V + 8, 256, kmap_s);
         pack_linear_sp(B, g.Wg_sp, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
     }
     return true;
