@@ -208,7 +208,7 @@ class Engine:
         """``precision``: 'f32' (default, also for None; the reference's arithmetic) or 'bf16x3' (OPT-IN split precision of the edge-message
         GEMMs on the bf16 matrix cores: faster, ~10x larger per-stage error, never used for parity claims).  It is an explicit argument
         only -- no environment variable changes what an Engine computes -- and is recorded in ``self.precision``.
-        ``tuning``: launch-tuning overrides of fm_config (ABI 5: tile_edge, tile_node, tile_edge_update, xcd_swizzle, fuse_node, pair_mlps,
+        ``tuning``: launch-tuning overrides of fm_config (ABI 5 / 6: tile_edge, tile_node, tile_edge_update, xcd_swizzle, fuse_node, pair_mlps, pair_slab,
         mlp_small_tiles; 0 / absent = automatic) for A/B measurements and the parity tests that run every tile size."""
         precision = precision or 'f32'
         if precision not in ('f32', 'bf16x3'):
