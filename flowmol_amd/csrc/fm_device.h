@@ -160,6 +160,13 @@ __device__ __forceinline__ void fm_buf_store_f32(R rs, int voff, int soff, float
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
 }
 template <class R>
+__device__ __forceinline__ void fm_buf_store_f32x2(R rs, int voff, int soff, float x, float y) {
+    typedef unsigned fm_u32x2 __attribute__((ext_vector_type(2)));
+    fm_u32x2 d;
+    d[0] = __builtin_bit_cast(unsigned, x); d[1] = __builtin_bit_cast(unsigned, y);
+    __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, 0);
+}
+template <class R>
 __device__ __forceinline__ void fm_buf_store_f32x4(R rs, int voff, int soff, float4 v) {
     typedef unsigned fm_u32x4 __attribute__((ext_vector_type(4)));
     fm_u32x4 d;

@@ -331,6 +331,10 @@ void launch_mlp(Launch& L, const char* name, FmMlpArgs a, const MlpW& w, int row
         // with the pair slab the kernel is matrix-pipe work followed by 3 KB of row stores per pair: 32-row tiles (38 KB of LDS) put four
         // independent workgroups on a CU instead of two, so that one's stores overlap the others' GEMMs
         L(name, fm_k_mlp2<FM_MLP_SC_EDGE, 32>, dim3((rows + 31) / 32), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh, 32), a);
+    else if (MODE == FM_MLP_EDGE_HEAD && (rows + 31) / 32 >= 16 * L.c->n_cus)
+        // large batches: the pair head is a gather of two 512-byte rows per pair in front of 17 k MAC -- latency / HBM work; 32-row tiles (34 KB of LDS)
+        // put four workgroups on a CU instead of two
+        L(name, fm_k_mlp2<FM_MLP_EDGE_HEAD, 32>, dim3((rows + 31) / 32), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh, 32), a);
     else L(name, fm_k_mlp2<MODE>, dim3((rows + FM_TM - 1) / FM_TM), dim3(FM_THREADS), lds_mlp(a.ldx, a.ldh), a);
 }
 template <int MODE_A, int MODE_B>
@@ -943,7 +947,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
-    set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 32>, mlp_max);
+    set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 32>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD, 32>, mlp_max);
     set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>, mlp_max);
     const size_t mlp_small = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260, 16);
     set_lds(fm_k_mlp2<FM_MLP_SC_NODE, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_TABLE, 16>, mlp_small);

@@ -310,13 +310,27 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
                 Hb[rr * a.ldh + k] = fm_rbf(dd[2 * rr], k, a.rbf_mu_step, a.rbf_inv_sigma);      // rows beyond the batch: finite, never stored
             }
             __syncthreads();
-            fm_block_gemm<TM / 16, 2>(Hb, a.ldh, TM / 16, 20, a.slabW0, 16, [&](int row, int col, float v) {
-                if (row0 + row < a.rows) a.slabQ0[(size_t)(row0 + row) * 256 + col] = v;
-            });
-            if (a.slabQ1)
-                fm_block_gemm<TM / 16, 2>(Hb, a.ldh, TM / 16, 20, a.slabW1, 16, [&](int row, int col, float v) {
-                    if (row0 + row < a.rows) a.slabQ1[(size_t)(row0 + row) * 256 + col] = v;
-                });
+            // Q rows are stored in ACCUMULATOR order: [wave w (8)][column i within a tile (16)][j (2)] = slab column 16 (2w + j) + i -- what lane i of
+            // wave w holds for its two column tiles here, and what lane i of wave w needs for ITS two column tiles in fm_k_edge_message's scalar GEMM
+            // (same ownership: wave w <-> column tiles 2w, 2w+1).  So a row is written with one 8-byte store per lane and later gathered with one
+            // 8-byte load per lane, through tile-relative buffer descriptors (no 64-bit address arithmetic; rows beyond the batch are dropped).
+            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int left = a.rows - row0;
+            auto slab_gemm = [&](const float2* __restrict__ W, float* Q) {
+                constexpr int MT = TM / 16;
+                f32x4 acc[MT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                fm_wave_gemm<MT, 2>(acc, Hb, 164, 20, W, 16, 2 * wave, lane);
+                const auto rs = fm_buf(Q + (size_t)row0 * 256, (unsigned)(left < TM ? left : TM) * 1024u);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fm_buf_store_f32x2(rs, (i * 16 + 4 * (lane >> 4) + q) * 1024 + (lane & 15) * 8, wave * 128, acc[i][0][q], acc[i][1][q]);
+            };
+            slab_gemm(a.slabW0, a.slabQ0);
+            if (a.slabQ1) slab_gemm(a.slabW1, a.slabQ1);
         }
     } else {
         // softmax heads (vector_field.py:336-344,364-367): one lane per (row, head)
@@ -529,7 +543,8 @@ struct FmMsgArgs {
     float* part_v;            // (N, P, 3, V)
     float rbf_mu_step, rbf_inv_sigma;
     float* dbg_s; float* dbg_v;   // optional: per-edge messages (E,256),(E,3,V) for debugging, else null
-    const float* Q;           // (U,256) PQ instances: the pair-symmetric [rbf | ef] slab of GVP0's scalar linear (FmMlpArgs::slabQ0, written by the SC_EDGE kernel)
+    const float* Q;           // (U,256) PQ instances: the pair-symmetric [rbf | ef] slab of GVP0's scalar linear (FmMlpArgs::slabQ0, written by the SC_EDGE kernel
+                              // in accumulator order: row[w * 32 + i * 2 + j] = column 16 (2w + j) + i)
     int xcd_chunk;            // > 0: workgroup b handles tile (b % 8) * xcd_chunk + b / 8 (grid = 8 * xcd_chunk); 0: tile = b
 };
 
@@ -612,8 +627,17 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     float preq[PQ ? TM / 16 : 1][PQ ? 1024 / NTH : 1][4];
     if constexpr (PQ) {      // the pair's slab row, requested right behind Ps[src]; summed into `pre` after the fill below (VMEM returns in order:
                              // once the fill's own gathers have arrived these have too, so the sum waits for nothing)
+        static_assert(!PQ || NTH == 512, "Q rows are laid out for 8 waves x 2 column tiles");
         const int pmin = __builtin_amdgcn_readfirstlane(m_doff[TM]);
-        fm_gather_pre<TM, NTH, false>(preq, a.Q + (size_t)pmin * 256, 0x7fffffff / 1024, m_doff);
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const auto rs = fm_buf(a.Q + (size_t)pmin * 256, 0x7ffffc00u);
+#pragma unroll
+        for (int i = 0; i < TM / 16; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {       // one 8-byte load per row: the row's values for this lane's two column tiles sit side by side (accumulator order)
+                const float2 t = fm_buf_f32x2(rs, m_doff[i * 16 + 4 * (lane >> 4) + r] + (lane & 15) * 8, wave * 128);
+                preq[i][0][r] = t.x; preq[i][1][r] = t.y;
+            }
     }
     // (D) X[:, 0..31] = rbf(d), X[:, 32..159] = ef; hidden vectors of GVP0: Vh[c*TM+r][:] = PV[src][c][:] + xhat[r][c]*w0[:]
     //     All gathers of a thread are issued back to back (unconditional loads from a clamped index, select afterwards):

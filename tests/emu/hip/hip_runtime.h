@@ -147,10 +147,14 @@ static inline emu_u32x4 emu_raw_buffer_load_b128(emu_rsrc r, int voff, int soff,
 static inline void emu_raw_buffer_store_b32(unsigned d, emu_rsrc r, int voff, int soff, int) {
     if (emu_buf_ok(r, voff, 4)) memcpy(r.base + (unsigned)voff + (unsigned)soff, &d, 4);
 }
+static inline void emu_raw_buffer_store_b64(emu_u32x2 d, emu_rsrc r, int voff, int soff, int) {
+    if (emu_buf_ok(r, voff, 8)) memcpy(r.base + (unsigned)voff + (unsigned)soff, &d, 8);
+}
 static inline void emu_raw_buffer_store_b128(emu_u32x4 d, emu_rsrc r, int voff, int soff, int) {
     if (emu_buf_ok(r, voff, 16)) memcpy(r.base + (unsigned)voff + (unsigned)soff, &d, 16);
 }
 #define __builtin_amdgcn_raw_buffer_store_b128 emu_raw_buffer_store_b128
+#define __builtin_amdgcn_raw_buffer_store_b64 emu_raw_buffer_store_b64
 #define __builtin_amdgcn_make_buffer_rsrc emu_make_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b32 emu_raw_buffer_load_b32
 #define __builtin_amdgcn_raw_buffer_load_b64 emu_raw_buffer_load_b64
