@@ -34,17 +34,33 @@ bench = json.loads((G / f'{gtag}_bench_{name}.json').read_text().strip().splitli
 (P / f'{ptag}_bench.json').write_text(json.dumps(bench) + '\n')
 
 
-def counter(txt, kernel, cname):
-    blk = txt[txt.index(kernel):]
-    return float(re.search(rf'{cname}\s+([0-9.]+)', blk).group(1))
+def instances(txt, prefix):
+    """{kernel instance name: (dispatches, {counter: per-dispatch average})} of every summary block whose kernel name starts with `prefix`."""
+    out = {}
+    for blk in re.split(r'\n\s*\n', txt):
+        m = re.match(r'\s*(' + re.escape(prefix) + r'<[^>]*>)\S*\s+dispatches=(\d+)', blk)
+        if m:
+            out[m.group(1)] = (int(m.group(2)), {c: float(v) for c, v in re.findall(r'^\s+(\w+)\s+([0-9.]+)\s*$', blk, re.M)})
+    return out
 
 
-k = re.search(r'fm_k_edge_message<[^>]*>', sq).group(0)
+def counter(txt, prefix, cname):
+    """Dispatch-weighted per-launch average of a counter over all instances of a kernel (the step runs fm_k_edge_message as full and as
+    pair-slab (PQ) instances: `achieved` in bench.py is the average over the step's launches, so is this)."""
+    inst = instances(txt, prefix)
+    n = sum(d for d, _ in inst.values())
+    return sum(d * c[cname] for d, c in inst.values()) / n
+
+
+k = 'fm_k_edge_message'
+k_names = sorted(instances(sq, k))
 f, w = counter(fetch, k, 'FETCH_SIZE'), counter(write, k, 'WRITE_SIZE')
 E = bench['config']['directed_edges_per_gpu']
 N = bench['config']['nodes_per_gpu']
 traffic = {
-    'kernel': k, 'workload': bench['config']['workload'],
+    'kernel': ' + '.join(k_names) + ' (dispatch-weighted average over the instances)', 'workload': bench['config']['workload'],
+    'per_instance': {name: {'dispatches': d, 'FETCH_SIZE_KiB': instances(fetch, k).get(name, (0, {}))[1].get('FETCH_SIZE'), 'WRITE_SIZE_KiB': instances(write, k).get(name, (0, {}))[1].get('WRITE_SIZE'),
+                            'mfma_busy_frac': c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024)} for name, (d, c) in instances(sq, k).items()},
     'source': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py ... --no-cpu-baseline --no-api-e2e`, '
               f'per-dispatch averages: profiles/{ptag}_pmc_fetch.txt, profiles/{ptag}_pmc_write_tcc.txt',
     'FETCH_SIZE_KiB': f, 'WRITE_SIZE_KiB': w,
@@ -69,7 +85,7 @@ if '--current' in sys.argv:
     except Exception:
         allw = {}
     allw[wl] = {'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'collected_at_commit': commit, 'library_digest': bench['config'].get('library_digest'),
-                'kernel': k, 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'], 'source': f'profiles/{ptag}_traffic.json',
+                'kernel': ' + '.join(k_names), 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'], 'source': f'profiles/{ptag}_traffic.json',
                 'mfma_busy_frac': busy / (gui / 8 * 1024), 'source_sq': f'profiles/{ptag}_pmc_sq.txt',
                 'note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs = 256 CUs x 4'}
     path.write_text(json.dumps(allw, indent=1) + '\n')

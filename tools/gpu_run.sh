@@ -10,7 +10,7 @@
 #   ab <reps> <lib>... [-- ab_bench args]    tools/ab_bench.py on every library, alternating, <reps> times -> <tag>_ab.jsonl
 #   latency [latency_sweep args] tools/latency_sweep.py       -> <tag>_latency.jsonl
 #   profile <name> [bench args]  rocprofv3 --kernel-trace --stats, then three separate PMC passes (SQ / FETCH / WRITE+TCC) of
-#                                `python bench.py <args> --no-cpu-baseline --no-api-e2e`   -> <tag>_prof_<name>/{stats,pmc_sq,pmc_fetch,pmc_write}
+#                                `python bench.py <args> --no-cpu-baseline --no-api-e2e --no-secondary`   -> <tag>_prof_<name>/{stats,pmc_sq,pmc_fetch,pmc_write}
 #   pmc <name> "<counters>" [bench args]     one extra PMC pass with the given counters -> <tag>_prof_<name>/pmc_extra
 #   py <script> [args]           python <script> [args]       -> <tag>_py.log (appended)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
@@ -30,7 +30,7 @@ run_step() {
              done; done ;;
     latency) timeout 400 python $R/tools/latency_sweep.py "$@" 2>&1 | grep '^{' | tee -a $O/${TAG}_latency.jsonl | cut -c1-500 ;;
     profile) local n=$1; shift; local D=$O/${TAG}_prof_$n; rm -rf $D; mkdir -p $D
-             local B="python $R/bench.py $* --no-cpu-baseline --no-api-e2e"
+             local B="python $R/bench.py $* --no-cpu-baseline --no-api-e2e --no-secondary"
              timeout 700 rocprofv3 --kernel-trace --stats -d $D/stats -o s -- $B > $D/stats.log 2>&1
              timeout 700 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $D/pmc_sq -o p -- $B > $D/pmc_sq.log 2>&1
              timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $D/pmc_fetch -o p -- $B > $D/pmc_fetch.log 2>&1
@@ -41,7 +41,7 @@ run_step() {
                find $D/$k -name '*_results.db' -delete          # summaries travel back, the databases (tens of MB) do not
              done; head -30 $D/stats.txt ;;
     pmc)     local n=$1; local ctr=$2; shift 2; local D=$O/${TAG}_prof_$n; mkdir -p $D; local x=pmc_extra_$(echo $ctr | tr ' ' '_' | cut -c1-40)
-             timeout 700 rocprofv3 --kernel-trace --pmc $ctr -d $D/$x -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-api-e2e > $D/$x.log 2>&1
+             timeout 700 rocprofv3 --kernel-trace --pmc $ctr -d $D/$x -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-api-e2e --no-secondary > $D/$x.log 2>&1
              db=$(find $D/$x -name '*_results.db' | tail -1); [ -n "$db" ] && python $R/tools/summarize_rocprof.py pmc $db fm_k_ > $D/$x.txt 2>&1
              find $D/$x -name '*_results.db' -delete; head -40 $D/$x.txt ;;
     py)      timeout 900 python "$@" 2>&1 | tee -a $O/${TAG}_py.log | tail -40 ;;
