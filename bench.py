@@ -89,7 +89,9 @@ def executed_macs(cfg):
     p16 = lambda k: (k + 15) // 16 * 16
     def gvp(first, vout):            # one GVP on one row (fm_gvp_core): [Wh|Wcp] (hoisted for the first edge GVP), Wu, Ws, gates
         vop = max(16, vout)
-        return (0 if first else 3 * V * (V + 16)) + 3 * (V + 8) * vop + ((R + F if first else S) + V + 8) * S + S * vop
+        # scalar GEMM: K = [rbf | ef | sh (padded to V + 8)] for the first GVP; [s | sh] = S + V + 4 for the others (the second MFMA pass of their last
+        # k-superstep -- four zero k-slots -- is skipped)
+        return (0 if first else 3 * V * (V + 16)) + 3 * (V + 8) * vop + ((R + F + V + 8) if first else (S + V + 4)) * S + S * vop
     msg = gvp(True, V) + 2 * gvp(False, V)
     sched = cfg.update_schedule()
     n_upd = sum(1 for u in sched if u >= 0)
@@ -112,7 +114,7 @@ def executed_macs(cfg):
     sc_n = (p8(S + cfg.n_atom_types + cfg.n_charges + R) * S + S * S) if cfg.self_conditioning else 0
     head_n = S * S + S * p16(cfg.n_atom_types + cfg.n_charges)
     per_node = cfg.n_convs * (node_upd + proj) + n_upd * (pos + S * S) + sc_n + head_n
-    return {'edge_message_per_edge': (cfg.n_convs * msg - n_pq * slab) / cfg.n_convs, 'edge_message_full_per_edge': msg, 'pair_slab_convs': n_pq,
+    return {'edge_message_per_edge': msg, 'edge_message_pq_per_edge': msg - slab, 'pair_slab_convs': n_pq,
             'pair_slab_per_pair': n_pq * slab, 'edge_update_per_edge': eupd, 'per_edge': per_edge, 'per_node': per_node}
 
 
@@ -275,7 +277,7 @@ def cpu_baseline(cfg, sd, all_sizes, cpu_mols, steps, T, evals, ref_batch=128, r
 WORKLOADS = {'c3': dict(preset='flowmol3', mols=1024, n=47, T=250, traj=False, label='BASELINE.json configs[2]; configs[3] at 8 GPUs'),
              'c2': dict(preset='qm9', mols=256, n=18, T=100, traj=False, label='BASELINE.json configs[1]'),
              'c5': dict(preset='geom_ctmc', mols=128, n=None, T=500, traj=True, label='BASELINE.json configs[4], trajectory sink on (--xt_traj / --ep_traj)')}
-KERNEL_NAMES = ('edge_message', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head', 'node_head', 'sc',
+KERNEL_NAMES = ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head', 'node_head', 'sc',
                 'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step', 'pair_slab')
 
 
@@ -361,8 +363,9 @@ class Leg:
         return kern, ovh
 
 
-def message_roofline(cfg, E, N, us, pmc=None, lib_digest=None):
-    """Roofline object of the dominant kernel (fm_k_edge_message) for one launch of E edges taking `us` microseconds."""
+def message_roofline(cfg, E, N, us, pmc=None, lib_digest=None, pq=None):
+    """Roofline object of the dominant kernel -- the full instance of fm_k_edge_message -- for one launch of E edges taking `us` microseconds.
+    pq = (launches per step, avg us) of its pair-slab (PQ) instance, reported beside it."""
     ex = executed_macs(cfg)
     flops = conv_message_flops_per_edge(cfg.n_vec_channels) * E
     ex_flops = 2 * ex['edge_message_per_edge'] * E
@@ -370,27 +373,37 @@ def message_roofline(cfg, E, N, us, pmc=None, lib_digest=None):
     stale = bool(pmc) and pmc.get('library_digest') != lib_digest
     traffic = pmc['hbm_bytes_per_launch'] if (pmc and not stale) else None
     busy = pmc.get('mfma_busy_frac') if (pmc and not stale) else None
-    return {'bound': 'mfma', 'kernel': 'fm_k_edge_message', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
-            'traffic_source': (f"committed profile {pmc['source']} (library digest {pmc.get('library_digest')} = this run's): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
-                               f"rocprofv3 PMC with the gfx950 FETCH correction; not measured by this run") if traffic else
-                              (f"committed counters were measured on library digest {pmc.get('library_digest')}, this run is {lib_digest}: not quoted" if stale else None),
-            'algorithmic_bytes_per_launch': E * (512 + 8) + N * 4 * (256 + 3 * cfg.n_vec_channels) * 2,
-            'avg_launch_us': us,
-            'hbm_gb_per_s': (traffic / (us * 1e-6) / 1e9) if traffic else None,
-            'hbm_frac_of_8tb_per_s': (traffic / (us * 1e-6) / 8e12) if traffic else None,
-            'algorithmic_flop_per_launch': flops,
-            'executed_flop_per_launch': ex_flops,
-            'executed_tflops': ex_flops / (us * 1e-6) / 1e12,
-            'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
-            'mfma_busy_frac': busy,
-            'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})" if busy else None),
-            'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
-                    'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms; '
-                    f"{ex['edge_message_full_per_edge']} MAC/edge, {ex['edge_message_full_per_edge'] - (cfg.rbf_dim + cfg.n_hidden_edge_feats) * cfg.n_hidden_scalars} in the {ex['pair_slab_convs']} pair-slab launches: "
-                    f"{ex['edge_message_per_edge']:.0f} on average over the step's launches, like avg_launch_us) / launch time / peak -- the matrix-pipe occupancy by construction; "
-                    'avg_launch_us = HIP-event pair on the launch stream minus the measured pair overhead (an empty kernel timed the same way in the same pass); '
-                    'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
+    out = {'bound': 'mfma', 'kernel': 'fm_k_edge_message (full instance: the convolutions after the first molecule update)', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': ach / FP32_PEAK_TFLOPS, 'traffic': traffic,
+           'traffic_source': (f"committed profile {pmc['source']} (library digest {pmc.get('library_digest')} = this run's): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, "
+                              f"rocprofv3 PMC with the gfx950 FETCH correction; not measured by this run") if traffic else
+                             (f"committed counters were measured on library digest {pmc.get('library_digest')}, this run is {lib_digest}: not quoted" if stale else None),
+           'algorithmic_bytes_per_launch': E * (512 + 8) + N * 4 * (256 + 3 * cfg.n_vec_channels) * 2,
+           'avg_launch_us': us,
+           'hbm_gb_per_s': (traffic / (us * 1e-6) / 1e9) if traffic else None,
+           'hbm_frac_of_8tb_per_s': (traffic / (us * 1e-6) / 8e12) if traffic else None,
+           'algorithmic_flop_per_launch': flops,
+           'executed_flop_per_launch': ex_flops,
+           'executed_tflops': ex_flops / (us * 1e-6) / 1e12,
+           'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
+           'mfma_busy_frac': busy,
+           'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})" if busy else None),
+           'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
+                   'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
+                   f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
+                   'avg_launch_us = HIP-event pair on the launch stream minus the measured pair overhead (an empty kernel timed the same way in the same pass); '
+                   'peak = f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) = f32 vector peak'}
+    if pq:
+        n_pq, us_pq = pq
+        ex_pq = 2 * ex['edge_message_pq_per_edge'] * E
+        out['pair_slab_instance'] = {
+            'kernel': 'fm_k_edge_message<..., PQ = 1>', 'launches_per_step': n_pq, 'avg_launch_us': us_pq,
+            'algorithmic_frac': flops / (us_pq * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 'executed_frac': ex_pq / (us_pq * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
+            'executed_mac_per_edge': ex['edge_message_pq_per_edge'],
+            'note': 'the convolutions before the first molecule update: the [rbf | ef] slab of their first scalar GEMM (40,960 MAC/edge of the reference count) is computed once per '
+                    'unordered pair in the self-conditioning edge kernel and gathered here, so the ALGORITHMIC fraction (reference FLOPs / time / peak) exceeds 1 -- that work is not '
+                    'executed in this kernel; executed_frac is the matrix-pipe share'}
+    return out
 
 
 def load_pmc(workload, N, E, ok):
@@ -433,9 +446,10 @@ def secondary_legs(engines, dev, lib_digest, steps):
              'finite': bool(torch.isfinite(L.state['x_t']).all().item()), 'event_pair_overhead_us': ovh,
              'kernels_us': {k: round(v['avg_us'], 1) for k, v in kern.items()}, 'launches_per_step': sum(v['launches_per_step'] for v in kern.values())}
         if 'edge_message' in kern:
-            r = message_roofline(cfg, L.E, L.N, kern['edge_message']['avg_us'], load_pmc(name, L.N, L.E, True), lib_digest)
+            pq = (kern['edge_message_pq']['launches_per_step'], kern['edge_message_pq']['avg_us']) if 'edge_message_pq' in kern else None
+            r = message_roofline(cfg, L.E, L.N, kern['edge_message']['avg_us'], load_pmc(name, L.N, L.E, True), lib_digest, pq)
             o['roofline'] = {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us', 'executed_frac', 'mfma_busy_frac')}
-            o['dominant_kernel_share_of_step'] = kern['edge_message']['avg_us'] * kern['edge_message']['launches_per_step'] / (ms * 1e3)
+            o['dominant_kernel_share_of_step'] = sum(kern[k]['avg_us'] * kern[k]['launches_per_step'] for k in ('edge_message', 'edge_message_pq') if k in kern) / (ms * 1e3)
         del L
         return o
     out = {}
@@ -654,7 +668,8 @@ def main():
                             'kernel is bound by the L1/L2 weight stream, the f32 vector-path GEMMs and VALU, not by the bf16 pipe. f32_equivalent_tflops = the reference '
                             'FLOP count of the op / launch time (exceeds the f32 peak because the work is not done in f32).'}
     elif 'edge_message' in kern:
-        roofline = message_roofline(cfg, E, N, kern['edge_message']['avg_us'], pmc, lib_digest)
+        pq = (kern['edge_message_pq']['launches_per_step'], kern['edge_message_pq']['avg_us']) if 'edge_message_pq' in kern else None
+        roofline = message_roofline(cfg, E, N, kern['edge_message']['avg_us'], pmc, lib_digest, pq)
     n_list = n_atoms.tolist()
     evals_per_s = mols_per_s / world * evals / B                      # network evaluations of this rank's batch per second
     alg_tf = sum(network_flops(int(k), cfg) for k in n_list) * evals_per_s / 1e12

@@ -456,7 +456,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
             else if (it < n_pq) {
                 m.Q = c->Q[it]; m.g0.Ws = cw.Ws_sh;          // GVP0's scalar GEMM: K = KU0 (hidden-vector norms); the rest arrives through Q
-                L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0, 1>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
+                L("edge_message_pq", fm_k_edge_message<V, TE, 512, 0, 0, 1>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
             }
             else L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
         } else {

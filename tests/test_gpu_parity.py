@@ -903,21 +903,37 @@ def test_split_precision_c3_full_size_properties():
     assert out['x'].reshape(1024, 47, 3).mean(1).abs().max() < 1e-3
 
 
-@pytest.mark.parametrize('seed', list(range(16)))
+_pq_engines = {}
+
+
+@pytest.mark.parametrize('seed', list(range(24)))
 def test_forward_matches_oracle_on_random_batches(seed):
     """Seeded random batches (ragged sizes 1..90 with a degenerate / tile-edge size in every batch, random time, with / without a
-    previous endpoint, every preset, both tile sizes): every stage and output of a network evaluation against the oracle."""
+    previous endpoint, every preset, both tile sizes): every stage and output of a network evaluation against the oracle.  Seeds 16..23:
+    the self-conditioned presets with the pair-slab hoist forced on (it switches on by itself only for large batches) and a previous endpoint,
+    so its tile-relative pair addressing meets ragged molecule boundaries, 1- and 2-atom molecules and both tile sizes."""
+    from flowmol_amd.engine import Engine
     rng = np.random.default_rng(1234 + seed)
-    name = ['flowmol3', 'geom_ctmc', 'dev', 'dev_narrow', 'arch_variants', 'qm9', 'geom_arom', 'flowmol3_arom'][seed % 8]
+    pq = seed >= 16
+    name = (['flowmol3', 'qm9', 'flowmol3_arom', 'arch_variants'][seed % 4] if pq else
+            ['flowmol3', 'geom_ctmc', 'dev', 'dev_narrow', 'arch_variants', 'qm9', 'geom_arom', 'flowmol3_arom'][seed % 8])
     tile = [16, 32][int(rng.integers(0, 2))]
     nmol = int(rng.integers(2, 9))
     sizes = [int(v) for v in rng.integers(1, 91 if name in ('flowmol3', 'geom_ctmc', 'geom_arom', 'flowmol3_arom') else 40, size=nmol)]
     sizes[int(rng.integers(0, nmol))] = [1, 2, 17, 33][int(rng.integers(0, 4))]
     t = float(np.float32(rng.uniform(0.05, 0.95)))
-    cfg, sd, eng, orc = engine_for(name, tile)
-    prev = bool(rng.integers(0, 2)) and cfg.self_conditioning
+    if pq:
+        if (name, tile) not in _pq_engines:
+            cfg = presets.PRESETS[name]()
+            sd = weights.synth_state_dict(cfg, 0)
+            _pq_engines[(name, tile)] = (cfg, sd, Engine(cfg, sd, device='cuda:0', precision='f32', tuning={'tile_edge': tile, 'tile_node': tile, 'pair_slab': 1}), cpu_ref.OracleVF(cfg, sd))
+        cfg, sd, eng, orc = _pq_engines[(name, tile)]
+        prev = True
+    else:
+        cfg, sd, eng, orc = engine_for(name, tile)
+        prev = bool(rng.integers(0, 2)) and cfg.self_conditioning
     errs, out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), t, prev)
-    _report(f'forward_random[{seed}: {name},{sizes},{t:.3f},prev={prev},tile{tile}]', errs)
+    _report(f'forward_random[{seed}: {name},{sizes},{t:.3f},prev={prev},tile{tile},pair_slab={"forced" if pq else "auto"}]', errs)
     bad = {k: v for k, v in errs.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
     assert not bad, f'{name} {sizes} t={t} tile={tile}: {bad}'
 
