@@ -498,11 +498,36 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     float bias_s[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bias_s[j] = w.bs[(NTW * wave + j) * 16 + (lane & 15)];
+    // ... and the gate bias of this thread's channel in the gating loop (NTH is a multiple of VOUT: the channel is the same in every iteration):
+    // a global load inside that loop sat on the critical path of every GVP of a small batch (profiles/r04i: 0.5 us of an 8.8-us GVP)
+    static_assert(NTH % VOUT == 0, "one gate channel per thread");
+    const float bias_g = w.bg[tid % VOUT];
 
     if (!FIRST && !(FM_ABLATE & 4)) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
-        fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * TM / 16, V / 8, w.Wv1, (V + 16) / 16,
-                            [&](int row, int col, float v) { Vh[row * T::LDVH + col] = v; });
+        constexpr int RT = 3 * TM / 16, CT = (V + 16) / 16;
+        if constexpr (CT == 3) {
+            // V = 32: column tiles {0, 1} as one job, {2} ([Wcp | 0]) as another: 2 RT jobs instead of 3 RT single-tile jobs -- one round of the
+            // eight waves for a 16-row tile instead of two (each job is four k-steps behind one L2 round trip: the phase is latency, not MFMA time)
+            for (int job = wave; job < 2 * RT; job += NW) {
+                const int rt = job >> 1;
+                const float* A = Vin + (size_t)rt * 16 * T::LDVI;
+                float* D = Vh + (rt * 16 + 4 * (lane >> 4)) * T::LDVH + (lane & 15);
+                if (job & 1) {
+                    f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+                    fm_wave_gemm<1, 1>(acc, A, T::LDVI, V / 8, w.Wv1, CT, 2, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) D[r * T::LDVH + 32] = acc[0][0][r];
+                } else {
+                    f32x4 acc[1][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+                    fm_wave_gemm<1, 2>(acc, A, T::LDVI, V / 8, w.Wv1, CT, 0, lane);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { D[r * T::LDVH] = acc[0][0][r]; D[r * T::LDVH + 16] = acc[0][1][r]; }
+                }
+            }
+        } else {
+            fm_block_gemm<1, 1>(Vin, T::LDVI, RT, V / 8, w.Wv1, CT, [&](int row, int col, float v) { Vh[row * T::LDVH + col] = v; });
+        }
         __syncthreads();
     }
     FM_MARKB(0);
@@ -602,11 +627,16 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     FM_MARKB(5);
     // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128): NJ = (TM/16) x (VOP/16) single-tile jobs, K = 256.
     // With fewer jobs than half the waves, K is split in two: waves [0,NJ) take k < 128 and write G, waves [NJ,2NJ)
-    // take k >= 128 and write G2 (in Vh, dead since the scalar GEMM); the gating loop adds the halves and the bias.
+    // take k >= 128 and write a partial tile in Vh (dead since the scalar GEMM); the gating loop adds the parts and the bias.  16-row tiles: four
+    // K quarters (profiles/r04i: the gate GEMM of a small batch is a latency chain of 16 k-steps on 2-4 waves).
     // (The 64-MFMA dependent chain of an unsplit job was the critical path of this phase: profiles/r01c.)
     constexpr int NJ = (TM / 16) * (VOP / 16);
-    constexpr int KS = (NW >= 2 * NJ) ? 2 : 1;
-    float* G2 = Vh;
+    constexpr bool FIT4 = (3 + (SP ? 1 : 0)) * TM * FM_LDG <= T::VH_FLOATS;      // room for three more partial gate tiles in Vh (not for V = 16 split precision)
+    constexpr int KS = (NW >= 4 * NJ && FIT4) ? 4 : (NW >= 2 * NJ) ? 2 : 1;       // 16-row tiles: four K quarters, all eight waves busy
+    // partial q >= 1 lives in slot (q - 1) of Vh (dead since the scalar GEMM), in units of a gate tile; split-precision instances keep G itself in
+    // slot 1 of Vh, so their partials 2, 3 move up one slot
+    auto gpart = [&](int q) { return Vh + (SP && q >= 2 ? q : q - 1) * TM * FM_LDG; };
+    static_assert((KS - 1 + (SP ? 1 : 0)) * TM * FM_LDG <= T::VH_FLOATS, "gate partial sums must fit into Vh");
     if (FM_ABLATE & 2) return;
     for (int jw = wave; jw < NJ * KS; jw += NW) {
         const int job = jw % NJ, half = jw / NJ;
@@ -621,7 +651,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
             g = fm_wave_gemm_1x1<32 / KS, 8>(X + (size_t)m0 * 16 * FM_LDX + half * (256 / KS), FM_LDX,
                                              w.Wg + (size_t)half * (32 / KS) * (VOP / 16) * 64, VOP / 16, n0, lane);
         }
-        float* go = (half ? G2 : G) + (m0 * 16 + 4 * (lane >> 4)) * FM_LDG + n0 * 16 + (lane & 15);
+        float* go = (half ? gpart(half) : G) + (m0 * 16 + 4 * (lane >> 4)) * FM_LDG + n0 * 16 + (lane & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) go[r * FM_LDG] = g[r];
     }
@@ -630,8 +660,9 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // gating: one (row, channel) pair per thread and iteration, its gate applied to the three spatial components
     for (int idx = tid; idx < TM * VOUT; idx += NTH) {
         const int r = idx / VOUT, u = idx % VOUT;
-        float gv = G[r * FM_LDG + u] + w.bg[u];
-        if (KS == 2) gv += G2[r * FM_LDG + u];
+        float gv = G[r * FM_LDG + u] + bias_g;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) gv += gpart(q)[r * FM_LDG + u];
         if (SIGMOID) gv = fm_sigmoid(gv);
 #pragma unroll
         for (int c = 0; c < 3; ++c) Vin[(c * TM + r) * T::LDVI + u] *= gv;
