@@ -256,6 +256,49 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
     if (ks + 1 < K8) { if (TAILX) fm_frag_mma_x<MT, NT>(acc, a1, b1); else fm_frag_mma<MT, NT>(acc, a1, b1); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4-row GEMM on v_mfma_f32_4x4x1_16B_f32 for the node kernels of very small batches (R4 instances): a tile of FOUR nodes, so that a molecule
+// spreads over 4x as many CUs and a tile's scalar GEMM is 1.0 us of matrix time instead of 3.9 (the instruction runs at the full f32 rate:
+// 8.5 cycles per 512 FLOP, profiles/r04h).  Sixteen 4x4 blocks per instruction; with A_b = X[0..3][k] for every block and B_b = W[k][4b..4b+3]
+// one instruction adds X[0..3][k] (x) W[k][0..63] to a 4 x 64 output tile held as acc[r] = out[r][lane] (layout verified on the device:
+// tools/ubench/mfma_4x4_layout.cpp).  Weights are quad-row packed, Wq4[(kq * 4 + g) * 64 + lane] = W[4kq .. 4kq+3][64g + lane]: one 1-KB
+// buffer_load_dwordx4 per four k and wave -- a CU's L2 port delivers 150 GB/s with such loads, 76 GB/s with the 512-byte loads of
+// fm_wave_gemm, and the weight stream (303 KB per scalar GEMM whatever the tile height) is what bounds a 4-row tile.  A operands: one
+// ds_read_b128 (four k of row lane & 3; the 16 lanes of a row read the same address).  KQ quad steps, software-pipelined PD deep.
+// ---------------------------------------------------------------------------------------------
+template <int KQ>
+__device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int ldx, const void* Wq4, int g, int lane) {
+    constexpr int PD = 4;
+    const float* ap = X + (lane & 3) * ldx;
+    const auto rs = fm_buf(Wq4);
+    f32x4 a[PD];
+    float4 b[PD];
+    auto load = [&](int q, int kq) {
+        a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * kq);
+        b[q] = fm_buf_f32x4(rs, lane * 16, (kq * 4 + g) * 1024);
+    };
+#pragma unroll
+    for (int q = 0; q < PD; ++q) if (q < KQ) load(q, q);
+    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};       // two accumulators: consecutive MFMAs never depend on each other
+    for (int kq = 0; kq < KQ; kq += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            if (kq + q < KQ) {
+                const f32x4 av = a[q];
+                const float4 bv = b[q];
+                if (kq + q + PD < KQ) load(q, kq + q + PD);
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv.w, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    return acc0 + acc1;
+}
+
 // Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
 // are requested before the MFMAs of chunk c.  A 1x1 tile has only 2 MFMAs (64 cycles) per k-superstep, far less
 // than the L2 latency of its B fragment, so the one-step pipelining of fm_wave_gemm leaves it latency-bound
@@ -435,6 +478,7 @@ struct FmGvpW {
     const float* bs;     // (256)
     const float2* Wg;    // gates packed, K = 256, N = VOUT padded to 16
     const float* bg;     // (VOUT padded)
+    const void* Ws4;     // Ws quad-row packed for fm_wave_gemm4 (node-side GVPs; R4 instances)
     const void* Ws_sp;   // split-precision builds only: Ws / Wg as hi/lo bf16 planes in v_mfma_f32_16x16x32_bf16 B-fragment order
     const void* Wg_sp;
 };
@@ -472,7 +516,9 @@ struct FmGvpTile {
 // registers and written as a plain f32 [TM][FM_LDX] tile over the (then dead) planes for the aggregation.  G must then alias Vh + TM*FM_LDG.
 // PQ (FIRST only): the [rbf | ef] slab of the scalar linear arrives inside `pre` (per-pair table Q, FmMlpArgs::slabQ0): X holds only the hidden-vector
 // norms sh at columns [0, KU0) and the scalar GEMM has K = KU0.
-template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false>
+// R4 (node kernels of very small batches): only rows 0..3 of the 16-row tile are nodes; the scalar GEMM -- the one phase whose cost scales
+// with the tile height -- runs on those four rows with fm_wave_gemm4 (waves 0..3, 64 columns each); every other phase is the 16-row code.
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false, bool R4 = false>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
     typedef FmGvpTile<V, TM, HX> T;
@@ -484,6 +530,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int H = FIRST ? T::H0 : V;                 // hidden vector channels
     constexpr int KUC = FIRST ? T::KU0 : T::KU;          // K of this GVP's Wu GEMM = width of [hidden | cp | pad] in Vh and of sh in X
     static_assert(!PQ || (FIRST && !SP), "PQ is a variant of the first f32 edge GVP");
+    static_assert(!R4 || (!FIRST && !SP && TM == 16 && NTH == 512), "R4 is a variant of the non-first f32 GVP on 16-row tiles");
     constexpr int SOFF = PQ ? 0 : (FIRST ? 160 : 256);   // where sh goes in X
     constexpr int K8S = (SOFF + KUC) / 8;
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
@@ -583,7 +630,22 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     }
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     float keep[(SP && LAST) ? MT : 1][(SP && LAST) ? NTW : 1][4];     // split precision, last GVP: the f32 scalar output for the aggregation
-    {
+    if constexpr (R4) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        FM_MARKB(2);
+        if (wave < 4) {
+            const float b4 = w.bs[64 * wave + lane];
+            acc = fm_wave_gemm4<(SOFF + KUC) / 4>(f32x4{b4, b4, b4, b4}, X, FM_LDX, w.Ws4, wave, lane);
+        }
+        FM_MARKB(3);
+        __syncthreads();                      // every wave has finished reading X (and Vh)
+        FM_MARKB(4);
+        if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[r * FM_LDX + 64 * wave + lane] = fm_silu(acc[r]);
+        }
+        __syncthreads();
+    } else {
         // The accumulators start at bias (+ `pre` for the FIRST GVP of an edge tile: the hoisted W_s*s[src] term, requested
         // long before so its latency is hidden) instead of zero: no separate add in the epilogue (VALU instructions cost
         // matrix-pipe issue slots).

@@ -36,6 +36,7 @@ struct ConvW {
     const float2* Ws_slab = nullptr;   // pair-slab convolutions: [rbf | ef] rows of GVP0's scalar linear (K = 160), multiplied per pair in the SC_EDGE kernel
     const float2* Ws_sh = nullptr;     //                         and its remaining rows, the hidden-vector norms (K = KU0)
     const void* Wps_sp = nullptr;      // split precision
+    const void* Wps4 = nullptr;        // quad-row packed (4-node tiles)
     FmGvpW dproj{}; const float2* Wsd = nullptr; const float2* Wpvd = nullptr;     // use_dst_feats: projection GVP + hoisted destination terms
     FmGvpW msg[3]; FmGvpW upd[3];
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -45,6 +46,7 @@ struct UpdW {
     const float2* Wasd; const float2* W1; const float* b1; const float2* W2; const float* b2;
     const float *ln_g, *ln_b;
     const void *W1_sp = nullptr, *W2_sp = nullptr, *Wasd_sp = nullptr;      // split-precision builds
+    const void* Wasd4 = nullptr;       // quad-row packed (4-node tiles)
 };
 
 }  // namespace
@@ -64,6 +66,7 @@ struct fm_ctx {
     int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
     int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (self-conditioned models; fm_config.pair_slab = -1: 0)
+    bool node_r4 = false;     // this batch runs the node kernel on 4-node tiles (R4 instance): chosen per bound batch, fm_config.tile_node = 4 forces it
     int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
@@ -169,6 +172,18 @@ std::vector<float> pack(int K, int N, const std::function<float(int, int)>& w) {
     return out;
 }
 
+// quad-row packing for fm_wave_gemm4 (4-row tiles on v_mfma_f32_4x4x1_16B_f32): W_logical[k][n] (K x 256, K%4==0); entry (kq, g, lane) = the four
+// weights W[4kq .. 4kq+3][64g + lane] -- one 1-KB buffer_load_dwordx4 per quad step and wave
+std::vector<float> pack4(int K, const std::function<float(int, int)>& w) {
+    const int KQ = K / 4;
+    std::vector<float> out((size_t)KQ * 4 * 64 * 4);
+    for (int kq = 0; kq < KQ; ++kq)
+        for (int g = 0; g < 4; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) out[(((size_t)kq * 4 + g) * 64 + lane) * 4 + i] = w(4 * kq + i, 64 * g + lane);
+    return out;
+}
+
 // split-precision packing (fm_device.h "bf16x3"): W_logical[k][n] (K x N, K%32==0, N%16==0) as hi/lo bf16 planes in
 // v_mfma_f32_16x16x32_bf16 B-fragment order: entry (kb, nt, plane, lane) = 8 bf16 = W[32kb + 8(lane>>4) + q][16nt + (lane&15)], q = 0..7
 inline uint16_t bf16_rne(float f) {
@@ -222,6 +237,13 @@ void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int 
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
     }));
 }
+void pack_linear4(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, const std::function<int(int)>& kmap) {
+    B.putv(slot, pack4(Kp, [&](int k, int n) -> float {
+        if (n >= out) return 0.f;
+        const int kk = kmap(k);
+        return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
+    }));
+}
 void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
     std::vector<float> t(np, 0.f);
     for (int i = 0; i < n; ++i) t[i] = v[i];
@@ -229,7 +251,7 @@ void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
 }
 
 // one non-first GVP (vin = V, hidden = V, S real scalar channels in a 256-wide tile): reference gvp.py:30-88 parameter shapes
-bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g, bool sp = false) {
+bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g, bool sp = false, bool rows4 = false) {
     const int vop = vout < 16 ? 16 : vout;
     const float* Wh = bl.get(key + ".Wh", V, V);
     const float* Wcp = bl.get(key + ".Wcp", V, 8);
@@ -251,6 +273,7 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vo
                                const int o = k - 256; if (o < V) return S + o;
                                return ((o - V) & 1) ? -1 : S + V + (o - V) / 2; };
     pack_linear(B, g.Ws, Ws, S, V + 4 + S, 256 + V + 8, 256, kmap_s);
+    if (rows4) pack_linear4(B, g.Ws4, Ws, S, V + 4 + S, 256 + V + 8, kmap_s);      // node-side GVPs: second copy for the 4-node tiles (fm_wave_gemm4)
     pad_vec(B, g.bs, bs, S, 256);
     pack_linear(B, g.Wg, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
     pad_vec(B, g.bg, bg, vout, vop);
@@ -474,10 +497,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         nu.agg_v = tagg ? c->tap_v : nullptr;
         nu.tile_e = TE;
         if (fuse) {
-            if (it + 1 < n_pass) { const ConvW& nx = c->conv[(i + 1) % cf.n_convs]; nu.Wps = nx.Wps; nu.Ps = c->Ps; nu.Wpv = nx.Wpv; nu.PV = c->PV; }
+            if (it + 1 < n_pass) { const ConvW& nx = c->conv[(i + 1) % cf.n_convs]; nu.Wps = nx.Wps; nu.Wps4 = nx.Wps4; nu.Ps = c->Ps; nu.Wpv = nx.Wpv; nu.PV = c->PV; }
             if (u >= 0) {
                 const UpdW& uw = c->upd[u];
-                nu.Wasd = uw.Wasd; nu.Asd = c->Asd; nu.p0 = uw.pos[0]; nu.p1 = uw.pos[1]; nu.p2 = uw.pos[2]; nu.x = c->xw;
+                nu.Wasd = uw.Wasd; nu.Wasd4 = uw.Wasd4; nu.Asd = c->Asd; nu.p0 = uw.pos[0]; nu.p1 = uw.pos[1]; nu.p2 = uw.pos[2]; nu.x = c->xw;
             }
         }
         nu.s_real = c->S;
@@ -487,6 +510,12 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
                 if (it + 1 < n_pass) nu.Wps_sp = c->conv[(i + 1) % cf.n_convs].Wps_sp;
                 if (u >= 0) nu.Wasd_sp = c->upd[u].Wasd_sp;
                 L("node_update", fm_k_node_update<V, TN, true, 1>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
+                launched = true;
+            }
+        }
+        if constexpr (HX == 0 && TN == 16) {
+            if (!launched && c->node_r4 && fuse && c->S == 256 && cf.precision == FM_PREC_F32) {      // a few molecules: four nodes per workgroup
+                L("node_update", fm_k_node_update<V, 16, false, 0, 1>, dim3((N + 3) / 4), blk, lds_gvp(V, 16, false), nu);
                 launched = true;
             }
         }
@@ -835,7 +864,9 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             pad_vec(B, dp.bg, pbg, HX, 16);
         }
         for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g], sp)) return bail(bl.err);
-        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g], sp)) return bail(bl.err);
+        const bool rows4 = S == 256 && HX == 0 && !sp;       // 4-node tiles exist for full-width f32 models on the fused node sequence
+        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g], sp, rows4)) return bail(bl.err);
+        if (rows4) pack_linear4(B, cw.Wps4, Ws, S, kin0, 256, [&](int k) { return k < S ? k : -1; });
         if (sp) pack_linear_sp(B, cw.Wps_sp, Ws, S, kin0, 256, 256, [&](int k) { return k < S ? k : -1; });
         const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", S); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", S);
         const float* l2g = bl.get(p + "update_layer_norm.feat_norm.weight", S); const float* l2b = bl.get(p + "update_layer_norm.feat_norm.bias", S);
@@ -852,7 +883,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         UpdW& uw = c->upd[u];
         const std::string p = "node_position_updaters." + std::to_string(u) + ".gvps.";
         const bool spu = cfg->precision == FM_PREC_BF16X3;
-        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu))
+        const bool rows4u = S == 256 && HX == 0 && !spu;
+        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu, rows4u) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu, rows4u) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu, rows4u))
             return bail(bl.err);
         const std::string q = "edge_updaters." + std::to_string(u) + ".";
         const bool with_d = !cfg->edge_update_no_distance;
@@ -863,6 +895,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!W1 || !b1 || !W2 || !b2 || !g || !be) return bail(bl.err);
         // input order [s_src(S) | s_dst(S) | ef(F) | d(32)] (vector_field.py:870-877); tile: Asd = [W1_src s | W1_dst s] (2 x 128 columns)
         B.put(uw.Wasd, pack(256, 256, [&](int k, int n) -> float {
+            const int o = n < 128 ? n : n - 128;
+            if (k >= S || o >= F) return 0.f;
+            return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
+        if (rows4u) B.putv(uw.Wasd4, pack4(256, [&](int k, int n) -> float {
             const int o = n < 128 ? n : n - 128;
             if (k >= S || o >= F) return 0.f;
             return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
@@ -920,9 +956,9 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             c->n_pq = i + 1;
         }
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
-    if (!tile_ok(c->tm_edge_forced) || !tile_ok(c->tm_node_forced)) {
+    if (!tile_ok(c->tm_edge_forced) || !(tile_ok(c->tm_node_forced) || c->tm_node_forced == 4)) {
         (void)hipFree(c->arena); delete c;
-        return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.tile_edge / tile_node must be 0 (automatic), 16, 32 or 64");
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.tile_edge must be 0 (automatic), 16, 32 or 64; tile_node additionally 4");
     }
     {
         int dev = 0; hipDeviceProp_t prop{};
@@ -941,6 +977,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
     set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
+    set_lds(fm_k_node_update<32, 16, false, 0, 1>, lds_gvp(32, 16, false)); set_lds(fm_k_node_update<16, 16, false, 0, 1>, lds_gvp(16, 16, false));
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
     set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
@@ -970,7 +1007,7 @@ int fm_destroy(fm_ctx* c) {
 
 // ---------------------------------------------------------------------------------------- workspace
 struct WsLayout {
-    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node;
+    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node; bool node_r4;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_Psd, off_PVd, off_stab, off_bx, off_ba,
         off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, off_Q0, off_Q1, total;
@@ -993,8 +1030,16 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
     w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
     if ((c->HX || !c->cfg.has_mask) && (w.tm_edge > 32)) w.tm_edge = 32;
-    w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 31) / 32 <= c->n_cus ? 16 : 32);
+    // node tiles: 32 rows once the chip is full, 16 while 32-row tiles would leave CUs idle, and FOUR nodes in a 16-row frame (R4 instance of
+    // fm_k_node_update) while even the 4-node tiles fit one per CU: the node kernel is a serial chain per tile, so for a few molecules the
+    // step latency is what one CU needs for it
+    w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 3) / 4 <= c->n_cus ? 4 : (N + 31) / 32 <= c->n_cus ? 16 : 32);
     if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
+    w.node_r4 = false;
+    if (w.tm_node == 4) {      // the 4-node instance lives in the 16-row frame; models it does not exist for (narrow, destination features, split precision, unfused) take 16-row tiles
+        w.node_r4 = c->S == 256 && c->HX == 0 && c->cfg.precision == FM_PREC_F32 && c->fuse_node;
+        w.tm_node = 16;
+    }
     w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
@@ -1097,7 +1142,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     const int work = w.E > w.N ? w.E : w.N;
     L("batch_setup", fm_k_batch_setup, dim3((work + 255) / 256), dim3(256), 0, b);
     if (L.rc) return L.rc;
-    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node;
+    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node; c->node_r4 = w.node_r4;
     return FM_OK;
 }
 

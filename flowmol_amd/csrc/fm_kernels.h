@@ -786,6 +786,7 @@ struct FmNodeUpdArgs {
     const float2* Wasd; float* Asd;
     FmGvpW p0, p1, p2; float* x;     // x != null: x += GVP3(GVP2(GVP1(s, v))).v[:, 0]
     const void* Wps_sp; const void* Wasd_sp;      // split-precision instance: Wps / Wasd as bf16 hi/lo planes
+    const void* Wps4; const void* Wasd4;          // R4 instance: Wps / Wasd quad-row packed (fm_wave_gemm4)
     int s_real;                      // NARROW instances: real scalar width (< 256); the LayerNorm statistics run over it
 };
 
@@ -795,7 +796,7 @@ struct FmNodeUpdArgs {
 // overlay the f32 tile, so every thread first finishes reading its row -- values in registers, one barrier -- then writes).
 template <int V, int TM, int SP = 0>
 __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, const float* g, const float* b_,
-                                                      int row0, int nrows, float* out_s, float* out_v, int s_width = 256) {
+                                                      int row0, int nrows, float* out_s, float* out_v, int s_width = 256, int rows_valid = TM) {
     typedef FmGvpTile<V, TM> T;
     constexpr int LPR = FM_THREADS / TM;          // lanes per row
     const int tid = threadIdx.x, r = tid / LPR, sub = tid % LPR;
@@ -811,7 +812,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
     const float vn = __builtin_amdgcn_sqrtf(q * (1.0f / (float)V) + 1e-5f) + 1e-5f;
     const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
-    const bool valid = row0 + r < nrows;
+    const bool valid = r < rows_valid && row0 + r < nrows;       // rows_valid < TM: the R4 instances' tiles hold four nodes in a 16-row frame
     if constexpr (SP) {
         float ys[256 / LPR];
 #pragma unroll
@@ -845,17 +846,23 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
 
 // SP = 1: opt-in split precision (fm_device.h "bf16x3"): the scalar / gate GEMMs of its six GVPs and the two 256 x 256 projections on the
 // bf16 matrix cores; LayerNorm, residuals, the vector path and the hidden-vector projection stay f32.
-template <int V, int TM, bool NARROW, int SP>
+// R4 = 1 (batches of a few molecules): a workgroup owns FOUR nodes in a 16-row frame -- a 47-atom molecule spreads over 12 CUs instead of 3.
+// The scalar GEMMs of its six GVPs and the two 256 x 256 projections, whose cost scales with the tile height, run on the four real rows with
+// v_mfma_f32_4x4x1_16B_f32 (fm_wave_gemm4); the vector-side GEMMs, LayerNorms and gates are the 16-row code over the frame (rows 4..15 carry
+// zeros / finite junk that is never stored).
+template <int V, int TM, bool NARROW, int SP, int R4 = 0>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) {
+    static_assert(!R4 || (TM == 16 && !NARROW && !SP), "the 4-node instance exists for f32 full-width models on the 16-row frame");
     typedef FmGvpTile<V, TM> T;
+    constexpr int RV = R4 ? 4 : TM;                                // rows of the frame that are nodes
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
     float* Vin = X + (SP ? TM * FM_LDP : T::X_FLOATS);
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = SP ? Vh + TM * FM_LDG : Vh + T::VH_FLOATS;
-    const int tid = threadIdx.x, row0 = blockIdx.x * TM;
+    const int tid = threadIdx.x, row0 = blockIdx.x * RV;
     const int N = a.b.N, P = a.b.P;
-    const int rows = N - row0 < TM ? N - row0 : TM;                // rows of this tile that exist
+    const int rows = N - row0 < RV ? N - row0 : RV;                // rows of this tile that exist
     // Number of partial-sum pieces of each row, once per row (G is free until the first gate GEMM).  Everything after
     // it is 16-byte buffer loads through tile-relative descriptors, all of a thread's requests issued back to back:
     // rows beyond N and pieces beyond a row's count read 0 through the range check (a per-element version of this
@@ -866,7 +873,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         const int n = row0 + tid;
         int np = 0;
         float iz = a.inv_z;
-        if (n < N) {
+        if (n < N && tid < RV) {
             const int m = a.b.node_mol[n];
             const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
             if (deg > 0) {
@@ -926,13 +933,13 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     }
     __syncthreads();
     const int s_width = NARROW ? a.s_real : 256;
-    fm_gvp_layernorm_tile<V, TM, SP>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v, s_width);     // s1, v1 -> HBM (needed for the residual)
+    fm_gvp_layernorm_tile<V, TM, SP>(X, Vin, a.ln1_g, a.ln1_b, row0, N, a.s, a.v, s_width, RV);     // s1, v1 -> HBM (needed for the residual)
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, true>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));      // SP: leaves the f32 tile for the residual
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, true, false, R4 != 0>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));      // SP: leaves the f32 tile for the residual
     }
     {   // residual: + (s1, v1), re-read from HBM with 16-byte loads (rows beyond N read 0)
         constexpr int NQ = TM * 64 / FM_THREADS;
@@ -958,7 +965,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         }
     }
     __syncthreads();
-    fm_gvp_layernorm_tile<V, TM, SP>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v, s_width);       // ends with a barrier: X = s (planes if SP), Vin = v
+    fm_gvp_layernorm_tile<V, TM, SP>(X, Vin, a.ln2_g, a.ln2_b, row0, N, a.s, a.v, s_width, RV);       // ends with a barrier: X = s (planes if SP), Vin = v
     // ---- fused tail: projections first (they only read the tile), then the position GVPs (which overwrite it)
     constexpr int MT = TM / 16;
     if constexpr (SP) {
@@ -984,6 +991,17 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         };
         if (a.Ps) project(a.Wps_sp, a.Ps);
         if (a.Asd) project(a.Wasd_sp, a.Asd);
+    } else if constexpr (R4) {
+        // the two 256 x 256 projections side by side: waves 0..3 the next convolution's Ps, waves 4..7 EdgeUpdate's Asd, 64 columns per wave
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const void* wq = wave < 4 ? a.Wps4 : a.Wasd4;
+        float* out = wave < 4 ? a.Ps : a.Asd;
+        if (out) {
+            const f32x4 acc = fm_wave_gemm4<64>(f32x4{0.f, 0.f, 0.f, 0.f}, X, FM_LDX, wq, wave & 3, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < rows) out[(size_t)(row0 + r) * 256 + 64 * (wave & 3) + lane] = acc[r];
+        }
     } else {
     if (a.Ps)
         fm_block_gemm<MT, 2>(X, FM_LDX, MT, 32, a.Wps, 16, [&](int row, int col, float val) {
@@ -997,18 +1015,18 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     if (a.PV)
         fm_block_gemm<1, 1>(Vin, T::LDVI, 3 * MT, V / 8, a.Wpv, (V + 16) / 16, [&](int row, int col, float val) {
             const int c = row / TM, r = row % TM;
-            if (row0 + r < N) a.PV[((size_t)(row0 + r) * 3 + c) * (V + 16) + col] = val;
+            if (r < rows) a.PV[((size_t)(row0 + r) * 3 + c) * (V + 16) + col] = val;
         });
     if (a.x) {
         __syncthreads();                     // every wave has read the tile for the projections
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, 1, false, false, TM, FM_THREADS, 0, SP, false>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, 1, false, false, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
         if (tid < TM * 3) {
             const int r = tid / 3, c = tid % 3, n = row0 + r;
-            if (n < N) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];
+            if (r < rows) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];
         }
     }
 }

@@ -168,6 +168,17 @@ void mfma16(float a, float b, float* c4) {
         c4[r] = acc;
     }
 }
+// v_mfma_f32_4x4x1_16B_f32 (layout verified on gfx950 by tools/ubench/mfma_4x4_layout.cpp): sixteen 4x4 blocks, block = lane >> 2; lane (b, i) supplies
+// A_b[i] and B_b[i]; register r of lane (b, j) accumulates A_b[r] * B_b[j]
+void mfma4(float a, float b, float* c4) {
+    Worker* w = tw; Lane* l = w->cur; WaveScratch& ws = w->waves[l->wave];
+    int p = ws.gen & 1;
+    ws.a[p][l->lane] = a;
+    ws.b[p][l->lane] = b;
+    wave_rendezvous(ws);
+    const int blk = l->lane >> 2;
+    for (int r = 0; r < 4; ++r) c4[r] = fmaf(ws.a[p][4 * blk + r], ws.b[p][l->lane], c4[r]);
+}
 // v_mfma_f32_16x16x32_bf16 (layout verified on gfx950 by tools/ubench/mfma_bf16_layout.cpp): lane l holds A[i=l&15][k=8(l>>4)..+7],
 // B[k=8(l>>4)..+7][j=l&15]; D as the 16x16x4 form.  Products of bf16 values are exact in f32; the accumulation order over k is the
 // hardware's business -- emulated as one f32 sum in ascending k (the kernels' tolerance covers either).

@@ -57,6 +57,7 @@ void syncthreads();
 float shfl_f(float v, int src_lane, int width);
 int shfl_i(int v, int src_lane, int width);
 void mfma16(float a, float b, float* c4);          // 16x16x4 f32
+void mfma4(float a, float b, float* c4);           // 4x4x1, 16 blocks
 void mfma32(float a, float b, float* c16);         // 32x32x2 f32
 void mfma16_bf16(const unsigned short* a8, const unsigned short* b8, float* c4);   // 16x16x32 bf16
 unsigned long long ballot(int pred);
@@ -105,6 +106,12 @@ static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, i
     for (int i = 0; i < 16; ++i) r[i] = t[i];
     return r;
 }
+static inline emu_f32x4 emu_mfma_4x4x1(float a, float b, emu_f32x4 c, int, int, int) {
+    float t[4] = {c[0], c[1], c[2], c[3]};
+    emu::mfma4(a, b, t);
+    return emu_f32x4{t[0], t[1], t[2], t[3]};
+}
+#define __builtin_amdgcn_mfma_f32_4x4x1f32 emu_mfma_4x4x1
 typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short emu_u16x8 __attribute__((ext_vector_type(8)));
 static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
