@@ -266,9 +266,11 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
 // fm_wave_gemm, and the weight stream (303 KB per scalar GEMM whatever the tile height) is what bounds a 4-row tile.  A operands: one
 // ds_read_b128 (four k of row lane & 3; the 16 lanes of a row read the same address).  KQ quad steps, software-pipelined PD deep.
 // ---------------------------------------------------------------------------------------------
-template <int KQ>
-__device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int ldx, const void* Wq4, int g, int lane) {
-    constexpr int PD = 4;
+// Quad steps [kq0, kq1) of the product; PD loads of 1 KB in flight per wave: the L2 answers in ~0.4 us under load, so the stream rate of a CU is
+// (bytes in flight) / latency -- eight waves x eight loads = 64 KB reach the port's 150 GB/s, four waves x four loads would reach a quarter of it
+// (first version of this path, profiles/r04o).
+__device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int ldx, const void* Wq4, int g, int lane, int kq0, int kq1) {
+    constexpr int PD = 8;
     const float* ap = X + (lane & 3) * ldx;
     const auto rs = fm_buf(Wq4);
     f32x4 a[PD];
@@ -278,15 +280,15 @@ __device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int l
         b[q] = fm_buf_f32x4(rs, lane * 16, (kq * 4 + g) * 1024);
     };
 #pragma unroll
-    for (int q = 0; q < PD; ++q) if (q < KQ) load(q, q);
+    for (int q = 0; q < PD; ++q) if (kq0 + q < kq1) load(q, kq0 + q);
     f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};       // two accumulators: consecutive MFMAs never depend on each other
-    for (int kq = 0; kq < KQ; kq += PD) {
+    for (int kq = kq0; kq < kq1; kq += PD) {
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
-            if (kq + q < KQ) {
+            if (kq + q < kq1) {
                 const f32x4 av = a[q];
                 const float4 bv = b[q];
-                if (kq + q + PD < KQ) load(q, kq + q + PD);
+                if (kq + q + PD < kq1) load(q, kq + q + PD);
                 __builtin_amdgcn_sched_barrier(0);
                 acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
@@ -631,18 +633,24 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     float keep[(SP && LAST) ? MT : 1][(SP && LAST) ? NTW : 1][4];     // split precision, last GVP: the f32 scalar output for the aggregation
     if constexpr (R4) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // waves 0..3: k quads [0, KQ/2) of their 64 columns (starting from the bias), waves 4..7: the other half; the halves meet in Vh (dead here)
+        constexpr int KQ = (SOFF + KUC) / 4, KQH = (KQ + 1) / 2;
+        static_assert(4 * 256 <= T::VH_FLOATS, "the exchange tile of the two K halves must fit into Vh");
+        const int g = wave & 3, half = wave >> 2;
         FM_MARKB(2);
-        if (wave < 4) {
-            const float b4 = w.bs[64 * wave + lane];
-            acc = fm_wave_gemm4<(SOFF + KUC) / 4>(f32x4{b4, b4, b4, b4}, X, FM_LDX, w.Ws4, wave, lane);
-        }
+        const float b4 = half ? 0.f : w.bs[64 * g + lane];
+        const f32x4 acc = fm_wave_gemm4(f32x4{b4, b4, b4, b4}, X, FM_LDX, w.Ws4, g, lane, half ? KQH : 0, half ? KQ : KQH);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
-        if (wave < 4) {
+        if (half) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[r * FM_LDX + 64 * wave + lane] = fm_silu(acc[r]);
+            for (int r = 0; r < 4; ++r) Vh[r * 256 + 64 * g + lane] = acc[r];
+        }
+        __syncthreads();
+        if (!half) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[r * FM_LDX + 64 * g + lane] = fm_silu(acc[r] + Vh[r * 256 + 64 * g + lane]);
         }
         __syncthreads();
     } else {
