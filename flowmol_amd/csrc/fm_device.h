@@ -266,37 +266,39 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
 // fm_wave_gemm, and the weight stream (303 KB per scalar GEMM whatever the tile height) is what bounds a 4-row tile.  A operands: one
 // ds_read_b128 (four k of row lane & 3; the 16 lanes of a row read the same address).  KQ quad steps, software-pipelined PD deep.
 // ---------------------------------------------------------------------------------------------
-// Quad steps [kq0, kq1) of the product; PD loads of 1 KB in flight per wave: the L2 answers in ~0.4 us under load, so the stream rate of a CU is
+// Quad steps [KQ0, KQ1) of the product; PD loads of 1 KB in flight per wave: the L2 answers in ~0.4 us under load, so the stream rate of a CU is
 // (bytes in flight) / latency -- eight waves x eight loads = 64 KB reach the port's 150 GB/s, four waves x four loads would reach a quarter of it
 // (first version of this path, profiles/r04o).
-__device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int ldx, const void* Wq4, int g, int lane, int kq0, int kq1) {
-    constexpr int PD = 8;
-    const float* ap = X + (lane & 3) * ldx;
+template <int KQ0, int KQ1>
+__device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int ldx, const void* Wq4, int g, int lane) {
+    constexpr int PD = 8, N = KQ1 - KQ0;
+    const float* ap = X + (lane & 3) * ldx + 4 * KQ0;
     const auto rs = fm_buf(Wq4);
+    const int s0 = (KQ0 * 4 + g) * 1024;             // wave-uniform byte offset of the first fragment; the others are compile-time multiples of 4 KB away
     f32x4 a[PD];
     float4 b[PD];
-    auto load = [&](int q, int kq) {
-        a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * kq);
-        b[q] = fm_buf_f32x4(rs, lane * 16, (kq * 4 + g) * 1024);
-    };
 #pragma unroll
-    for (int q = 0; q < PD; ++q) if (kq0 + q < kq1) load(q, kq0 + q);
-    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};       // two accumulators: consecutive MFMAs never depend on each other
-    for (int kq = kq0; kq < kq1; kq += PD) {
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            if (kq + q < kq1) {
-                const f32x4 av = a[q];
-                const float4 bv = b[q];
-                if (kq + q + PD < kq1) load(q, kq + q + PD);
-                __builtin_amdgcn_sched_barrier(0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv.w, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    for (int q = 0; q < PD; ++q)
+        if (q < N) {
+            a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * q);
+            b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * 4096);
         }
+    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};       // two accumulators: consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int k = 0; k < N; ++k) {                  // fully unrolled: register set k % PD, every offset an immediate, exact wait counts
+        const int q = k % PD;
+        const f32x4 av = a[q];
+        const float4 bv = b[q];
+        if (k + PD < N) {
+            a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * (k + PD));
+            b[q] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv.w, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc0 + acc1;
 }
@@ -639,7 +641,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         const int g = wave & 3, half = wave >> 2;
         FM_MARKB(2);
         const float b4 = half ? 0.f : w.bs[64 * g + lane];
-        const f32x4 acc = fm_wave_gemm4(f32x4{b4, b4, b4, b4}, X, FM_LDX, w.Ws4, g, lane, half ? KQH : 0, half ? KQ : KQH);
+        const f32x4 acc = half ? fm_wave_gemm4<KQH, KQ>(f32x4{0.f, 0.f, 0.f, 0.f}, X, FM_LDX, w.Ws4, g, lane)
+                               : fm_wave_gemm4<0, KQH>(f32x4{b4, b4, b4, b4}, X, FM_LDX, w.Ws4, g, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);

@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         const void* wq = wave < 4 ? a.Wps4 : a.Wasd4;
         float* out = wave < 4 ? a.Ps : a.Asd;
         if (out) {
-            const f32x4 acc = fm_wave_gemm4(f32x4{0.f, 0.f, 0.f, 0.f}, X, FM_LDX, wq, wave & 3, lane, 0, 64);
+            const f32x4 acc = fm_wave_gemm4<0, 64>(f32x4{0.f, 0.f, 0.f, 0.f}, X, FM_LDX, wq, wave & 3, lane);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (r < rows) out[(size_t)(row0 + r) * 256 + 64 * (wave & 3) + lane] = acc[r];
