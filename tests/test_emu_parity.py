@@ -441,3 +441,23 @@ def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
         torch.testing.assert_close(outs[1][k], outs[-1][k], rtol=1e-4, atol=2e-6)
     same = all(torch.equal(outs[1][k], outs[-1][k]) for k in 'xace')
     assert same != bool(prev and cfg.self_conditioning)
+
+
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [5, 9, 2, 1], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False), ('dev_narrow', [5, 3], 0.5, True)])
+def test_four_node_tiles_on_emulation(emu_lib, name, sizes, t, prev):
+    """fm_config.tile_node = 4 (the automatic choice for a few molecules): the node kernel on FOUR nodes per workgroup, its scalar GEMMs and the
+    two 256 x 256 projections on v_mfma_f32_4x4x1_16B_f32 with quad-row packed weights (R4 instance of fm_k_node_update; the emulation executes
+    the instruction with the operand layout verified on the device, tools/ubench/mfma_4x4_layout.cpp).  Every stage against the oracle, and the
+    switch really selects other arithmetic for the models the instance exists for (full-width f32; dev_narrow falls back to 16-row tiles)."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    outs = {}
+    for tile in (4, 16):
+        eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning={'tile_node': tile, 'tile_edge': 16})
+        errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), t, prev)
+        bad = {k: v for k, v in errs.items() if not v < 2e-5}
+        assert not bad, (tile, bad)
+        outs[tile] = {k: v.clone() for k, v in out.items()}
+    same = all(torch.equal(outs[4][k], outs[16][k]) for k in 'xace')
+    assert same == (cfg.n_hidden_scalars != 256), name
