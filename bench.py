@@ -96,10 +96,11 @@ def executed_macs(cfg):
     msg = gvp(True, V) + 2 * gvp(False, V)
     sched = cfg.update_schedule()
     n_upd = sum(1 for u in sched if u >= 0)
-    # pair-slab hoist (fm_config.pair_slab, ABI 6): for the leading convolutions that run before any molecule update (at most two) the [rbf | ef]
-    # slab of GVP0's scalar linear is computed once per unordered pair (fm_k_pair_slab) and leaves the per-edge kernel
+    # pair-slab hoist (fm_config.pair_slab, ABI 6): in self-conditioned models, for the leading convolutions that run before any molecule update
+    # (at most two), the [rbf | ef] slab of GVP0's scalar linear is computed once per unordered pair inside the self-conditioning edge kernel and
+    # leaves the per-edge kernel (large batches; the bench workloads that are smaller report the full instance only)
     n_pq = 0
-    if not getattr(cfg, 'use_dst_feats', False):
+    if cfg.self_conditioning and not getattr(cfg, 'use_dst_feats', False):
         for i in range(min(2, cfg.n_convs)):
             if any(u >= 0 for u in sched[:i]):
                 break
@@ -279,7 +280,7 @@ WORKLOADS = {'c3': dict(preset='flowmol3', mols=1024, n=47, T=250, traj=False, l
              'c2': dict(preset='qm9', mols=256, n=18, T=100, traj=False, label='BASELINE.json configs[1]'),
              'c5': dict(preset='geom_ctmc', mols=128, n=None, T=500, traj=True, label='BASELINE.json configs[4], trajectory sink on (--xt_traj / --ep_traj)')}
 KERNEL_NAMES = ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head', 'node_head', 'sc',
-                'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step', 'pair_slab')
+                'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step')
 
 
 def job_sizes(world, B, n, size_dist):

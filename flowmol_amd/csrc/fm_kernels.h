@@ -1,6 +1,8 @@
 // __global__ kernels of the FlowMol3 sampling hot path for gfx950.  See DESIGN.md for the map
-// kernel -> reference function and the HBM data layout.  All kernels use 512-thread workgroups
-// over 64-row tiles unless noted; weights come pre-packed (fm_device.h).
+// kernel -> reference function and the HBM data layout.  All kernels use 512-thread workgroups over
+// row tiles whose height TM is a template parameter (fm_device.h: 32 / 16 rows for the GVP kernels,
+// four nodes in a 16-row frame for the node kernel of a few molecules, 64 / 32 / 16 rows for the MLPs);
+// weights come pre-packed in MFMA fragment order.
 #pragma once
 #include <type_traits>
 

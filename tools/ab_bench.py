@@ -60,7 +60,7 @@ for _ in range(3):
 eng.synchronize()
 kern = {}
 for k in ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc', 'heads', 'sc_edge', 'sc_node', 'edge_head', 'node_head',
-          'embed_table', 'gather_rows', 'pair_slab', 'event_overhead'):
+          'embed_table', 'gather_rows', 'event_overhead'):
     ms, cnt = eng.profile_get(k)
     if cnt:
         kern[k] = round(ms * 1e3 / cnt, 1)
