@@ -257,8 +257,8 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// 4-row GEMM on v_mfma_f32_4x4x1_16B_f32 for the node kernels of very small batches (R4 instances): a tile of FOUR nodes, so that a molecule
-// spreads over 4x as many CUs and a tile's scalar GEMM is 1.0 us of matrix time instead of 3.9 (the instruction runs at the full f32 rate:
+// 4-row GEMM on v_mfma_f32_4x4x1_16B_f32 for the node kernels of small batches (RG instances): a tile of 4 RG nodes (RG groups of four rows), so
+// that the nodes spread over more CUs and a 4-node tile's scalar GEMM is 1.0 us of matrix time instead of 3.9 (the instruction runs at the full f32 rate:
 // 8.5 cycles per 512 FLOP, profiles/r04h).  Sixteen 4x4 blocks per instruction; with A_b = X[0..3][k] for every block and B_b = W[k][4b..4b+3]
 // one instruction adds X[0..3][k] (x) W[k][0..63] to a 4 x 64 output tile held as acc[r] = out[r][lane] (layout verified on the device:
 // tools/ubench/mfma_4x4_layout.cpp).  Weights are quad-row packed, Wq4[(kq * 4 + g) * 64 + lane] = W[4kq .. 4kq+3][64g + lane]: one 1-KB
@@ -269,38 +269,49 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
 // Quad steps [KQ0, KQ1) of the product; PD loads of 1 KB in flight per wave: the L2 answers in ~0.4 us under load, so the stream rate of a CU is
 // (bytes in flight) / latency -- eight waves x eight loads = 64 KB reach the port's 150 GB/s, four waves x four loads would reach a quarter of it
 // (first version of this path, profiles/r04o).
-template <int KQ0, int KQ1>
-__device__ __forceinline__ f32x4 fm_wave_gemm4(f32x4 acc0, const float* X, int ldx, const void* Wq4, int g, int lane) {
-    constexpr int PD = 8, N = KQ1 - KQ0;
+// RG row groups of four (rows 4g .. 4g+3 of the frame): every weight fragment is loaded once and multiplied with RG A operands.
+template <int KQ0, int KQ1, int RG>
+__device__ __forceinline__ void fm_wave_gemm4(f32x4 (&acc)[RG], const float* X, int ldx, const void* Wq4, int g, int lane) {
+    constexpr int PD = 8, PA = 2, N = KQ1 - KQ0;       // weight fragments (L2) eight quad steps ahead, A operands (LDS) two
     const float* ap = X + (lane & 3) * ldx + 4 * KQ0;
     const auto rs = fm_buf(Wq4);
     const int s0 = (KQ0 * 4 + g) * 1024;             // wave-uniform byte offset of the first fragment; the others are compile-time multiples of 4 KB away
-    f32x4 a[PD];
+    f32x4 a[PA][RG];
     float4 b[PD];
+    auto load_a = [&](int q, int k) {
 #pragma unroll
-    for (int q = 0; q < PD; ++q)
-        if (q < N) {
-            a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * q);
-            b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * 4096);
-        }
-    f32x4 acc1 = f32x4{0.f, 0.f, 0.f, 0.f};       // two accumulators: consecutive MFMAs never depend on each other
+        for (int rg = 0; rg < RG; ++rg) a[q][rg] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + rg * 4 * ldx + 4 * k);
+    };
 #pragma unroll
-    for (int k = 0; k < N; ++k) {                  // fully unrolled: register set k % PD, every offset an immediate, exact wait counts
-        const int q = k % PD;
-        const f32x4 av = a[q];
-        const float4 bv = b[q];
-        if (k + PD < N) {
-            a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * (k + PD));
-            b[q] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * 4096);
-        }
+    for (int q = 0; q < PD; ++q) if (q < N) b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * 4096);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) if (q < N) load_a(q, q);
+    f32x4 acc1[RG];                                // two accumulators per group: consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) acc1[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {                  // fully unrolled: every offset an immediate, exact wait counts
+        const float4 bv = b[k % PD];
+        f32x4 av[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) av[rg] = a[k % PA][rg];
+        if (k + PD < N) b[k % PD] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * 4096);
+        if (k + PA < N) load_a(k % PA, k + PA);
         __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv.w, acc1, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][0], bv.x, acc[rg], 0, 0, 0);
+            acc1[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][1], bv.y, acc1[rg], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][2], bv.z, acc[rg], 0, 0, 0);
+            acc1[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][3], bv.w, acc1[rg], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
-    return acc0 + acc1;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) acc[rg] += acc1[rg];
 }
 
 // Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
@@ -482,7 +493,7 @@ struct FmGvpW {
     const float* bs;     // (256)
     const float2* Wg;    // gates packed, K = 256, N = VOUT padded to 16
     const float* bg;     // (VOUT padded)
-    const void* Ws4;     // Ws quad-row packed for fm_wave_gemm4 (node-side GVPs; R4 instances)
+    const void* Ws4;     // Ws quad-row packed for fm_wave_gemm4 (node-side GVPs; RG instances)
     const void* Ws_sp;   // split-precision builds only: Ws / Wg as hi/lo bf16 planes in v_mfma_f32_16x16x32_bf16 B-fragment order
     const void* Wg_sp;
 };
@@ -520,9 +531,10 @@ struct FmGvpTile {
 // registers and written as a plain f32 [TM][FM_LDX] tile over the (then dead) planes for the aggregation.  G must then alias Vh + TM*FM_LDG.
 // PQ (FIRST only): the [rbf | ef] slab of the scalar linear arrives inside `pre` (per-pair table Q, FmMlpArgs::slabQ0): X holds only the hidden-vector
 // norms sh at columns [0, KU0) and the scalar GEMM has K = KU0.
-// R4 (node kernels of very small batches): only rows 0..3 of the 16-row tile are nodes; the scalar GEMM -- the one phase whose cost scales
-// with the tile height -- runs on those four rows with fm_wave_gemm4 (waves 0..3, 64 columns each); every other phase is the 16-row code.
-template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false, bool R4 = false>
+// RG > 0 (node kernels of small batches): only rows 0 .. 4 RG - 1 of the TM-row frame are nodes; the scalar GEMM -- the one phase whose cost
+// scales with the tile height -- runs on those rows with fm_wave_gemm4 (64 columns per wave, K split over the two wave groups, the halves
+// meeting in an exchange tile behind G); every other phase is the TM-row code over the frame.
+template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false, int RG = 0>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
     typedef FmGvpTile<V, TM, HX> T;
@@ -534,7 +546,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     constexpr int H = FIRST ? T::H0 : V;                 // hidden vector channels
     constexpr int KUC = FIRST ? T::KU0 : T::KU;          // K of this GVP's Wu GEMM = width of [hidden | cp | pad] in Vh and of sh in X
     static_assert(!PQ || (FIRST && !SP), "PQ is a variant of the first f32 edge GVP");
-    static_assert(!R4 || (!FIRST && !SP && TM == 16 && NTH == 512), "R4 is a variant of the non-first f32 GVP on 16-row tiles");
+    static_assert(RG == 0 || (!FIRST && !SP && 4 * RG <= TM && NTH == 512), "RG is a variant of the non-first f32 GVP: 4 RG nodes in a TM-row frame");
     constexpr int SOFF = PQ ? 0 : (FIRST ? 160 : 256);   // where sh goes in X
     constexpr int K8S = (SOFF + KUC) / 8;
     constexpr int VOP = VOUT < 16 ? 16 : VOUT;           // padded vector-out width
@@ -634,26 +646,34 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     }
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     float keep[(SP && LAST) ? MT : 1][(SP && LAST) ? NTW : 1][4];     // split precision, last GVP: the f32 scalar output for the aggregation
-    if constexpr (R4) {
-        // waves 0..3: k quads [0, KQ/2) of their 64 columns (starting from the bias), waves 4..7: the other half; the halves meet in Vh (dead here)
+    if constexpr (RG > 0) {
+        // waves 0..3: k quads [0, KQ/2) of their 64 columns (starting from the bias), waves 4..7: the other half; the halves meet in the exchange
+        // tile S [4 RG][256] that the RG instances allocate behind G
         constexpr int KQ = (SOFF + KUC) / 4, KQH = (KQ + 1) / 2;
-        static_assert(4 * 256 <= T::VH_FLOATS, "the exchange tile of the two K halves must fit into Vh");
+        float* S = G + TM * FM_LDG;
         const int g = wave & 3, half = wave >> 2;
         FM_MARKB(2);
         const float b4 = half ? 0.f : w.bs[64 * g + lane];
-        const f32x4 acc = half ? fm_wave_gemm4<KQH, KQ>(f32x4{0.f, 0.f, 0.f, 0.f}, X, FM_LDX, w.Ws4, g, lane)
-                               : fm_wave_gemm4<0, KQH>(f32x4{b4, b4, b4, b4}, X, FM_LDX, w.Ws4, g, lane);
+        f32x4 acc[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{b4, b4, b4, b4};
+        if (half) fm_wave_gemm4<KQH, KQ, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
+        else fm_wave_gemm4<0, KQH, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
         if (half) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Vh[r * 256 + 64 * g + lane] = acc[r];
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(4 * rg + r) * 256 + 64 * g + lane] = acc[rg][r];
         }
         __syncthreads();
         if (!half) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) X[r * FM_LDX + 64 * g + lane] = fm_silu(acc[r] + Vh[r * 256 + 64 * g + lane]);
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(4 * rg + r) * FM_LDX + 64 * g + lane] = fm_silu(acc[rg][r] + S[(4 * rg + r) * 256 + 64 * g + lane]);
         }
         __syncthreads();
     } else {

@@ -66,7 +66,8 @@ struct fm_ctx {
     int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
     int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (self-conditioned models; fm_config.pair_slab = -1: 0)
-    bool node_r4 = false;     // this batch runs the node kernel on 4-node tiles (R4 instance): chosen per bound batch, fm_config.tile_node = 4 forces it
+    int node_rg = 0;          // this batch runs the node kernel on tiles of 4 * node_rg nodes (RG instances; 1, 2, 3 in the 16-row frame, 5 in the 32-row
+                              // frame): chosen per bound batch, fm_config.tile_node = 4 / 8 / 12 / 20 forces it
     int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
@@ -513,9 +514,18 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
                 launched = true;
             }
         }
-        if constexpr (HX == 0 && TN == 16) {
-            if (!launched && c->node_r4 && fuse && c->S == 256 && cf.precision == FM_PREC_F32) {      // a few molecules: four nodes per workgroup
-                L("node_update", fm_k_node_update<V, 16, false, 0, 1>, dim3((N + 3) / 4), blk, lds_gvp(V, 16, false), nu);
+        if constexpr (HX == 0 && (TN == 16 || TN == 32)) {
+            if (!launched && c->node_rg && fuse && c->S == 256 && cf.precision == FM_PREC_F32) {      // small batches: 4 * node_rg nodes per workgroup, one tile per CU
+                const int rg = c->node_rg;
+                const dim3 grg((N + 4 * rg - 1) / (4 * rg));
+                const size_t lds_rg = lds_gvp(V, TN, false) + (size_t)rg * 4096;                       // + the exchange tile of the two K halves
+                if constexpr (TN == 16) {
+                    if (rg == 1) L("node_update", fm_k_node_update<V, 16, false, 0, 1>, grg, blk, lds_rg, nu);
+                    else if (rg == 2) L("node_update", fm_k_node_update<V, 16, false, 0, 2>, grg, blk, lds_rg, nu);
+                    else L("node_update", fm_k_node_update<V, 16, false, 0, 3>, grg, blk, lds_rg, nu);
+                } else {
+                    L("node_update", fm_k_node_update<V, 32, false, 0, 5>, grg, blk, lds_rg, nu);
+                }
                 launched = true;
             }
         }
@@ -956,9 +966,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             c->n_pq = i + 1;
         }
     auto tile_ok = [](int t) { return t == 0 || t == 16 || t == 32 || t == 64; };
-    if (!tile_ok(c->tm_edge_forced) || !(tile_ok(c->tm_node_forced) || c->tm_node_forced == 4)) {
+    auto rg_tile = [](int t) { return t == 4 || t == 8 || t == 12 || t == 20; };
+    if (!tile_ok(c->tm_edge_forced) || !(tile_ok(c->tm_node_forced) || rg_tile(c->tm_node_forced))) {
         (void)hipFree(c->arena); delete c;
-        return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.tile_edge must be 0 (automatic), 16, 32 or 64; tile_node additionally 4");
+        return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.tile_edge must be 0 (automatic), 16, 32 or 64; tile_node additionally 4, 8, 12 or 20");
     }
     {
         int dev = 0; hipDeviceProp_t prop{};
@@ -977,7 +988,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
     set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
-    set_lds(fm_k_node_update<32, 16, false, 0, 1>, lds_gvp(32, 16, false)); set_lds(fm_k_node_update<16, 16, false, 0, 1>, lds_gvp(16, 16, false));
+#define FM_SET_RG(V_) set_lds(fm_k_node_update<V_, 16, false, 0, 1>, lds_gvp(V_, 16, false) + 4096); set_lds(fm_k_node_update<V_, 16, false, 0, 2>, lds_gvp(V_, 16, false) + 8192); \
+    set_lds(fm_k_node_update<V_, 16, false, 0, 3>, lds_gvp(V_, 16, false) + 12288); set_lds(fm_k_node_update<V_, 32, false, 0, 5>, lds_gvp(V_, 32, false) + 20480);
+    FM_SET_RG(32) FM_SET_RG(16)
+#undef FM_SET_RG
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
     set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
@@ -1007,7 +1021,7 @@ int fm_destroy(fm_ctx* c) {
 
 // ---------------------------------------------------------------------------------------- workspace
 struct WsLayout {
-    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node; bool node_r4;
+    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node, node_rg;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_Psd, off_PVd, off_stab, off_bx, off_ba,
         off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, off_Q0, off_Q1, total;
@@ -1030,16 +1044,26 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
     w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
     if ((c->HX || !c->cfg.has_mask) && (w.tm_edge > 32)) w.tm_edge = 32;
-    // node tiles: 32 rows once the chip is full, 16 while 32-row tiles would leave CUs idle, and FOUR nodes in a 16-row frame (R4 instance of
-    // fm_k_node_update) while even the 4-node tiles fit one per CU: the node kernel is a serial chain per tile, so for a few molecules the
-    // step latency is what one CU needs for it
-    w.tm_node = c->tm_node_forced ? c->tm_node_forced : ((N + 3) / 4 <= c->n_cus ? 4 : (N + 31) / 32 <= c->n_cus ? 16 : 32);
-    if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
-    w.node_r4 = false;
-    if (w.tm_node == 4) {      // the 4-node instance lives in the 16-row frame; models it does not exist for (narrow, destination features, split precision, unfused) take 16-row tiles
-        w.node_r4 = c->S == 256 && c->HX == 0 && c->cfg.precision == FM_PREC_F32 && c->fuse_node;
-        w.tm_node = 16;
+    // node tiles: 32 rows once the chip is full, 16 while 32-row tiles would leave CUs idle -- and, for full-width f32 models on the fused node
+    // sequence, tiles of 4 / 8 / 12 nodes in the 16-row frame or 20 nodes in the 32-row frame (RG instances of fm_k_node_update) whenever such
+    // tiles fit ONE per CU: the node kernel is a serial chain per tile whose scalar GEMMs scale with the tile height, so the smallest tile that
+    // still gives every tile a CU of its own is the fastest (beyond one tile per CU the small tiles lose: each streams the full weights)
+    const bool rg_ok = c->S == 256 && c->HX == 0 && c->cfg.precision == FM_PREC_F32 && c->fuse_node;
+    int tn = c->tm_node_forced;
+    if (!tn) {
+        tn = (N + 31) / 32 <= c->n_cus ? 16 : 32;
+        if (rg_ok) {
+            static const int cand[] = {4, 8, 12, 16, 20};
+            for (int r : cand) if ((N + r - 1) / r <= c->n_cus) { tn = r; break; }
+        }
     }
+    w.node_rg = 0;
+    if (tn == 4 || tn == 8 || tn == 12 || tn == 20) {
+        if (rg_ok) { w.node_rg = tn / 4; tn = tn == 20 ? 32 : 16; }
+        else tn = tn == 20 ? 32 : 16;          // models the instances do not exist for take the frame's regular tile
+    }
+    w.tm_node = tn;
+    if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
     w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
@@ -1142,7 +1166,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     const int work = w.E > w.N ? w.E : w.N;
     L("batch_setup", fm_k_batch_setup, dim3((work + 255) / 256), dim3(256), 0, b);
     if (L.rc) return L.rc;
-    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node; c->node_r4 = w.node_r4;
+    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node; c->node_rg = w.node_rg;
     return FM_OK;
 }
 

@@ -788,7 +788,7 @@ struct FmNodeUpdArgs {
     const float2* Wasd; float* Asd;
     FmGvpW p0, p1, p2; float* x;     // x != null: x += GVP3(GVP2(GVP1(s, v))).v[:, 0]
     const void* Wps_sp; const void* Wasd_sp;      // split-precision instance: Wps / Wasd as bf16 hi/lo planes
-    const void* Wps4; const void* Wasd4;          // R4 instance: Wps / Wasd quad-row packed (fm_wave_gemm4)
+    const void* Wps4; const void* Wasd4;          // RG instances: Wps / Wasd quad-row packed (fm_wave_gemm4)
     int s_real;                      // NARROW instances: real scalar width (< 256); the LayerNorm statistics run over it
 };
 
@@ -814,7 +814,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
     const float vn = __builtin_amdgcn_sqrtf(q * (1.0f / (float)V) + 1e-5f) + 1e-5f;
     const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
-    const bool valid = r < rows_valid && row0 + r < nrows;       // rows_valid < TM: the R4 instances' tiles hold four nodes in a 16-row frame
+    const bool valid = r < rows_valid && row0 + r < nrows;       // rows_valid < TM: the RG instances' tiles hold 4 RG nodes in a TM-row frame
     if constexpr (SP) {
         float ys[256 / LPR];
 #pragma unroll
@@ -848,15 +848,17 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
 
 // SP = 1: opt-in split precision (fm_device.h "bf16x3"): the scalar / gate GEMMs of its six GVPs and the two 256 x 256 projections on the
 // bf16 matrix cores; LayerNorm, residuals, the vector path and the hidden-vector projection stay f32.
-// R4 = 1 (batches of a few molecules): a workgroup owns FOUR nodes in a 16-row frame -- a 47-atom molecule spreads over 12 CUs instead of 3.
-// The scalar GEMMs of its six GVPs and the two 256 x 256 projections, whose cost scales with the tile height, run on the four real rows with
-// v_mfma_f32_4x4x1_16B_f32 (fm_wave_gemm4); the vector-side GEMMs, LayerNorms and gates are the 16-row code over the frame (rows 4..15 carry
-// zeros / finite junk that is never stored).
-template <int V, int TM, bool NARROW, int SP, int R4 = 0>
+// RG > 0 (small batches): a workgroup owns 4 RG nodes in a TM-row frame (RG = 1, 2, 3 in the 16-row frame, 5 in the 32-row frame), chosen so
+// that the tiles fit one per CU: a 47-atom molecule spreads over 12 CUs instead of 3, and 256 x 18 atoms (C2) over 231 CUs with one tile each
+// instead of 288 sixteen-row tiles on 256 CUs.  The scalar GEMMs of its six GVPs and the two 256 x 256 projections, whose cost scales with the
+// tile height, run on the real rows with v_mfma_f32_4x4x1_16B_f32 (fm_wave_gemm4: every 1-KB weight fragment is loaded once and multiplied with
+// RG row groups); the vector-side GEMMs, LayerNorms and gates are the TM-row code over the frame (the other rows carry zeros / finite junk
+// that is never stored).
+template <int V, int TM, bool NARROW, int SP, int RG = 0>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) {
-    static_assert(!R4 || (TM == 16 && !NARROW && !SP), "the 4-node instance exists for f32 full-width models on the 16-row frame");
+    static_assert(RG == 0 || (4 * RG <= TM && !NARROW && !SP), "the 4 RG-node instances exist for f32 full-width models");
     typedef FmGvpTile<V, TM> T;
-    constexpr int RV = R4 ? 4 : TM;                                // rows of the frame that are nodes
+    constexpr int RV = RG ? 4 * RG : TM;                           // rows of the frame that are nodes
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
     float* Vin = X + (SP ? TM * FM_LDP : T::X_FLOATS);
@@ -939,9 +941,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
     {
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, true, false, R4 != 0>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));      // SP: leaves the f32 tile for the residual
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, RG>(X, Vin, Vh, G, a.g0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, RG>(X, Vin, Vh, G, a.g1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, true, false, RG>(X, Vin, Vh, G, a.g2, pre FM_MARK_PASS(50));      // SP: leaves the f32 tile for the residual
     }
     {   // residual: + (s1, v1), re-read from HBM with 16-byte loads (rows beyond N read 0)
         constexpr int NQ = TM * 64 / FM_THREADS;
@@ -993,16 +995,21 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         };
         if (a.Ps) project(a.Wps_sp, a.Ps);
         if (a.Asd) project(a.Wasd_sp, a.Asd);
-    } else if constexpr (R4) {
+    } else if constexpr (RG > 0) {
         // the two 256 x 256 projections side by side: waves 0..3 the next convolution's Ps, waves 4..7 EdgeUpdate's Asd, 64 columns per wave
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const void* wq = wave < 4 ? a.Wps4 : a.Wasd4;
         float* out = wave < 4 ? a.Ps : a.Asd;
         if (out) {
-            const f32x4 acc = fm_wave_gemm4<0, 64>(f32x4{0.f, 0.f, 0.f, 0.f}, X, FM_LDX, wq, wave & 3, lane);
+            f32x4 acc[RG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < rows) out[(size_t)(row0 + r) * 256 + 64 * (wave & 3) + lane] = acc[r];
+            for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fm_wave_gemm4<0, 64, RG>(acc, X, FM_LDX, wq, wave & 3, lane);
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * rg + r < rows) out[(size_t)(row0 + 4 * rg + r) * 256 + 64 * (wave & 3) + lane] = acc[rg][r];
         }
     } else {
     if (a.Ps)
@@ -1023,9 +1030,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
         __syncthreads();                     // every wave has read the tile for the projections
         FM_MARK_DECL
         float pre[TM / 16][2][4];
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
-        fm_gvp_core<V, 1, false, false, TM, FM_THREADS, 0, SP, false, false, R4 != 0>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, RG>(X, Vin, Vh, G, a.p0, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, V, false, true, TM, FM_THREADS, 0, SP, false, false, RG>(X, Vin, Vh, G, a.p1, pre FM_MARK_PASS(50));
+        fm_gvp_core<V, 1, false, false, TM, FM_THREADS, 0, SP, false, false, RG>(X, Vin, Vh, G, a.p2, pre FM_MARK_PASS(50));
         if (tid < TM * 3) {
             const int r = tid / 3, c = tid % 3, n = row0 + r;
             if (r < rows) a.x[n * 3 + c] += Vin[(c * TM + r) * T::LDVI];

@@ -98,8 +98,8 @@ typedef struct fm_config {
      * A/B measurements under profiles/ and for the parity tests that run every tile size; up to ABI 4 they were environment variables
      * read inside fm_create, which hid them from the interface.  The library reads NO environment variable. */
     int32_t tile_edge;            /* rows per workgroup tile of the edge kernels: 0 = per batch (16 while 32-row tiles would leave CUs idle, else 32) | 16 | 32 | 64 */
-    int32_t tile_node;            /* same for the node kernels; additionally 4 = four nodes per workgroup (in the 16-row frame, scalar GEMMs on v_mfma_f32_4x4x1):
-                                   * the automatic choice while such tiles fit one per CU (a few molecules) */
+    int32_t tile_node;            /* same for the node kernels; additionally 4 | 8 | 12 (nodes per workgroup in the 16-row frame) | 20 (in the 32-row frame), scalar GEMMs
+                                   * on v_mfma_f32_4x4x1: the automatic choice is the smallest of 4 / 8 / 12 / 16 / 20 whose tiles fit one per CU */
     int32_t tile_edge_update;     /* EdgeUpdate tile: 0 = 32 | 32 | 64 */
     int32_t xcd_swizzle;          /* edge-message tile -> workgroup map: 0 / 1 = one contiguous tile range per XCD | -1 = identity */
     int32_t fuse_node;            /* 0 / 1 = node_update also runs the next conv's projections + NodePositionUpdate | -1 = separate launches */
