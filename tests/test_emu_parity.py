@@ -443,21 +443,24 @@ def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
     assert same != bool(prev and cfg.self_conditioning)
 
 
-@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [5, 9, 2, 1], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False), ('dev_narrow', [5, 3], 0.5, True)])
-def test_four_node_tiles_on_emulation(emu_lib, name, sizes, t, prev):
-    """fm_config.tile_node = 4 (the automatic choice for a few molecules): the node kernel on FOUR nodes per workgroup, its scalar GEMMs and the
-    two 256 x 256 projections on v_mfma_f32_4x4x1_16B_f32 with quad-row packed weights (R4 instance of fm_k_node_update; the emulation executes
-    the instruction with the operand layout verified on the device, tools/ubench/mfma_4x4_layout.cpp).  Every stage against the oracle, and the
-    switch really selects other arithmetic for the models the instance exists for (full-width f32; dev_narrow falls back to 16-row tiles)."""
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [5, 9, 2, 1, 11], 0.5, True), ('geom_ctmc', [6, 3], 0.4, False), ('dev_narrow', [5, 3], 0.5, True)])
+def test_small_node_tiles_on_emulation(emu_lib, name, sizes, t, prev):
+    """fm_config.tile_node = 4 / 8 / 12 / 20 (chosen automatically as the smallest tile that fits one per CU): the node kernel on 4 RG nodes per
+    workgroup in a 16- or 32-row frame, its scalar GEMMs and the two 256 x 256 projections on v_mfma_f32_4x4x1_16B_f32 with quad-row packed
+    weights (RG instances of fm_k_node_update; the emulation executes the instruction with the operand layout verified on the device,
+    tools/ubench/mfma_4x4_layout.cpp).  Every stage against the oracle for every tile; the 4 / 8 / 12-node tiles share the arithmetic of a row
+    (bit-identical results), the regular 16-row tile is other arithmetic, and models the instances do not exist for (dev_narrow) fall back to
+    the frame's regular tile."""
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
     sd = weights.synth_state_dict(cfg, 0)
     outs = {}
-    for tile in (4, 16):
+    for tile in (4, 8, 12, 16, 20):
         eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning={'tile_node': tile, 'tile_edge': 16})
-        errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), t, prev)
+        errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), t, prev, taps=(tile in (4, 20)))
         bad = {k: v for k, v in errs.items() if not v < 2e-5}
         assert not bad, (tile, bad)
         outs[tile] = {k: v.clone() for k, v in out.items()}
-    same = all(torch.equal(outs[4][k], outs[16][k]) for k in 'xace')
-    assert same == (cfg.n_hidden_scalars != 256), name
+    full_width = cfg.n_hidden_scalars == 256
+    assert all(torch.equal(outs[4][k], outs[8][k]) and torch.equal(outs[4][k], outs[12][k]) for k in 'xace')
+    assert all(torch.equal(outs[4][k], outs[16][k]) for k in 'xace') == (not full_width), name

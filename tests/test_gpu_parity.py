@@ -85,13 +85,13 @@ def test_forward_matches_oracle(name, sizes, t, prev, tile):
 
 @pytest.mark.parametrize('tuning', [{'tile_edge': 64, 'tile_node': 64}, {'tile_edge_update': 64}, {'tile_edge': 64, 'tile_node': 64, 'tile_edge_update': 64, 'pair_slab': -1},
                                     {'pair_slab': -1}, {'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': -1, 'mlp_small_tiles': -1}, {'xcd_swizzle': -1, 'fuse_node': -1},
-                                    {'tile_node': 4}, {'tile_node': 4, 'tile_edge': 32, 'pair_slab': 1}, {'tile_node': 16}])
+                                    {'tile_node': 4}, {'tile_node': 4, 'tile_edge': 32, 'pair_slab': 1}, {'tile_node': 8}, {'tile_node': 12}, {'tile_node': 20}, {'tile_node': 16}])
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [70, 2, 47, 130], 0.3, True), ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False), ('flowmol3', [5, 9, 12, 3, 2], 0.0, False)])
 def test_forward_matches_oracle_under_every_accepted_tuning(name, sizes, t, prev, tuning):
     """Every launch-tuning value fm_config accepts is parity-tested (VERDICT r3 hygiene #14): 64-row tiles of the GVP kernels and of EdgeUpdate
     (accepted by fm_create, never chosen automatically), the pair-slab hoist switched off / forced on at small sizes (ABI 6; automatic only for
-    large batches), the unfused / unswizzled launch sequence, and the 4-node tiles of the node kernel (automatic for a few molecules) forced on
-    for batches with 130-atom molecules and off for small ones."""
+    large batches), the unfused / unswizzled launch sequence, and the 4 / 8 / 12 / 20-node tiles of the node kernel (chosen automatically as the smallest tile
+    that fits one per CU) forced on for batches with 130-atom molecules, and the regular 16-row tile forced for small ones."""
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
     sd = weights.synth_state_dict(cfg, 0)
