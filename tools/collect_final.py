@@ -30,8 +30,26 @@ fetch = take('pmc_fetch.txt', f'{ptag}_pmc_fetch.txt')
 write = take('pmc_write.txt', f'{ptag}_pmc_write_tcc.txt')
 for extra in sorted(D.glob('pmc_extra_*.txt')):
     take(extra.name, f'{ptag}_{extra.stem[:48]}.txt')
-bench = json.loads((G / f'{gtag}_bench_{name}.json').read_text().strip().splitlines()[-1])
-(P / f'{ptag}_bench.json').write_text(json.dumps(bench) + '\n')
+
+
+def pass_line(log):
+    """The bench line the profiled command itself printed (every pass logs it): workload sizes and the digest of the library the counters were measured on."""
+    for line in reversed((D / log).read_text().splitlines()):
+        if line.startswith('{"metric"'):
+            return json.loads(line)
+    raise SystemExit(f'{D / log}: no bench line')
+
+
+passes = {log: pass_line(log + '.log') for log in ('stats', 'pmc_sq', 'pmc_fetch', 'pmc_write')}
+digests = {b['config'].get('library_digest') for b in passes.values()}
+if len(digests) != 1:
+    raise SystemExit(f'the passes ran on different libraries: {digests}')
+bench_file = G / f'{gtag}_bench_{name}.json'
+bench = json.loads(bench_file.read_text().strip().splitlines()[-1]) if bench_file.exists() else None
+if bench is not None and bench['config'].get('library_digest') in digests:
+    (P / f'{ptag}_bench.json').write_text(json.dumps(bench) + '\n')          # the un-profiled bench line of the same call
+else:
+    bench = passes['stats']                                                     # sizes / algorithmic bytes: the profiled run's own line (its timings carry the profiler)
 
 
 def instances(txt, prefix):
@@ -88,7 +106,7 @@ if '--current' in sys.argv:
             allw = {}
     except Exception:
         allw = {}
-    allw[wl] = {'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'collected_at_commit': commit, 'library_digest': bench['config'].get('library_digest'),
+    allw[wl] = {'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'collected_at_commit': commit, 'library_digest': digests.copy().pop(),
                 'kernel': k_main, 'other_instances': [n for n in k_names if n != k_main], 'hbm_bytes_per_launch': traffic['hbm_bytes_per_launch'], 'source': f'profiles/{ptag}_traffic.json',
                 'mfma_busy_frac': busy / (gui / 8 * 1024), 'source_sq': f'profiles/{ptag}_pmc_sq.txt',
                 'note': 'GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs = 256 CUs x 4'}
