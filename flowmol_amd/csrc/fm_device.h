@@ -791,20 +791,38 @@ __device__ __forceinline__ void fm_gather_pre(float (&pre)[TM / 16][1024 / NTH][
         }
 }
 
+// Sum over a group of LPR consecutive lanes (LPR = 2 .. 32, group-aligned), every lane receiving the total: bit for bit the xor butterfly
+// `for (o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o)`.  After each level all lanes of a 2^k group hold the same value (IEEE addition commutes), so
+// the partner of the next level may be ANY lane of the neighbouring group: quad_perm [1,0,3,2] / [2,3,0,1] for o = 1, 2, row_half_mirror for 4,
+// row_mirror for 8 -- one v_add_f32 with a DPP operand per level instead of address arithmetic (4 VALU) + ds_bpermute + add; o = 16 swaps the
+// two rows of 16 with ds_swizzle (no address register).
+template <int CTRL>
+__device__ __forceinline__ float fm_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int LPR>
+__device__ __forceinline__ float fm_group_sum(float s) {
+    static_assert(LPR == 2 || LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32, "group of 2 .. 32 lanes");
+    s += fm_dpp<0xB1>(s);
+    if constexpr (LPR > 2) s += fm_dpp<0x4E>(s);
+    if constexpr (LPR > 4) s += fm_dpp<0x141>(s);
+    if constexpr (LPR > 8) s += fm_dpp<0x140>(s);
+    if constexpr (LPR > 16) s += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s), 0x401F));   // lane ^ 16
+    return s;
+}
+
 // LayerNorm statistics of one LDS row handled by a group of LPR consecutive lanes (LPR = 8 or 16):
 // two-pass mean / biased variance like torch.nn.functional.layer_norm.  All lanes must call it.
 template <int LPR>
 __device__ __forceinline__ void fm_row_stats(const float* row, int n, int sub, float& mean, float& rstd) {
     float s = 0.f;
     for (int c = sub; c < n; c += LPR) s += row[c];
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    s = fm_group_sum<LPR>(s);
     const float inv_n = 1.0f / (float)n;          // n is a power of two in every use: s * inv_n == s / n bit for bit
     mean = s * inv_n;
     float q = 0.f;
     for (int c = sub; c < n; c += LPR) { const float d = row[c] - mean; q += d * d; }
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
+    q = fm_group_sum<LPR>(q);
     rstd = __builtin_amdgcn_rsqf(q * inv_n + 1e-5f);     // v_rsq_f32 (~1 ulp) instead of IEEE 1/sqrt (about 25 VALU less per row lane)
 }
 __device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {

@@ -810,8 +810,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
         const float vx = Vin[(0 * TM + r) * T::LDVI + u], vy = Vin[(1 * TM + r) * T::LDVI + u], vz = Vin[(2 * TM + r) * T::LDVI + u];
         q += fmaxf(vx * vx + vy * vy + vz * vz, 1e-8f);
     }
-    #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o);
+    q = fm_group_sum<LPR>(q);
     const float vn = __builtin_amdgcn_sqrtf(q * (1.0f / (float)V) + 1e-5f) + 1e-5f;
     const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
     const bool valid = r < rows_valid && row0 + r < nrows;       // rows_valid < TM: the RG instances' tiles hold 4 RG nodes in a TM-row frame
@@ -1122,9 +1121,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     constexpr int LDX = 164, LDH = 132, MT = TM / 16, LPR = FM_THREADS / TM;
     float* X = lds;                       // [TM][164]: ef(128) | rbf(32)
     float* Hb = lds + TM * LDX;           // [TM][132]
-    int* m_src = reinterpret_cast<int*>(Hb + TM * LDH);
-    int* m_dst = m_src + TM;
-    float* m_d = reinterpret_cast<float*>(m_dst + TM);
+    int* m_soff = reinterpret_cast<int*>(Hb + TM * LDH);      // [TM] byte offset of the source's row in Asd (FM_BUF_OOB for rows past the edge list:
+    int* m_doff = m_soff + TM;                                // the range check returns 0 whatever column offset is added), same for the destination
+    float* m_d = reinterpret_cast<float*>(m_doff + TM);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), e0 = blockIdx.x * TM;
     // the tile's ef rows depend only on the tile index: request them first.  Tile-relative descriptor; its range check
     // zero-fills the rows of a ragged last tile on load and drops them on the final store.
@@ -1141,7 +1140,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
             s = a.b.e_src[e]; d = a.b.e_dst[e];
             dist = fm_norm3(a.x[s * 3] - a.x[d * 3], a.x[s * 3 + 1] - a.x[d * 3 + 1], a.x[s * 3 + 2] - a.x[d * 3 + 2]) + 1e-8f;
         }
-        m_src[tid] = s; m_dst[tid] = d; m_d[tid] = dist;
+        m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB; m_doff[tid] = s >= 0 ? d * 1024 : FM_BUF_OOB; m_d[tid] = dist;
     }
     __syncthreads();
     // layer 1: wave w owns column tile w for all MT row tiles.  The hoisted node terms W1_src*s[src] + W1_dst*s[dst]
@@ -1153,20 +1152,26 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     {
         const auto rs = fm_buf(a.Asd, (unsigned)a.b.N * 1024u);
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {       // the lane's four rows of a row tile: one ds_read_b128 per table, one v_add per gathered row (fm_gather_pre's addressing)
+            const int4 so = *reinterpret_cast<const int4*>(m_soff + i * 16 + 4 * (lane >> 4)), dof = *reinterpret_cast<const int4*>(m_doff + i * 16 + 4 * (lane >> 4));
+            const int so_[4] = {so.x, so.y, so.z, so.w}, do_[4] = {dof.x, dof.y, dof.z, dof.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = i * 16 + 4 * (lane >> 4) + r;
-                const int sidx = m_src[row], didx = m_dst[row];
-                pre_s[i][r] = fm_buf_f32(rs, sidx >= 0 ? sidx * 1024 + (lane & 15) * 4 : FM_BUF_OOB, wave * 64);
-                pre_d[i][r] = fm_buf_f32(rs, sidx >= 0 ? didx * 1024 + (lane & 15) * 4 : FM_BUF_OOB, 512 + wave * 64);
+                pre_s[i][r] = fm_buf_f32(rs, so_[r] + (lane & 15) * 4, wave * 64);
+                pre_d[i][r] = fm_buf_f32(rs, do_[r] + (lane & 15) * 4, 512 + wave * 64);
             }
+        }
     }
+    {   // thread -> (row fr + 16 k, float4 column c4): one address per thread, the passes are immediate offsets
+        constexpr int RP = FM_THREADS / 32;
+        const int fr = tid >> 5, c4 = tid & 31;
+        float* xe = X + fr * LDX + 4 * c4;
+        float* xr = X + fr * LDX + 128 + c4;
 #pragma unroll
-    for (int k = 0; k < NEF; ++k) {
-        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
-        *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = efv[k];       // one ds_write_b128 (row pitch 656 B and column offset are multiples of 16 B)
-        X[r * LDX + 128 + c4] = (m_src[r] >= 0) ? fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma) : 0.f;
+        for (int k = 0; k < NEF; ++k) {
+            *reinterpret_cast<float4*>(xe + k * RP * LDX) = efv[k];       // one ds_write_b128 (row pitch 656 B and column offset are multiples of 16 B)
+            xr[k * RP * LDX] = fm_rbf(m_d[fr + k * RP], c4, a.rbf_mu_step, a.rbf_inv_sigma);      // rows past the edge list (d = 0): finite junk, dropped by the final store's range check
+        }
     }
     __syncthreads();
     float* ho = Hb + (4 * (lane >> 4)) * LDH + col;

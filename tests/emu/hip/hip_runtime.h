@@ -170,6 +170,24 @@ static inline void emu_raw_buffer_store_b128(emu_u32x4 d, emu_rsrc r, int voff, 
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l))   /* must be called by the whole wave */
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* value is wave-uniform by contract */
+// DPP / swizzle lane exchanges (must be called by the whole wave): the source lane each control selects
+static inline int emu_update_dpp(int /*old*/, int v, int ctrl, int, int, bool) {
+    const int l = emu::lane_id();
+    int src;
+    if (ctrl < 0x100) src = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);           // quad_perm
+    else if (ctrl == 0x140) src = (l & ~15) | (15 - (l & 15));                   // row_mirror
+    else if (ctrl == 0x141) src = (l & ~7) | (7 - (l & 7));                      // row_half_mirror
+    else abort();
+    return emu::shfl_i(v, src, 64);
+}
+static inline int emu_ds_swizzle(int v, int pattern) {                           // bit-mask mode within groups of 32 lanes
+    if (pattern & 0x8000) abort();
+    const int l = emu::lane_id(), l5 = l & 31;
+    const int src5 = ((l5 & (pattern & 31)) | ((pattern >> 5) & 31)) ^ ((pattern >> 10) & 31);
+    return emu::shfl_i(v, (l & ~31) | src5, 64);
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+#define __builtin_amdgcn_ds_swizzle emu_ds_swizzle
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_exp2f(x) exp2f(x)

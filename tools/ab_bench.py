@@ -1,8 +1,8 @@
 """A/B micro-benchmark of kernel variants on the GPU box (one process per variant).
 
     python tools/ab_bench.py --lib <lib.so> [--preset flowmol3] [--mols 1024] [--atoms 47] [--precision f32] [--tuning tile_edge=32,tile_node=32]
-prints one JSON line: per-kernel avg us over 3 profiled network evaluations, eval wall ms, and the
-max relative output error of a small parity batch against the CPU oracle."""
+prints one JSON line: per-kernel avg us over 3 profiled network evaluations, eval wall ms, the max relative
+output error of a small parity batch against the CPU oracle, and a sha256 of the full batch's outputs (equal for bit-identical variants)."""
 import argparse
 import json
 import sys
@@ -64,6 +64,9 @@ for k in ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_
     ms, cnt = eng.profile_get(k)
     if cnt:
         kern[k] = round(ms * 1e3 / cnt, 1)
-print(json.dumps({'lib': Path(args.lib).name, 'preset': args.preset, 'precision': args.precision, 'tuning': tuning, 'mols': B, 'atoms': n, 'eval_ms': round(wall, 2),
+import hashlib                                          # noqa: E402
+# bit-level fingerprints of the full batch's outputs: equal between two libraries <=> same arithmetic
+sha = {k: hashlib.sha256(out[k].detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:12] for k in sorted(out) if torch.is_tensor(out[k])}
+print(json.dumps({'lib': Path(args.lib).name, 'out_sha': sha, 'preset': args.preset, 'precision': args.precision, 'tuning': tuning, 'mols': B, 'atoms': n, 'eval_ms': round(wall, 2),
                   'mol_per_s_at_250': round(B / (250 * wall / 1e3), 2), 'kernels_us': kern,
                   'parity_out_rel': {k: float(f'{v:.2e}') for k, v in errs.items()}}))
