@@ -83,9 +83,16 @@ __device__ __forceinline__ float fm_exp_neg(float x) { return __builtin_amdgcn_e
 __device__ __forceinline__ float fm_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + fm_exp_neg(x)); }
 __device__ __forceinline__ float fm_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fm_exp_neg(x)); }
 
-// Correctly rounded, never-contracted f32 operations for the few places whose results must equal the
-// reference's separately rounded torch ops bit for bit (Euler step, purity-sampling probabilities).
-// HIP's __fmul_rn & co. are plain operators that hipcc's default -ffp-contract=fast may fuse into FMAs.
+// Floating-point contraction is OFF for the whole library (flowmol_amd/build.py: -ffp-contract=off): the compiler never fuses a
+// multiply with an add on its own, so the last bits of every result follow from the SOURCE, not from how a kernel's loops happen to be
+// arranged (round 4 measured the same source giving different output fingerprints after a fill loop was rearranged: hipcc's default
+// -ffp-contract=fast decides per call site).  Where a fused multiply-add is wanted -- one VALU instruction instead of two, and VALU
+// instructions cost matrix-pipe issue slots on gfx950 -- it is written out: fm_fma(a, b, c) = a * b + c with ONE rounding (v_fma_f32).
+__device__ __forceinline__ float fm_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Correctly rounded, separately rounded f32 operations for the few places whose results must equal the
+// reference's torch ops bit for bit (Euler step, purity-sampling probabilities).  With contraction off these are the plain
+// operators; the pragmas keep them so under any build flags.
 __device__ __forceinline__ float fm_mul_rn(float a, float b) {
 #pragma clang fp contract(off)
     return a * b;
@@ -105,13 +112,13 @@ __device__ __forceinline__ float fm_div_rn(float a, float b) {
 
 // Gaussian RBF, reference flowmol/utils/embedding.py:19-34: mu_k = k*Dmax/(R-1), sigma = Dmax/R
 __device__ __forceinline__ float fm_rbf(float d, int k, float mu_step, float inv_sigma) {
-    float z = (d - (float)k * mu_step) * inv_sigma;
+    const float z = fm_fma(-(float)k, mu_step, d) * inv_sigma;      // d - k mu_step, one rounding
     return __builtin_amdgcn_exp2f(z * z * -1.44269504088896341f);
 }
 
 // distance with the reference's clamps: sqrt(max(|dx|^2,1e-8)) (+1e-8 added by the caller where the reference does)
 __device__ __forceinline__ float fm_norm3(float dx, float dy, float dz) {
-    float s = dx * dx + dy * dy + dz * dz;
+    const float s = fm_fma(dz, dz, fm_fma(dy, dy, dx * dx));
     return __builtin_amdgcn_sqrtf(fmaxf(s, 1e-8f));     // v_sqrt_f32 (~1 ulp); the argument is >= 1e-8, far from denormals, so
                                                         // sqrtf()'s scaling / fix-up sequence (8 more VALU per call) buys nothing
 }
@@ -608,9 +615,9 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
             a[c] = Vh[(c * TM + r) * T::LDVH + CPSRC + p];
             b[c] = Vh[(c * TM + r) * T::LDVH + CPSRC + 4 + p];
         }
-        const float cx = a[1] * b[2] - a[2] * b[1];
-        const float cy = a[2] * b[0] - a[0] * b[2];
-        const float cz = a[0] * b[1] - a[1] * b[0];
+        const float cx = fm_fma(a[1], b[2], -(a[2] * b[1]));
+        const float cy = fm_fma(a[2], b[0], -(a[0] * b[2]));
+        const float cz = fm_fma(a[0], b[1], -(a[1] * b[0]));
         if (!FIRST) {   // the b-channels sit inside the K range of the Wu GEMM: clear them
 #pragma unroll
             for (int c = 0; c < 3; ++c) Vh[(c * TM + r) * T::LDVH + V + 4 + p] = 0.f;
@@ -821,9 +828,9 @@ __device__ __forceinline__ void fm_row_stats(const float* row, int n, int sub, f
     const float inv_n = 1.0f / (float)n;          // n is a power of two in every use: s * inv_n == s / n bit for bit
     mean = s * inv_n;
     float q = 0.f;
-    for (int c = sub; c < n; c += LPR) { const float d = row[c] - mean; q += d * d; }
+    for (int c = sub; c < n; c += LPR) { const float d = row[c] - mean; q = fm_fma(d, d, q); }
     q = fm_group_sum<LPR>(q);
-    rstd = __builtin_amdgcn_rsqf(q * inv_n + 1e-5f);     // v_rsq_f32 (~1 ulp) instead of IEEE 1/sqrt (about 25 VALU less per row lane)
+    rstd = __builtin_amdgcn_rsqf(fm_fma(q, inv_n, 1e-5f));     // v_rsq_f32 (~1 ulp) instead of IEEE 1/sqrt (about 25 VALU less per row lane)
 }
 __device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {
     fm_row_stats<8>(row, n, sub, mean, rstd);

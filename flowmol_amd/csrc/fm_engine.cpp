@@ -371,6 +371,14 @@ void launch_mlp_pair(Launch& L, const char* name, FmMlpArgs a, const MlpW& wa, i
     else L(name, fm_k_mlp2_pair<MODE_A, MODE_B>, dim3(ta + tb), dim3(FM_THREADS), lds, a, b, ta);
 }
 
+// Pair-slab convolutions of a bound batch (fm_ctx::n_pq of them at most): the hoist is on for batches with at least four rounds of 32-row pair tiles
+// (measured neutral below: the table costs a kernel phase, the saving is matrix-pipe time small batches are not bound by) or when fm_config.pair_slab
+// forces it.  ONE predicate for the workspace layout (the Q tables, U KB each, exist only when it holds) and for every evaluation.
+inline int pq_convs(const fm_ctx* c, long long U) {
+    if (c->n_pq == 0 || U <= 0 || ld_for(c->sc_edge.H) > 164) return 0;      // the slab GEMM reads [rbf | ef] rows at the pitch 164 of a 128-wide hidden tile
+    return (c->pq_forced || (U + 31) / 32 >= 16LL * c->n_cus) ? c->n_pq : 0;
+}
+
 // ---------------------------------------------------------------------------------------- one network evaluation
 template <int V, int TE, int TN, int HX>
 int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
@@ -395,7 +403,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
     // pair-slab convolutions of this evaluation (first pass only; FmMlpArgs::slabQ0): self-conditioned evaluations with at least four rounds of
     // 32-row pair tiles (measured neutral on small batches: the table costs a kernel phase, the saving is matrix-pipe time they are not bound by)
-    const int n_pq = (HX == 0 && prev && !dense && (c->pq_forced ? U > 0 : (U + 31) / 32 >= 16 * c->n_cus)) ? c->n_pq : 0;
+    const int n_pq = (HX == 0 && prev && !dense) ? pq_convs(c, U) : 0;
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -629,8 +637,9 @@ int forward_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const float* 
 
 __global__ void fm_k_noop() {}
 
+// frame: this step's slice of the trajectory sink (x, a, c, e, x1 used; a1 / c1 / e1 travel in `smp`); campbell steps write it inside the fused kernel
 int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* dst, const fm_step_noise* nz,
-              const fm_step_scalars* sc, const fm_sampled* smp, const float* x_raw = nullptr) {
+              const fm_step_scalars* sc, const fm_sampled* smp, const float* x_raw = nullptr, const fm_traj_sink* frame = nullptr) {
     Launch L{c, st};
     // profiling only: an event pair around an empty kernel, once per step.  Its elapsed time is what a pair adds to every profiled launch
     // (event signalling + the dispatch that cannot overlap the previous kernel's tail); fm_profile_get("event_overhead") lets the caller
@@ -668,10 +677,12 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
         FmCtmcMod& d = f.mod[m];
         d.K = mods[m].K; d.p = mods[m].p; d.xt = mods[m].xt; d.x1 = mods[m].x1; d.q = mods[m].q; d.u1 = mods[m].u1; d.u2 = mods[m].u2;
         d.off = offs[m]; d.unmask_prob = sc->unmask_prob[m]; d.mask_prob = sc->mask_prob[m];
+        d.sink_t = frame ? (m == 0 ? frame->a : m == 1 ? frame->c : frame->e) : nullptr;
     }
     f.temp = sc->cat_temperature; f.hc_thresh = sc->hc_thresh; f.last_step = sc->last_step;
     f.x_t = state->x_t; f.x1 = dst->x; f.node_off = b.mol_node_off; f.coef = sc->x_coef; f.dt = sc->dt; f.scale = sc->x_scale;
     f.x_raw = x_raw; f.x1_out = dst->x;
+    if (frame) { f.sink_x = frame->x; f.sink_x1 = frame->x1; }
     if (sc->noise_mode == FM_NOISE_PHILOX) { f.philox = 1; f.seed_lo = sc->philox_seed_lo; f.seed_hi = sc->philox_seed_hi; f.step = sc->step_index; f.mol_gid = c->mol_gid; }
     else if (!nz->q_a || !nz->u1_a || !nz->q_e) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: noise tensors missing (noise_mode FM_NOISE_TENSORS)");
     L("ctmc", fm_k_ctmc_fused, dim3(b.B, 4), dim3(256), 0, f);
@@ -1082,7 +1093,8 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.off_tap_s = take((size_t)N * 256 * 4); w.off_tap_v = take((size_t)N * 3 * V * 4);
     w.off_gid = take((size_t)B * 4);
     w.off_sa1 = take((size_t)N * 4); w.off_sc1 = take((size_t)N * 4); w.off_se1 = take((size_t)w.U * 4);
-    w.off_Q0 = take(c->n_pq > 0 ? (size_t)w.U * 256 * 4 : 0); w.off_Q1 = take(c->n_pq > 1 ? (size_t)w.U * 256 * 4 : 0);
+    const int npq = pq_convs(c, w.U);      // the pair-slab tables are as large as `ef` each: only batches that use them pay for them (8192 x 47 atoms: 13.3 GB without, 31.5 GB with)
+    w.off_Q0 = take(npq > 0 ? (size_t)w.U * 256 * 4 : 0); w.off_Q1 = take(npq > 1 ? (size_t)w.U * 256 * 4 : 0);
     w.total = o;
     return FM_OK;
 }
@@ -1265,20 +1277,27 @@ int fm_integrate(fm_ctx* c, void* stream, const fm_state* state, int n_steps, co
         int rc = forward_impl(c, st, state, temb + (size_t)i * tt, prev, boot, defer_com ? 2 : 1, out, i % FM_TAB_SLOTS);
         if (rc) return rc;
         fm_sampled smp{};
+        fm_traj_sink frame{};      // step i's frames: the fused CTMC kernel writes them next to the state (no copy nodes per step)
         if (sink) {
             smp.a1 = sink->a1 ? sink->a1 + (size_t)i * b.N : nullptr;
             smp.c1 = sink->c1 ? sink->c1 + (size_t)i * b.N : nullptr;
             smp.e1 = sink->e1 ? sink->e1 + (size_t)i * b.U : nullptr;
+            frame.x = sink->x ? sink->x + (size_t)i * b.N * 3 : nullptr;
+            frame.a = sink->a ? sink->a + (size_t)i * b.N : nullptr;
+            frame.c = sink->c ? sink->c + (size_t)i * b.N : nullptr;
+            frame.e = sink->e ? sink->e + (size_t)i * b.U : nullptr;
+            frame.x1 = sink->x1 ? sink->x1 + (size_t)i * b.N * 3 : nullptr;
         }
-        rc = ctmc_impl(c, st, state, out, noise ? &noise[i] : nullptr, &steps[i], &smp, defer_com ? c->xw : nullptr);
+        const bool in_kernel = sink && steps[i].dfm_type == FM_DFM_CAMPBELL;
+        rc = ctmc_impl(c, st, state, out, noise ? &noise[i] : nullptr, &steps[i], &smp, defer_com ? c->xw : nullptr, in_kernel ? &frame : nullptr);
         if (rc) return rc;
-        if (sink) {
+        if (sink && !in_kernel) {      // 'gat' steps (three small kernels): frames by copy
             Launch L{c, st};
-            if (sink->x) L.copy(sink->x + (size_t)i * b.N * 3, state->x_t, (size_t)b.N * 12);
-            if (sink->a) L.copy(sink->a + (size_t)i * b.N, state->a_t, (size_t)b.N * 4);
-            if (sink->c) L.copy(sink->c + (size_t)i * b.N, state->c_t, (size_t)b.N * 4);
-            if (sink->e) L.copy(sink->e + (size_t)i * b.U, state->e_t, (size_t)b.U * 4);
-            if (sink->x1) L.copy(sink->x1 + (size_t)i * b.N * 3, out->x, (size_t)b.N * 12);
+            L.copy(frame.x, state->x_t, frame.x ? (size_t)b.N * 12 : 0);
+            L.copy(frame.a, state->a_t, frame.a ? (size_t)b.N * 4 : 0);
+            L.copy(frame.c, state->c_t, frame.c ? (size_t)b.N * 4 : 0);
+            L.copy(frame.e, state->e_t, frame.e ? (size_t)b.U * 4 : 0);
+            L.copy(frame.x1, out->x, frame.x1 ? (size_t)b.N * 12 : 0);
             if (L.rc) return L.rc;
         }
         prev = out;

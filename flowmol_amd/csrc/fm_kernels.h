@@ -276,7 +276,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
             float* o0 = a.out + (size_t)(a.p_e0 ? a.p_e0[grow] : grow) * a.out_ld;
             float* o1 = a.p_e1 ? a.out + (size_t)a.p_e1[grow] * a.out_ld : nullptr;
             for (int c = sub; c < a.O; c += LPR) {
-                const float y = (X[r * a.ldx + c] - mean) * rstd * a.ln_g[c] + a.ln_b[c];
+                const float y = fm_fma((X[r * a.ldx + c] - mean) * rstd, a.ln_g[c], a.ln_b[c]);
                 o0[c] = y;
                 if (o1) o1[c] = y;
             }
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         for (int p_ = 0; p_ < NP; ++p_) {
             const int ch = q + p_ * QN, r = ch % TM, ccb = ch / TM, c = ccb / CB, cb = ccb % CB;
             if (NCH % QN == 0 || ch < NCH)
-                Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = pv[p_] + m_geo[4 * r + c] * w0v[p_];      // rows without an edge: 0 + 0 * w0 (range-checked gather, zero geometry)
+                Vh[(c * TM + r) * T::LDVH + cb * 16 + j] = fm_fma(m_geo[4 * r + c], w0v[p_], pv[p_]);      // rows without an edge: 0 + 0 * w0 (range-checked gather, zero geometry)
         }
     }
     if (SP) {
@@ -808,10 +808,10 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     float q = 0.f;
     for (int u = sub; u < V; u += LPR) {
         const float vx = Vin[(0 * TM + r) * T::LDVI + u], vy = Vin[(1 * TM + r) * T::LDVI + u], vz = Vin[(2 * TM + r) * T::LDVI + u];
-        q += fmaxf(vx * vx + vy * vy + vz * vz, 1e-8f);
+        q += fmaxf(fm_fma(vz, vz, fm_fma(vy, vy, vx * vx)), 1e-8f);
     }
     q = fm_group_sum<LPR>(q);
-    const float vn = __builtin_amdgcn_sqrtf(q * (1.0f / (float)V) + 1e-5f) + 1e-5f;
+    const float vn = __builtin_amdgcn_sqrtf(fm_fma(q, 1.0f / (float)V, 1e-5f)) + 1e-5f;
     const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
     const bool valid = r < rows_valid && row0 + r < nrows;       // rows_valid < TM: the RG instances' tiles hold 4 RG nodes in a TM-row frame
     if constexpr (SP) {
@@ -819,7 +819,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
 #pragma unroll
         for (int k = 0; k < 256 / LPR; ++k) {
             const int c = sub + k * LPR;
-            ys[k] = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
+            ys[k] = fm_fma((X[r * FM_LDX + c] - mean) * rstd, g[c], b_[c]);
             if (out_s && valid) out_s[(size_t)(row0 + r) * 256 + c] = ys[k];
         }
         __syncthreads();
@@ -830,7 +830,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
         for (int c = 256 + V + 8 + sub; c < 320; c += LPR) { XH[r * FM_LDP + c] = 0; XL[r * FM_LDP + c] = 0; }      // K padding of the [s | sh] layout
     } else {
     for (int c = sub; c < 256; c += LPR) {
-        const float y = (X[r * FM_LDX + c] - mean) * rstd * g[c] + b_[c];
+        const float y = fm_fma((X[r * FM_LDX + c] - mean) * rstd, g[c], b_[c]);
         X[r * FM_LDX + c] = y;
         if (out_s && valid) out_s[(size_t)(row0 + r) * 256 + c] = y;
     }
@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
                 for (int j = 0; j < 4; ++j) { acc.x += q[j].x; acc.y += q[j].y; acc.z += q[j].z; acc.w += q[j].w; }
             }
             const float iz = r_iz[r];
-            acc.x *= iz; acc.y *= iz; acc.z *= iz; acc.w *= iz;
+            acc.x *= iz; acc.y *= iz; acc.z *= iz; acc.w *= iz;      // the aggregated message M / z (tapped), then the residual: two roundings, as the reference's ops
             if (a.agg_s && r < rows) *reinterpret_cast<float4*>(a.agg_s + (size_t)(row0 + r) * 256 + c4 * 4) = acc;
             *reinterpret_cast<float4*>(X + r * FM_LDX + c4 * 4) = make_float4(sv.x + acc.x, sv.y + acc.y, sv.z + acc.z, sv.w + acc.w);
         }
@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * LDX] += fm_silu(acc[i][0][r]);   // own element: ef + update
+            for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * LDX] = fm_fma(acc[i][0][r], fm_sigmoid(acc[i][0][r]), xo[(i * 16 + r) * LDX]);   // own element: ef + silu(.), one fma
     }
     __syncthreads();
     const int r = tid / LPR, sub = tid % LPR;
@@ -1209,10 +1209,10 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
         const float4 xv = *reinterpret_cast<const float4*>(X + r * LDX + c);
         const float4 g = reinterpret_cast<const float4*>(a.ln_g)[c >> 2], bb = reinterpret_cast<const float4*>(a.ln_b)[c >> 2];
         float4 o;
-        o.x = (xv.x - mean) * rstd * g.x + bb.x;
-        o.y = (xv.y - mean) * rstd * g.y + bb.y;
-        o.z = (xv.z - mean) * rstd * g.z + bb.z;
-        o.w = (xv.w - mean) * rstd * g.w + bb.w;
+        o.x = fm_fma((xv.x - mean) * rstd, g.x, bb.x);
+        o.y = fm_fma((xv.y - mean) * rstd, g.y, bb.y);
+        o.z = fm_fma((xv.z - mean) * rstd, g.z, bb.z);
+        o.w = fm_fma((xv.w - mean) * rstd, g.w, bb.w);
         fm_buf_store_f32x4(rs_ef, r * 512 + c * 4, 0, o);
     }
 }
@@ -1309,10 +1309,10 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update_sp(FmEdgeUpdArgs 
         const float4 xv = *reinterpret_cast<const float4*>(Xf + r * LDF + c);
         const float4 g = reinterpret_cast<const float4*>(a.ln_g)[c >> 2], bb = reinterpret_cast<const float4*>(a.ln_b)[c >> 2];
         float4 o;
-        o.x = (xv.x - mean) * rstd * g.x + bb.x;
-        o.y = (xv.y - mean) * rstd * g.y + bb.y;
-        o.z = (xv.z - mean) * rstd * g.z + bb.z;
-        o.w = (xv.w - mean) * rstd * g.w + bb.w;
+        o.x = fm_fma((xv.x - mean) * rstd, g.x, bb.x);
+        o.y = fm_fma((xv.y - mean) * rstd, g.y, bb.y);
+        o.z = fm_fma((xv.z - mean) * rstd, g.z, bb.z);
+        o.w = fm_fma((xv.w - mean) * rstd, g.w, bb.w);
         fm_buf_store_f32x4(rs_ef, r * 512 + c * 4, 0, o);
     }
 }
@@ -1412,6 +1412,7 @@ struct FmCtmcMod {
     const float* q; const float* u1; const float* u2;
     const int* off;                 // [B+1] first row of every molecule
     float unmask_prob, mask_prob;
+    int* sink_t;                    // trajectory sink: this step's frame of the new state tokens (rows), null = off
 };
 struct FmCtmcFusedArgs {
     FmCtmcMod mod[3];
@@ -1421,6 +1422,9 @@ struct FmCtmcFusedArgs {
     int philox; unsigned seed_lo, seed_hi; int step; const int* mol_gid;      // philox != 0: q / u1 / u2 come from fm_philox4x32, not from memory
     const float* x_raw; float* x1_out;   // x_raw != null: the network's raw endpoint positions; x1_out = x_raw - per-molecule mean
                                          // (vector_field.py:347-350, arithmetic of fm_k_remove_com) is written first and used as x1
+    // trajectory sink (ctmc_vector_field.py:235-255), null = off: this step's frames of the new positions and of the endpoint positions.  The kernel holds
+    // every value of a frame in registers when it writes the state, so the frames cost one more store each -- not five copy nodes per step
+    float* sink_x; float* sink_x1;
 };
 
 __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
@@ -1443,13 +1447,20 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
                 const float x1 = a.x_raw[i] - com[(i - n0 * 3) % 3];
                 a.x1_out[i] = x1;
                 const float vf = fm_mul_rn(a.coef, fm_sub_rn(x1, a.x_t[i]));
-                a.x_t[i] = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
+                const float xn = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
+                a.x_t[i] = xn;
+                if (a.sink_x) a.sink_x[i] = xn;
+                if (a.sink_x1) a.sink_x1[i] = x1;
             }
             return;
         }
         for (int i = n0 * 3 + tid; i < n1 * 3; i += 256) {
-            const float vf = fm_mul_rn(a.coef, fm_sub_rn(a.x1[i], a.x_t[i]));
-            a.x_t[i] = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
+            const float x1 = a.x1[i];
+            const float vf = fm_mul_rn(a.coef, fm_sub_rn(x1, a.x_t[i]));
+            const float xn = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
+            a.x_t[i] = xn;
+            if (a.sink_x) a.sink_x[i] = xn;
+            if (a.sink_x1) a.sink_x1[i] = x1;
         }
         return;
     }
@@ -1523,6 +1534,7 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
         if (will_unmask) nt = x1;
         md.xt[i] = nt;
         md.x1[i] = x1;
+        if (md.sink_t) md.sink_t[i] = nt;
     }
 }
 

@@ -427,10 +427,13 @@ def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
     cfg = presets.PRESETS[name]()
     sd = weights.synth_state_dict(cfg, 0)
     outs = {}
-    for flag in (-1, 1, 2):
-        # 2: forced on with the launch shape of a large batch (separate node / pair launches, large tiles: the 32-row instance of the fused kernel)
-        tuning = {'pair_slab': flag} if flag < 2 else {'pair_slab': 1, 'pair_mlps': -1, 'mlp_small_tiles': -1}
-        if flag == 2 and name != 'flowmol3':
+    for flag in (-1, 1, 2, 3, 4):
+        # 2: forced on with the launch shape of a large batch (separate node / pair launches, large tiles: the 32-row instance of the fused kernel);
+        # 3: the PQ instance of the edge kernel on 64-row tiles; 4: the slab inside the SHARED node + pair launch on 64-row tiles (accepted
+        # by fm_create, never executed before)
+        tuning = {'pair_slab': flag} if flag < 2 else [{'pair_slab': 1, 'pair_mlps': -1, 'mlp_small_tiles': -1}, {'pair_slab': 1, 'tile_edge': 64},
+                                                       {'pair_slab': 1, 'pair_mlps': 1, 'mlp_small_tiles': -1}][flag - 2]
+        if flag >= 2 and name != 'flowmol3':
             continue
         eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning=tuning)
         errs, out, ref = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), 0.5, prev)

@@ -85,6 +85,7 @@ def test_forward_matches_oracle(name, sizes, t, prev, tile):
 
 @pytest.mark.parametrize('tuning', [{'tile_edge': 64, 'tile_node': 64}, {'tile_edge_update': 64}, {'tile_edge': 64, 'tile_node': 64, 'tile_edge_update': 64, 'pair_slab': -1},
                                     {'pair_slab': -1}, {'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': -1, 'mlp_small_tiles': -1}, {'xcd_swizzle': -1, 'fuse_node': -1},
+                                    {'tile_edge': 64, 'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': 1, 'mlp_small_tiles': -1},      # the PQ instance on 64-row tiles, the slab in the shared 64-row SC launch
                                     {'tile_node': 4}, {'tile_node': 4, 'tile_edge': 32, 'pair_slab': 1}, {'tile_node': 8}, {'tile_node': 12}, {'tile_node': 20}, {'tile_node': 16}])
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [70, 2, 47, 130], 0.3, True), ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False), ('flowmol3', [5, 9, 12, 3, 2], 0.0, False)])
 def test_forward_matches_oracle_under_every_accepted_tuning(name, sizes, t, prev, tuning):
@@ -547,7 +548,7 @@ def test_misc_campbell_fixture_through_the_kernel(golden_dir):
 @pytest.mark.parametrize('B,mols', [
     (1024, (0, 127, 128, 600, 1023)),
     # BASELINE configs[3]'s WHOLE job bound on one GPU (VERDICT r3 #1a): 8192 molecules = 385,024 nodes, 17.7 M directed edges, ef = 9.07 GB
-    # (13.3 GB workspace) -- the first oracle comparison past 4 GiB of edge state: the far end of the batch (molecule 8191's ef rows start
+    # (31.5 GB workspace: 13.3 GB + the two pair-slab tables this batch size switches on) -- the first oracle comparison past 4 GiB of edge state: the far end of the batch (molecule 8191's ef rows start
     # 9.06 GB into the buffer), both sides of the middle (4095 | 4096), an XCD tile-chunk boundary (553,472 tiles / 8 = 1024 molecules) and
     # the first molecule whose ef rows lie beyond 2^32 bytes (3880).
     (8192, (0, 1023, 1024, 3879, 3880, 4095, 4096, 8191)),
@@ -618,7 +619,7 @@ def test_full_size_forward_matches_oracle_on_selected_molecules(B, mols):
     _report('c3_size_forward' if B == 1024 else f'c4_whole_job_forward[{B}x{n}]', {**worst, 'ef_bytes': E * 512, 'workspace_bytes': eng.workspace_bytes})
     bad = {k: v for k, v in worst.items() if not (v < (OUT_TOL if k.startswith('out.') else STAGE_TOL))}
     assert not bad, worst
-    if B == 8192:       # release the 13 GB of taps (the cached engine keeps its 13 GB workspace for the next 8192-molecule test)
+    if B == 8192:       # release the 13 GB of taps (the cached engine keeps its 31.5 GB workspace for the next 8192-molecule test)
         del bufs, out, state
         torch.cuda.empty_cache()
 
