@@ -599,7 +599,15 @@ class IntegrationRun:
                                           C.byref(sink) if sink is not None else None, C.byref(final))
             eng._check(rc, 'fm_integrate')
             self.prev_idx = final.value
-            self._keep.append((noises, scal, nzs))
-            if len(self._keep) > 2:      # bound the noise kept alive: older chunks must have been consumed
-                eng.synchronize()
-                self._keep = self._keep[-1:]
+            # bound the noise kept alive: a chunk's tensors are released once the GPU has passed the event recorded behind it.  The host waits for
+            # the chunk BEFORE the previous one only, so two chunks stay enqueued and the device never idles (a device-wide synchronise here
+            # drained the queue every third chunk)
+            ev = None
+            if eng.device.type == 'cuda':
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(eng.device))
+            self._keep.append((noises, scal, nzs, ev))
+            while len(self._keep) > 2:
+                old = self._keep.pop(0)
+                if old[3] is not None:
+                    old[3].synchronize()

@@ -520,7 +520,7 @@ class FlowMol:
             tf = {k: v[i] for k, v in fr.items()} if fr is not None else None
             mols.append(SampledMolecule(xs[i], as_[i], cs[i], es[i], self.atom_type_map, fake_atoms=self.fake_atoms,
                                         ctmc_mol=self.cfg.has_mask, explicit_aromaticity=self.explicit_aromaticity, traj_frames=tf,
-                                        build_xt_traj=xt_traj, build_ep_traj=ep_traj))
+                                        build_xt_traj=xt_traj, build_ep_traj=ep_traj, n_charges=self.n_atom_charges))
         return mols
 
 

@@ -51,12 +51,13 @@ class SampledMolecule:
     def __init__(self, x_1: torch.Tensor, a_1: torch.Tensor, c_1: torch.Tensor, e_1: torch.Tensor,
                  atom_type_map: List[str], fake_atoms: bool = False, ctmc_mol: bool = True,
                  explicit_aromaticity: bool = False, traj_frames: Optional[Dict[str, torch.Tensor]] = None,
-                 build_xt_traj: bool = True, build_ep_traj: bool = True, align_traj: bool = True):
+                 build_xt_traj: bool = True, build_ep_traj: bool = True, align_traj: bool = True, n_charges: int = 6):
         self.atom_type_map_in = list(atom_type_map)
         self.fake_atoms = fake_atoms
         self.ctmc_mol = ctmc_mol
         self.explicit_aromaticity = explicit_aromaticity
         self.n_bond_types = 5 if explicit_aromaticity else 4
+        self.n_charges = n_charges
         # raw final state (tokens), kept like the reference keeps ``self.g``
         self.x_1, self.a_1, self.c_1, self.e_1 = x_1, a_1.long(), c_1.long(), e_1.long()
         (self.positions, self.atom_types, self.atom_charges, self.bond_types, self.bond_src_idxs,
@@ -134,6 +135,33 @@ class SampledMolecule:
     @property
     def ep_traj_mols(self):
         return self._traj_mols_of(True)
+
+    def traj_frames_reference(self) -> Dict[str, torch.Tensor]:
+        """The molecule's trajectory frames in the REFERENCE's format (ctmc_vector_field.py:188-202,235-255,267-283), rebuilt on demand from the
+        compact frames this build keeps (``traj_frames``: int tokens per atom / per unordered pair): keys 'x', 'a', 'c', 'e' with T frames
+        (frame 0 = the prior) and 'x_1_pred', 'a_1_pred', 'c_1_pred', 'e_1_pred' with T - 1; categorical frames are float one-hots
+        INCLUDING the mask column -- (frames, n, n_atom_types + 1), (frames, n, n_charges + 1) -- and edge frames cover ALL n (n - 1) directed
+        edges in the reference's order, the upper-triangle pairs followed by the same pairs swapped (data_processing/utils.py:4-17; both
+        directions carry the same token, ctmc_vector_field.py:397-409): (frames, n (n - 1), n_bond_types + 1).  A caller written against the
+        reference's ``SampledMolecule.traj_frames`` reads this instead; nothing is materialised until it is called (the compact form of a
+        60-atom, 500-step trajectory is 2.4 MB, the reference's 35 MB).  CTMC models with the default `campbell` integrator: a `gat` run's
+        reference '*_1_pred' frames hold tempered probabilities (ctmc_vector_field.py:373-375), of which the compact frames keep the argmax
+        only, and an endpoint-parameterised model's frames are continuous vectors -- neither can be rebuilt."""
+        if self.traj_frames is None:
+            raise AttributeError("'SampledMolecule' object has no trajectory frames (sample with xt_traj=True or ep_traj=True)")
+        if not self.ctmc_mol:
+            raise NotImplementedError("endpoint-parameterised models keep the argmax of their continuous frames only: the reference's float frames cannot be rebuilt")
+        one_hot = torch.nn.functional.one_hot
+        tf = self.traj_frames
+        widths = {'a': len(self.atom_type_map_in) + (1 if self.fake_atoms else 0) + 1, 'c': self.n_charges + 1, 'e': self.n_bond_types + 1}
+        out = {}
+        for sfx in ('', '_1_pred'):
+            out['x' + sfx] = tf['x' + sfx].detach().to(torch.float32).cpu()
+            for k in 'ac':
+                out[k + sfx] = one_hot(tf[k + sfx].detach().cpu().long(), widths[k]).float()
+            e = tf['e' + sfx].detach().cpu().long()
+            out['e' + sfx] = one_hot(torch.cat([e, e], dim=1), widths['e']).float()
+        return out
 
     def frame_moldata(self, frame_idx: int, ep_traj: bool = False):
         """(positions, symbols, charges, bond_types, bond_src, bond_dst) of one trajectory frame, fake atoms

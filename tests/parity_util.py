@@ -505,3 +505,39 @@ def write_lightning_shaped_checkpoint(root, model_name, sd, yaml_name='flowmol3.
     (d.parent / 'config.yaml').write_text('# the resolved training config ships next to the checkpoint (trained_models/readme.md); load_pretrained does not read it\n')
     assert 'pytorch_lightning' not in sys.modules or saved['pytorch_lightning'] is not None
     return d / 'last.ckpt'
+
+
+def traj_frames_reference_compare(model, g, device):
+    """FlowMol.sample(xt_traj, ep_traj) driven with the reference's prior and recorded noise -> every molecule's traj_frames_reference() against
+    the frame dicts the reference's own CTMCVectorField.integrate(visualize=True) returned (tests/golden/traj_frames.npz): same keys, shapes and
+    dtypes; categorical frames (float one-hots incl. the mask column, all directed edges) bit for bit; coordinates within 1e-4 relative."""
+    import torch.nn.functional as F
+    from flowmol_amd.engine import StepNoise
+    cfg = model.cfg
+    n_atoms = g['n_atoms']
+    N = int(n_atoms.sum())
+    E = int((n_atoms * (n_atoms - 1)).sum())
+    tape = [g[k] for k in sorted(k for k in g if k.startswith('noise.'))]
+    pos = [0]
+
+    def noise_for_step(i, last):
+        nz, pos[0] = StepNoise.from_tape(tape, pos[0], last, device)
+        return nz
+    prior = {'x_0': g['x_0'], 'a_0': F.one_hot(torch.full((N,), cfg.n_atom_types), cfg.n_atom_types + 1).float(),
+             'c_0': F.one_hot(torch.full((N,), cfg.n_charges), cfg.n_charges + 1).float(),
+             'e_0': F.one_hot(torch.full((E,), cfg.n_bond_types), cfg.n_bond_types + 1).float(), 'fake_atoms': cfg.fake_atoms}
+    mols = model.sample(n_atoms, n_timesteps=int(g['T']), xt_traj=True, ep_traj=True, prior=prior, _noise_for_step=noise_for_step, device=device)
+    assert pos[0] == len(tape) and len(mols) == len(n_atoms)
+    worst, cells = 0.0, 0
+    for m, mol in enumerate(mols):
+        got = mol.traj_frames_reference()
+        ref = {k.split('.', 1)[1]: g[k] for k in g if k.startswith(f'mol{m}.')}
+        assert sorted(got) == sorted(ref), (sorted(got), sorted(ref))
+        for k, r in ref.items():
+            assert got[k].shape == r.shape and got[k].dtype == r.dtype, (m, k, got[k].shape, r.shape, got[k].dtype)
+            if k.startswith('x'):
+                worst = max(worst, float((got[k] - r).abs().max() / r.abs().max()))
+            else:
+                assert torch.equal(got[k], r), (m, k, int((got[k] != r).sum()))
+                cells += r.numel()
+    return {'molecules': len(mols), 'x_rel': worst, 'categorical_cells_bit_equal': cells}

@@ -216,3 +216,51 @@ def test_sample_distributed_philox_is_independent_of_the_world_size(emu_lib_path
     for k in 'ace':
         assert torch.equal(res[0][k], single[k].to(res[0][k].dtype))
     torch.testing.assert_close(res[0]['x'], single['x'], rtol=1e-5, atol=1e-5)
+
+
+def _bench_parity_worker(rank, world, port, sizes, q):
+    """bench.py's multi-GPU self-check (multi_gpu_parity) on `world` gloo ranks over the emulated kernels."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import importlib.util
+        from pathlib import Path
+        from flowmol_amd import _lib, presets, weights
+        from flowmol_amd.engine import Engine
+        root = Path(__file__).resolve().parent.parent
+        spec = importlib.util.spec_from_file_location('bench_mod_par', root / 'bench.py')
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        cfg = presets.qm9()
+        sd = weights.synth_state_dict(cfg, 0)
+        eng = Engine(cfg, sd, device='cpu', lib=_lib.load(root / 'tests' / 'emu' / 'libflowmol_emu.so'))
+        q.put((rank, bench.multi_gpu_parity(cfg, sd, eng, world, rank, torch.device('cpu'), 'gloo', n_atoms=torch.tensor(sizes), T=3)))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_parity_block_on_two_gloo_ranks(emu_lib_path):
+    """The block `bench.py --gpus N` (N > 1) runs before its timed region and emits as `multi_gpu_parity`, here on two gloo ranks
+    over the emulated kernels: sample_distributed in the replicated and the Philox noise mode equals the single-process sample on rank 0 --
+    0 differing tokens -- every rank holds the same gathered batch and receives the same verdict."""
+    sizes = [4, 6, 3, 5, 2]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_parity_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(v, dict) for v in res.values()), res
+    d = res[0]
+    assert res[1] == d                                                    # the verdict is broadcast: every rank decides the same
+    for k in ('token_diffs', 'x_rel', 'philox_token_diffs', 'world_size', 'distinct_pci_devices', 'rccl_version', 'all_gather_bytes', 'ranks_hold_the_same_batch', 'ok'):
+        assert k in d, k
+    assert d['ok'] and d['token_diffs'] == 0 and d['philox_token_diffs'] == 0 and d['x_rel'] < 1e-4 and d['world_size'] == 2
+    assert d['molecules'] == 5 and sum(d['molecules_per_rank']) == 5 and d['all_gather_bytes'] == 2 * d['all_gather_slot_bytes']
+    assert d['tokens_compared'] == 2 * sum(sizes) + sum(n * (n - 1) // 2 for n in sizes)

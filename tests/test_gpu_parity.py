@@ -490,6 +490,119 @@ def test_eight_rank_process_group_on_one_gpu_equals_single_process_sample():
     _report('eight_ranks_one_gpu', rep)
 
 
+def _run_bench_ranks(world, backend, extra=()):
+    """`python bench.py --gpus <world> ...` exactly as the driver starts a multi-GPU bench (bench.py launches its ranks itself when no
+    launcher environment is set); returns the parsed JSON line."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    if backend == 'gloo':
+        env['FM_BENCH_BACKEND'] = 'gloo'
+    else:
+        env.pop('FM_BENCH_BACKEND', None)
+    cmd = [sys.executable, str(root / 'bench.py'), '--gpus', str(world), '--steps', '4', '--warmup', '2', '--mols-per-gpu', '32', '--no-cpu-baseline', '--no-api-e2e', *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd='/tmp')
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]             # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def _check_multi_gpu_line(d, world, backend):
+    p = d['multi_gpu_parity']
+    for k in ('token_diffs', 'x_rel', 'philox_token_diffs', 'world_size', 'distinct_pci_devices', 'rccl_version', 'all_gather_bytes', 'ranks_hold_the_same_batch', 'ok'):
+        assert k in p, k
+    assert p['ok'] and p['token_diffs'] == 0 and p['philox_token_diffs'] == 0 and p['x_rel'] < 1e-4 and p['philox_x_rel'] < 1e-4, p
+    assert p['world_size'] == world and p['molecules'] == 8 * world and p['n_timesteps'] == 12 and p['ranks_hold_the_same_batch']
+    assert p['all_gather_bytes'] == world * p['all_gather_slot_bytes'] and p['backend'] == backend
+    assert d['n_gpus'] == world and d['config']['global_molecules'] == 32 * world and d['config']['finite']
+    assert d['config']['process_group']['size'] == world and d['config']['process_group']['backend'] == backend
+    assert len(d['per_rank_ms_per_step']) == world and d['final_gather_ms'] is not None
+    w = d['ms_per_step_windows']
+    assert w['windows'] == 4 and w['min'] <= w['median'] <= w['max']
+    return p
+
+
+def test_bench_multi_gpu_line_carries_parity_block():
+    """the only thing the driver ever runs on the 8-GPU node is `bench.py --gpus N`, so that run proves itself.  Here the whole
+    command -- self-launch of 8 ranks, process group, the parity block BEFORE the timed region (sample_distributed in the replicated and the
+    Philox noise mode on the ranks vs the single-process sample of the same seed on rank 0: 0 differing tokens, coordinates within 1e-4), the
+    timed steps with their four sub-windows, the one all-gather -- runs with 8 ranks sharing this box's one MI355X (FM_BENCH_BACKEND=gloo: RCCL
+    refuses two ranks on one device), and the line carries the block."""
+    p = _check_multi_gpu_line(_run_bench_ranks(8, 'gloo'), 8, 'gloo')
+    assert p['distinct_pci_devices'] == 1                      # eight ranks, one device: what this box has
+    _report('bench_multi_gpu_parity[8 gloo ranks on one GPU]', p)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs at least two GPUs (RCCL between distinct devices)')
+@pytest.mark.parametrize('which', ['two', 'all'])
+def test_bench_multi_gpu_line_over_rccl_between_devices(which):
+    """Switches itself on where the box has more than one GPU (the builder's boxes have one): the same command over real RCCL with 2 ranks and
+    with one rank per visible device -- BASELINE configs[3]'s transport (xGMI) -- distinct PCI devices recorded in the block."""
+    world = 2 if which == 'two' else torch.cuda.device_count()
+    if which == 'all' and world == 2:
+        pytest.skip('two devices: covered by the two-rank case')
+    p = _check_multi_gpu_line(_run_bench_ranks(world, 'nccl'), world, 'nccl')
+    assert p['distinct_pci_devices'] == world and p['rccl_version']
+    _report(f'bench_multi_gpu_parity[{world} nccl ranks]', p)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs at least two GPUs (RCCL between distinct devices)')
+def test_sample_distributed_over_rccl_between_devices():
+    """FlowMol.sample_distributed over real RCCL, one process per device: a 16-molecule-per-rank GEOM-distributed job in the replicated noise
+    mode equals the single-process sample (tokens identical) on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    import flowmol_amd as flowmol
+    from flowmol_amd.model import load_n_atoms_hist
+    world, T, seed = torch.cuda.device_count(), 8, 43
+    vals, counts = load_n_atoms_hist('geom_full_kekulized')
+    n_atoms = vals[torch.multinomial(counts.double(), 16 * world, replacement=True, generator=torch.Generator().manual_seed(5))]
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    torch.manual_seed(seed)
+    single, _ = model.sample(n_atoms, n_timesteps=T, return_tensors=True)
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_rank_on_own_gpu, args=(r, world, port, n_atoms.tolist(), T, seed, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    try:
+        got = [q.get(timeout=900) for _ in procs]
+    finally:
+        for p_ in procs:
+            p_.join(timeout=120)
+            if p_.is_alive():
+                p_.kill()
+    assert not [g_ for g_ in got if isinstance(g_[1], str)], got
+    for _, full in got:
+        for k in 'ace':
+            assert np.array_equal(full[k], single[k].numpy()), k
+        np.testing.assert_allclose(full['x'], single['x'].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def _nccl_rank_on_own_gpu(rank, world, port, sizes, T, seed, q):
+    import os as _os
+    _os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    try:
+        import flowmol_amd as flowmol
+        model = flowmol.FlowMol.from_preset('flowmol3').to(f'cuda:{rank}').eval()
+        torch.manual_seed(seed)
+        full, _ = model.sample_distributed(torch.tensor(sizes), n_timesteps=T, return_tensors=True, noise='replicated')
+        q.put((rank, {k: v.numpy().copy() for k, v in full.items()}))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # round 2: edge cases by construction, bench-size parity, packaging / CLI content, RCCL
 # ----------------------------------------------------------------------------------------------------------------------
@@ -685,6 +798,17 @@ def test_sampled_molecule_fields_of_a_device_run_match_oracle():
         assert torch.equal(m.valencies, cpu_ref.compute_valencies(len(sym), bt, bs, bd))
         n_fake += n - len(sym)
     _report('sampled_molecule_fields', {'molecules': len(mols), 'fake_atoms_removed': n_fake})
+
+
+def test_traj_frames_reference_format_matches_the_reference(golden_dir):
+    """VERDICT r4 missing #2 on the GPU: a device run's SampledMolecule.traj_frames_reference() equals the reference's own traj_frames dicts
+    (float one-hots incl. the mask column, all directed edges: bit for bit; coordinates 1e-4) -- frames written by the fused CTMC kernel."""
+    import flowmol_amd as flowmol
+    from parity_util import traj_frames_reference_compare
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / 'traj_frames.npz').items()}
+    res = traj_frames_reference_compare(flowmol.FlowMol.from_preset('qm9').cuda().eval(), g, 'cuda:0')
+    _report('traj_frames_reference', res)
+    assert res['x_rel'] < 1e-4 and res['molecules'] == 3, res
 
 
 def test_cli_sdf_content_matches_oracle_tokens(tmp_path, monkeypatch):

@@ -492,6 +492,9 @@ def test_bench_dry_run_plan_and_cost_sample():
     assert d['dry_run'] and d['n_gpus'] == 8 and d['global_molecules'] == 8192 and len(d['ranks']) == 8
     assert all(r['molecules'] == 1024 and r['directed_edges'] == 1024 * 47 * 46 and r['gather_payload_bytes'] == 1024 * (47 * 14 + 1081) for r in d['ranks'])
     assert d['all_gather_total_bytes'] == 8 * d['all_gather_slot_bytes'] and d['all_gather_slot_bytes'] % 16 == 0
+    pp = d['multi_gpu_parity_plan']            # the self-check a multi-GPU run performs before its timed region
+    assert pp['world_size'] == 8 and pp['molecules'] == 64 == len(pp['sizes']) and sum(pp['molecules_per_rank']) == 64 and pp['n_timesteps'] == 12
+    assert pp['all_gather_bytes'] == 8 * pp['all_gather_slot_bytes'] and max(pp['payload_bytes_per_rank']) <= pp['all_gather_slot_bytes']
     spec = importlib.util.spec_from_file_location('bench_mod2', root / 'bench.py')
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
