@@ -1162,6 +1162,17 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
             }
         }
     }
+#ifdef FM_ALT_FILL
+    // dev-only (-DFM_ALT_FILL): round 4's EARLIER arrangement of this fill (index arithmetic per pass, profiles/r04x).  Same arithmetic per element; under
+    // -ffp-contract=fast the two arrangements produced different output bits (the compiler fused fm_rbf's d - k mu in one and not in the other), with
+    // contraction off they must not -- tools/fingerprint_matrix.py compares the two builds (profiles/r05a_*)
+#pragma unroll
+    for (int k = 0; k < NEF; ++k) {
+        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = efv[k];
+        X[r * LDX + 128 + c4] = fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma);
+    }
+#else
     {   // thread -> (row fr + 16 k, float4 column c4): one address per thread, the passes are immediate offsets
         constexpr int RP = FM_THREADS / 32;
         const int fr = tid >> 5, c4 = tid & 31;
@@ -1173,6 +1184,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
             xr[k * RP * LDX] = fm_rbf(m_d[fr + k * RP], c4, a.rbf_mu_step, a.rbf_inv_sigma);      // rows past the edge list (d = 0): finite junk, dropped by the final store's range check
         }
     }
+#endif
     __syncthreads();
     float* ho = Hb + (4 * (lane >> 4)) * LDH + col;
     float* xo = X + (4 * (lane >> 4)) * LDX + col;

@@ -1,8 +1,7 @@
 """Build-container-only tooling: import the reference's OWN sampling modules from
 /root/reference with pure-torch stand-ins for the third-party packages that are not installed
 (``dgl`` 2.0.0, ``torch_scatter`` 2.1.2).  Used by ``oracle/make_golden.py`` to generate the
-golden vectors under ``tests/golden/``, by ``oracle/make_hparams_fixture.py`` and by ``tools/oracle_long_parity.py`` /
-``tools/cpu_ref_vs_oracle_timing.py`` (all of them run in the build container only: /root/reference does not exist on the GPU
+golden vectors under ``tests/golden/`` and by ``tools/cpu_ref_vs_oracle_timing.py`` (all of them run in the build container only: /root/reference does not exist on the GPU
 box; the tests compare against the committed fixtures, ``tests/test_oracle_golden.py``).  Nothing from the reference is copied; the
 stand-ins implement only the documented semantics of the handful of DGL calls on the path
 (SURVEY.md §2.2 K1,K3,K5,K10,K18): gather, segmented sum/mean, subtraction.

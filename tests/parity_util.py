@@ -351,6 +351,16 @@ def long_report(g, traj, final):
             first = int(bad[0]) if first is None else min(first, int(bad[0]))
     res['first_divergent_step'] = first
     res['state_token_diffs_all_steps'] = total
+    # molecules whose state tokens differ from the reference's at ANY step: molecules never interact, so a decision that falls the other way on a
+    # near-tie (two p~/q values, or a purity against the high-confidence threshold, equal to f32 summation order) is confined to its molecule
+    n_t = torch.tensor(sizes)
+    mol_of = {'a': torch.repeat_interleave(torch.arange(len(sizes)), n_t), 'e': torch.repeat_interleave(torch.arange(len(sizes)), n_t * (n_t - 1) // 2)}
+    mol_of['c'] = mol_of['a']
+    div = set()
+    for k in 'ace':
+        d = (traj[k].cpu().long() != g[f'traj.{k}'][1:].long()).any(dim=0)
+        div |= set(mol_of[k][d].tolist())
+    res['molecules_with_state_diffs'] = sorted(div)
     x = traj['x'].cpu()
     nrm = torch.stack([c.flatten(1).norm(dim=1) for c in torch.split(x, sizes, dim=1)], dim=1)          # (T-1, B)
     res['x_norm_rel'] = float(((nrm - g['traj.x_norm'][1:]).abs() / g['traj.x_norm'][1:]).max())
@@ -541,3 +551,140 @@ def traj_frames_reference_compare(model, g, device):
                 assert torch.equal(got[k], r), (m, k, int((got[k] != r).sum()))
                 cells += r.numel()
     return {'molecules': len(mols), 'x_rel': worst, 'categorical_cells_bit_equal': cells}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# teacher-forced run of a long fixture with an audit of every decision that differs from the reference's
+SAMPLE_TIE_TOL = 1e-4       # two candidates' (p~ / sum) / q within this relative distance: their order is decided by f32 summation order (measured flips: <= 2e-5)
+PURITY_TIE_TOL = 5e-5       # |max p~ - hc_thresh| / hc_thresh
+
+
+def integrate_long_teacher_forced(eng, cfg, g, device=None, max_steps=None):
+    """Every step of a long fixture started from the REFERENCE's token state of that step (our own coordinates and self-conditioning input run
+    free), so that every one of the fixture's categorical decisions -- sampled endpoint token and new state token of every row at every step -- is
+    compared under the reference's own preconditions instead of only up to the first divergence.  Each step's endpoint probabilities are kept;
+    audit_long_decisions() then explains every differing decision.  Returns (traj, probs): traj[k] / traj[k+'1'] (steps, rows) int32 new state /
+    sampled tokens, traj['x'|'x1']; probs[k] (steps, rows, K)."""
+    from flowmol_amd.engine import IntegrationRun, StepNoise, make_step_plan
+    device = device or eng.device
+    eng.bind(g['n_atoms'])
+    T = int(g['T'])
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature,
+                          schedule_type=cfg.schedule_type, cosine_params=cfg.cosine_params)
+    state = eng.prior_state(g['x_0'])
+    N, U = eng.N, eng.U
+    torch.manual_seed(int(g['seed_noise']))
+
+    def noise_for_step(i, last):
+        nz = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, 'cpu')
+        return StepNoise(**{k: (None if getattr(nz, k) is None else getattr(nz, k).to(device)) for k in nz.__slots__})
+    n_steps = T - 1 if max_steps is None else min(max_steps, T - 1)
+    i32 = dict(dtype=torch.int32, device=device)
+    ref = {k: g[f'traj.{k}'][:n_steps].to(device, torch.int32) for k in 'ace'}            # frame i = the state step i starts from
+    traj = {'x': torch.zeros(n_steps, N, 3, device=device), 'x1': torch.zeros(n_steps, N, 3, device=device)}
+    probs = {}
+    for k, rows, K in (('a', N, cfg.n_atom_types), ('c', N, cfg.n_charges), ('e', U, cfg.n_bond_types)):
+        traj[k] = torch.zeros(n_steps, rows, **i32)
+        traj[f'{k}1'] = torch.zeros(n_steps, rows, **i32)
+        probs[k] = torch.zeros(n_steps, rows, K, device=device)
+    run = IntegrationRun(eng, state, plan, noise_for_step, traj=traj)
+    for i in range(n_steps):
+        for k in 'ace':
+            state[f'{k}_t'].copy_(ref[k][i])
+        run.run(i, i + 1, chunk=1)
+        d = run.last_dst()
+        for k in 'ace':
+            probs[k][i].copy_(d[k])
+    eng.synchronize()
+    return traj, probs
+
+
+def audit_long_decisions(cfg, g, traj, probs):
+    """Compare the teacher-forced decisions with the reference's and explain every difference.  A sampled endpoint token may differ only where the
+    two candidates' (p~ / sum p~) / q -- OUR tempered probabilities, the shared noise -- lie within SAMPLE_TIE_TOL of each other; a new state token may
+    differ only at a row whose sampled token differs that way, or in a molecule with a masked row whose purity max p~ lies within PURITY_TIE_TOL of
+    the high-confidence threshold (ctmc_utils.py:10-18: the count h of high-confidence rows then differs by one and with it the molecule's
+    unmasking probabilities).  Returns {'decisions', 'sample_diffs', 'state_diffs', 'events': [...], 'unexplained': [...]}."""
+    from flowmol_amd.engine import StepNoise
+    sizes = g['n_atoms']
+    n_steps = int(traj['a'].shape[0])
+    N, U = int(sizes.sum()), int((sizes * (sizes - 1) // 2).sum())
+    B = int(sizes.numel())
+    mol_n = torch.repeat_interleave(torch.arange(B), sizes)
+    mol_p = torch.repeat_interleave(torch.arange(B), sizes * (sizes - 1) // 2)
+    mods = (('a', cfg.n_atom_types, mol_n), ('c', cfg.n_charges, mol_n), ('e', cfg.n_bond_types, mol_p))
+    ours = {k: v.cpu().long() for k, v in traj.items() if k not in ('x', 'x1')}
+    flagged = set()
+    for k, K, _ in mods:
+        d = (ours[k] != g[f'traj.{k}'][1:n_steps + 1].long()) | (ours[f'{k}1'] != g[f'traj.{k}1'][:n_steps].long())
+        flagged |= set(torch.nonzero(d.any(dim=1)).flatten().tolist())
+    out = {'steps': n_steps, 'decisions': n_steps * (2 * N + U), 'sample_diffs': 0, 'state_diffs': 0, 'events': [], 'unexplained': []}
+    if not flagged:
+        return out
+    temp, hc = float(cfg.cat_temperature), float(cfg.high_confidence_threshold)
+    torch.manual_seed(int(g['seed_noise']))
+    for i in range(max(flagged) + 1):              # the reference's draws again, in its order; only flagged steps are looked at
+        nz = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, i == int(g['T']) - 2, 'cpu')
+        if i not in flagged:
+            continue
+        for k, K, mol in mods:
+            p = probs[k][i].cpu()
+            pt = torch.softmax(torch.log(p) / temp, dim=-1)
+            v = (pt / pt.sum(-1, keepdim=True)) / getattr(nz, f'q_{k}')
+            s_our, s_ref = ours[f'{k}1'][i], g[f'traj.{k}1'][i].long()
+            tie_rows = {}
+            for r in torch.nonzero(s_our != s_ref).flatten().tolist():
+                a_, b_ = float(v[r, s_our[r]]), float(v[r, s_ref[r]])
+                margin = abs(a_ - b_) / max(a_, b_)
+                tie_rows[r] = margin
+                out['sample_diffs'] += 1
+                ev = {'step': i, 'modality': k, 'kind': 'sampled token', 'row': r, 'molecule': int(mol[r]), 'ours': int(s_our[r]), 'reference': int(s_ref[r]), 'margin': margin}
+                out['events'].append(ev)
+                if not margin < SAMPLE_TIE_TOL:
+                    out['unexplained'].append(ev)
+            masked = g[f'traj.{k}'][i].long() == K                      # the state the step started from (= the reference's)
+            purity = pt.max(-1).values
+            near = masked & ((purity - hc).abs() <= PURITY_TIE_TOL * hc)
+            tie_mols = set(mol[near].tolist()) if hc > 0 else set()
+            t_our, t_ref = ours[k][i], g[f'traj.{k}'][i + 1].long()
+            bad_rows = torch.nonzero(t_our != t_ref).flatten().tolist()
+            out['state_diffs'] += len(bad_rows)
+            seen = set()
+            for r in bad_rows:
+                m = int(mol[r])
+                if r in tie_rows and tie_rows[r] < SAMPLE_TIE_TOL:
+                    continue                                       # the row took its (differently) sampled token: explained by the tie above
+                if m in tie_mols:
+                    if (k, m) not in seen:
+                        seen.add((k, m))
+                        rr = [x_ for x_ in torch.nonzero(near & (mol == m)).flatten().tolist()]
+                        out['events'].append({'step': i, 'modality': k, 'kind': 'purity at the high-confidence threshold', 'molecule': m, 'rows': rr,
+                                              'purity_minus_threshold': [float(purity[x_] - hc) for x_ in rr], 'state_rows_differing': sum(1 for q_ in bad_rows if int(mol[q_]) == m)})
+                    continue
+                out['unexplained'].append({'step': i, 'modality': k, 'kind': 'state token', 'row': r, 'molecule': m, 'ours': int(t_our[r]), 'reference': int(t_ref[r])})
+    return out
+
+
+def oracle_long_fixture(cfg, sd, n_atoms, T, seed_prior, seed_noise):
+    """A fixture with the keys of tests/golden/long_*.npz, produced by the CPU ORACLE instead of the reference (tiny cases for the CPU tests of the
+    teacher-forced audit; the committed fixtures come from the reference itself, oracle/make_golden.py:gen_integrate_long)."""
+    batch = cpu_ref.build_batch(n_atoms)
+    orc = cpu_ref.OracleVF(cfg, sd)
+    torch.manual_seed(seed_prior)
+    prior = orc.sample_prior(batch)
+    m = batch.upper_edge_mask
+    rec = {k: [] for k in ('a', 'c', 'e', 'a1', 'c1', 'e1')}
+    rec['a'].append(prior['a_0'].argmax(-1)); rec['c'].append(prior['c_0'].argmax(-1)); rec['e'].append(prior['e_0'][m].argmax(-1))
+
+    def hook(s_idx, new, dst):
+        for k in 'ac':
+            rec[k].append(new[f'{k}_t'].argmax(-1)); rec[f'{k}1'].append(new[f'{k}_1_pred'].argmax(-1))
+        rec['e'].append(new['e_t'][m].argmax(-1)); rec['e1'].append(new['e_1_pred'][m].argmax(-1))
+    torch.manual_seed(seed_noise)
+    with torch.no_grad():
+        out = orc.integrate(batch, prior, T, step_hook=hook)
+    g = {'n_atoms': n_atoms, 'T': torch.tensor(T), 'weight_scale': torch.tensor(1.0), 'seed_prior': torch.tensor(seed_prior), 'seed_noise': torch.tensor(seed_noise),
+         'x_0': prior['x_0'], 'x_1': out['x_1']}
+    for k, v in rec.items():
+        g[f'traj.{k}'] = torch.stack(v).to(torch.uint8)
+    return g

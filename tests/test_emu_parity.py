@@ -482,3 +482,27 @@ def test_traj_frames_reference_format_on_emulation(emu_lib, golden_dir):
     plain = model.sample(torch.tensor([3, 2]), n_timesteps=2, device='cpu')
     with pytest.raises(AttributeError):
         plain[0].traj_frames_reference()          # no frames were kept
+
+
+def test_teacher_forced_decision_audit_on_emulation(emu_lib):
+    """tests/parity_util.py: integrate_long_teacher_forced + audit_long_decisions (the gate of the 20-M-decision fixture on the GPU) on a tiny
+    oracle-made fixture: every decision equals the oracle's (no events); a tampered reference token -- sampled or state -- is reported as an
+    UNEXPLAINED difference (its margin is nowhere near a tie), so the audit cannot wave a real disagreement through."""
+    from flowmol_amd.engine import Engine
+    from parity_util import audit_long_decisions, integrate_long_teacher_forced, oracle_long_fixture
+    cfg = presets.qm9()
+    sd = weights.synth_state_dict(cfg, 0)
+    g = oracle_long_fixture(cfg, sd, torch.tensor([3, 2, 4]), 5, 3, 4)
+    eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+    traj, probs = integrate_long_teacher_forced(eng, cfg, g, device='cpu')
+    res = audit_long_decisions(cfg, g, traj, probs)
+    assert res['sample_diffs'] == 0 and res['state_diffs'] == 0 and not res['events'] and not res['unexplained'], res
+    assert res['decisions'] == 4 * (2 * 9 + 10)
+    bad = dict(g)
+    bad['traj.a1'] = g['traj.a1'].clone()
+    bad['traj.a1'][1, 0] = (int(g['traj.a1'][1, 0]) + 1) % cfg.n_atom_types
+    bad['traj.e'] = g['traj.e'].clone()
+    bad['traj.e'][3, 2] = (int(g['traj.e'][3, 2]) + 1) % cfg.n_bond_types          # new state of step 2
+    res = audit_long_decisions(cfg, bad, traj, probs)
+    kinds = sorted(e['kind'] for e in res['unexplained'])
+    assert kinds == ['sampled token', 'state token'] and res['sample_diffs'] == 1 and res['state_diffs'] == 1, res

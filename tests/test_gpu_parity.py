@@ -121,7 +121,7 @@ def test_integrate_matches_reference_golden(golden_dir, fname, name):
 
 
 @pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
-                                      ('flowmol3_geom64_T250', 'flowmol3')])
+                                      ('flowmol3_geom64_T250', 'flowmol3'), ('flowmol3_geom16_T250_pos128', 'flowmol3')])
 def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
     """The product's DEFAULT protocol against the reference itself: free-running trajectories of the reference's own
     CTMCVectorField.integrate at n_timesteps = 250 (test.py:25, flowmol.py:46; 8 x 47 atoms, and a 5/33/60/90-atom batch with all weight
@@ -133,25 +133,30 @@ def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
     from parity_util import integrate_long_golden
     g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / f'long_{tag}.npz').items()}
     cfg = presets.PRESETS[name]()
-    scale = float(g['weight_scale'])
+    scale = float(g['weight_scale']) * (float(g['pos_head_scale']) if 'pos_head_scale' in g else 1.0)
     if scale == 1:
         eng = engine_for(name)[2]
     else:
-        eng = Engine(cfg, weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale), device='cuda:0', precision='f32')
+        eng = Engine(cfg, weights.long_fixture_weights(cfg, g), device='cuda:0', precision='f32')
     res = integrate_long_golden(eng, cfg, g)
     res['categorical_decisions'] = (int(g['T']) - 1) * int(2 * g['a_1'].numel() + g['e_1_upper'].numel())       # tempered argmax + unmask decisions: rows x steps
     _report(f'long[{tag}]', res)
-    # every STATE token of every step and the final tokens equal the reference's -- the trajectory is the reference's trajectory.  The sampled
-    # endpoint tokens ("*_1_pred": argmax(p~/q), only used where a position is unmasked in that step) are compared too; on the 8-molecule
-    # fixtures none differs, on the 20-M-decision fixture r4 measured ONE (a near-tie of two p~/q values decided by the summation order of the
-    # f32 logits; it was not used), so for that fixture the count is reported and bounded instead of required to be zero.
+    # Fixtures of up to ~1 M decisions: every STATE token and every sampled endpoint token of every step equals the reference's -- the trajectory
+    # is the reference's trajectory.  The 20-M-decision fixture holds a handful of decisions whose two candidates are equal to f32 summation
+    # order (measured over five builds: 0-2 sampled tokens; with contraction off one of them is USED at step 113): which way such a near-tie
+    # falls depends on the order of the f32 sums, so there the free-running gate is the final state (tokens identical, coordinates 1e-4) with
+    # the divergence CONFINED to the tie's molecule (molecules never interact), and test_teacher_forced_decisions_... audits every one of the
+    # 20.2 M decisions under the reference's own state and shows that each differing one is such a tie.
     sample_diffs = res['a1_sample_diffs'] + res['c1_sample_diffs'] + res['e1_sample_diffs']
-    assert res['state_token_diffs_all_steps'] == 0, res
+    big = res['categorical_decisions'] > 10_000_000
     assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0, res
-    assert sample_diffs <= (4 if res['categorical_decisions'] > 10_000_000 else 0), res
+    if big:
+        assert len(res['molecules_with_state_diffs']) <= 2, res
+    else:
+        assert res['state_token_diffs_all_steps'] == 0 and sample_diffs == 0, res
     assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4 and res['x_norm_rel'] < 1e-4 and res['x1_norm_rel'] < 1e-4, res
     if scale > 1:
-        assert res['mean_rel_move'] > 0.02, res
+        assert res['mean_rel_move'] > 0.02, res          # all weights x2 / the position heads x128: the coordinates really depend on the network's arithmetic
 
 
 def test_long_horizon_64_molecules_with_the_pair_slab_forced(golden_dir):
@@ -167,10 +172,35 @@ def test_long_horizon_64_molecules_with_the_pair_slab_forced(golden_dir):
     res = integrate_long_golden(eng, cfg, g)
     res['categorical_decisions'] = (int(g['T']) - 1) * int(2 * g['a_1'].numel() + g['e_1_upper'].numel())
     _report('long[flowmol3_geom64_T250, pair_slab=1]', res)
-    assert res['state_token_diffs_all_steps'] == 0 and res['a_flips'] == res['c_flips'] == res['e_flips'] == 0, res
-    assert res['a1_sample_diffs'] + res['c1_sample_diffs'] + res['e1_sample_diffs'] <= 4, res
+    assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and len(res['molecules_with_state_diffs']) <= 2, res
     assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4 and res['x_norm_rel'] < 1e-4, res
     eng.close()
+
+
+@pytest.mark.parametrize('tag,tuning', [('flowmol3_geom64_T250', {}), ('flowmol3_geom64_T250', {'pair_slab': 1}), ('flowmol3_geom16_T250_pos128', {})])
+def test_teacher_forced_decisions_differ_from_the_reference_only_at_near_ties(golden_dir, tag, tuning):
+    """"Bit-exact categorical indices" made checkable over 20.2 M decisions: every step is started from the REFERENCE's token
+    state (coordinates and self-conditioning input run free), so each of the fixture's decisions -- sampled endpoint token and new state token of
+    every row at every step -- is compared under the reference's own preconditions, not only up to the first divergence.  Every differing decision
+    must be EXPLAINED (tests/parity_util.py:audit_long_decisions): a sampled token whose two candidates' (p~ / sum) / q lie within 1e-4 of each
+    other, or a molecule with a masked row whose purity lies within 5e-5 of the high-confidence threshold (the count h moves by one and with it
+    the molecule's unmasking probabilities) -- decisions that f32 summation order decides; anything else fails.  The events are recorded
+    (which step, row, candidates, margin): the measured constant of this library instead of a loose bound."""
+    from flowmol_amd.engine import Engine
+    from parity_util import audit_long_decisions, integrate_long_teacher_forced
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / f'long_{tag}.npz').items()}
+    cfg = presets.flowmol3()
+    eng = Engine(cfg, weights.long_fixture_weights(cfg, g), device='cuda:0', precision='f32', tuning=tuning)
+    traj, probs = integrate_long_teacher_forced(eng, cfg, g)
+    res = audit_long_decisions(cfg, g, traj, probs)
+    _report(f'teacher_forced_audit[{tag},{tuning}]', {k: v for k, v in res.items()})
+    assert not res['unexplained'], res['unexplained'][:5]
+    assert len(res['events']) <= 8, res['events']
+    x = traj['x'][-1].cpu()
+    assert float((x - g['x_1']).abs().max() / g['x_1'].abs().max()) < 1e-4
+    eng.close()
+    del traj, probs
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('fname,dfm_type', [('integrate_qm9_gat.npz', 'gat'), ('integrate_qm9_sched.npz', 'campbell')])
@@ -1311,7 +1341,7 @@ def test_full_batch_reproduces_reference_long_trajectory(golden_dir, B, slots, n
 
 
 @pytest.mark.parametrize('tag,name', [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
-                                      ('flowmol3_geom64_T250', 'flowmol3')])
+                                      ('flowmol3_geom64_T250', 'flowmol3'), ('flowmol3_geom16_T250_pos128', 'flowmol3')])
 def test_split_precision_long_horizon_flip_counts(golden_dir, tag, name):
     """The OPT-IN split precision on the reference's default-protocol trajectories: it is not f32 arithmetic, so token differences against the
     reference are COUNTED and reported (first divergent step, differing state tokens), not required to be zero; the run must stay finite, resolve
@@ -1320,8 +1350,8 @@ def test_split_precision_long_horizon_flip_counts(golden_dir, tag, name):
     from parity_util import integrate_long_golden
     g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / f'long_{tag}.npz').items()}
     cfg = presets.PRESETS[name]()
-    scale = float(g['weight_scale'])
-    eng = sp_engine_for(name)[2] if scale == 1 else Engine(cfg, weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale), device='cuda:0', precision='bf16x3')
+    scale = float(g['weight_scale']) * (float(g['pos_head_scale']) if 'pos_head_scale' in g else 1.0)
+    eng = sp_engine_for(name)[2] if scale == 1 else Engine(cfg, weights.long_fixture_weights(cfg, g), device='cuda:0', precision='bf16x3')
     res = integrate_long_golden(eng, cfg, g)
     res['categorical_decisions'] = (int(g['T']) - 1) * int(2 * g['a_1'].numel() + g['e_1_upper'].numel())
     _report(f'split_precision_long[{tag}]', res)

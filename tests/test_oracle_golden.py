@@ -293,7 +293,8 @@ def test_endpoint_parameterization_matches_reference(golden_dir):
 
 
 LONG = [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
-        ('flowmol3_geom64_T250', 'flowmol3')]       # 64 GEOM-sized molecules (r4): 3 steps here (1.3 s of oracle per evaluation)
+        ('flowmol3_geom64_T250', 'flowmol3'),       # 64 GEOM-sized molecules (r4): 3 steps here (1.3 s of oracle per evaluation)
+        ('flowmol3_geom16_T250_pos128', 'flowmol3')]       # 16 GEOM-sized molecules, position heads x128 (r5): the coordinates move 4.6 % per evaluation
 
 
 @pytest.mark.parametrize('tag,name', LONG)
@@ -306,15 +307,15 @@ def test_long_horizon_reference_trajectory_first_steps(golden_dir, tag, name):
     from parity_util import oracle_long_golden
     g = _load(golden_dir, f'long_{tag}.npz')
     cfg = presets.PRESETS[name]()
-    sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), float(g['weight_scale']))
+    sd = weights.long_fixture_weights(cfg, g)
     full = os.environ.get('FM_LONG_ORACLE') == '1'
     res = oracle_long_golden(cpu_ref.OracleVF(cfg, sd), cfg, g, max_steps=None if full else (3 if int(g['n_atoms'].numel()) > 16 else 12))
     assert res['first_divergent_step'] is None and res['state_token_diffs_all_steps'] == 0, res
     assert res['x_norm_rel'] < 1e-5 and res['x1_norm_rel'] < 1e-5 and res['x_frames_rel'] < 1e-5, res
     if full:
         assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and res['x_rel'] < 1e-4, res
-    if float(g['weight_scale']) > 1:
-        assert res['mean_rel_move'] > 0.02, res            # the x2 weights really make the coordinates depend on the network
+    if float(g['weight_scale']) > 1 or 'pos_head_scale' in g:
+        assert res['mean_rel_move'] > 0.02, res            # the scaled weights really make the coordinates depend on the network
 
 
 def test_long_fixture_noise_is_the_seeded_redraw(golden_dir):

@@ -44,7 +44,8 @@ run_step() {
              timeout 700 rocprofv3 --kernel-trace --pmc $ctr -d $D/$x -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-api-e2e --no-secondary > $D/$x.log 2>&1
              db=$(find $D/$x -name '*_results.db' | tail -1); [ -n "$db" ] && python $R/tools/summarize_rocprof.py pmc $db fm_k_ > $D/$x.txt 2>&1
              find $D/$x -name '*_results.db' -delete; head -40 $D/$x.txt ;;
-    py)      timeout 900 python "$@" 2>&1 | tee -a $O/${TAG}_py.log | tail -40 ;;
+    py)      local sc=$1; shift; [ -f "$R/$sc" ] && sc="$R/$sc"          # the steps run from /tmp: a path relative to the repository root is resolved here
+             timeout 900 python "$sc" "$@" 2>&1 | tee -a $O/${TAG}_py.log | tail -40 ;;
     *)       echo "unknown step $s"; return 2 ;;
   esac
 }

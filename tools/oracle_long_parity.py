@@ -21,7 +21,7 @@ for tag in (sys.argv[1:] or LONG_CASES):
     name = LONG_CASES[tag][0]
     g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(ROOT / 'tests' / 'golden' / f'long_{tag}.npz').items()}
     cfg = presets.PRESETS[name]()
-    sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), float(g['weight_scale']))
+    sd = weights.long_fixture_weights(cfg, g)
     t0 = time.time()
     res = oracle_long_golden(cpu_ref.OracleVF(cfg, sd), cfg, g)
     print(json.dumps({'fixture': f'long_{tag}.npz', 'impl': 'oracle/cpu_ref.py (CPU, f32)', **res, 'seconds': round(time.time() - t0, 1)}), flush=True)
