@@ -321,6 +321,60 @@ __device__ __forceinline__ void fm_wave_gemm4(f32x4 (&acc)[RG], const float* X, 
     for (int rg = 0; rg < RG; ++rg) acc[rg] += acc1[rg];
 }
 
+// The same 4-row product for the node-side MLP kernels of small batches (fm_k_mlp4): quad steps [kq0, kq0 + NQ) with a run-time, wave-uniform kq0 (each of
+// the eight waves takes its own K slice), and G column groups of 64 in the packing -- Wq4[(kq * G + g) * 64 + lane] = W[4kq .. 4kq+3][64g + lane] -- so that a
+// narrow second layer (N = 64: G = 1) splits its K over all eight waves.  Up to eight 1-KB fragment loads in flight per wave, fully unrolled.
+template <int NQ, int G>
+__device__ __forceinline__ f32x4 fm_wave_gemm4_at(const float* X, int ldx, const void* Wq4, int kq0, int g, int lane) {
+    constexpr int PD = NQ < 8 ? NQ : 8, PA = 2;
+    const float* ap = X + (lane & 3) * ldx + 4 * kq0;
+    const auto rs = fm_buf(Wq4);
+    const int s0 = (kq0 * G + g) * 1024;             // wave-uniform byte offset of the first fragment; consecutive quad steps are G KB apart
+    f32x4 a[PA];
+    float4 b[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * G * 1024);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) if (q < NQ) a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * q);
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const float4 bv = b[k % PD];
+        const f32x4 av = a[k % PA];
+        if (k + PD < NQ) b[k % PD] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * G * 1024);
+        if (k + PA < NQ) a[k % PA] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * (k + PA));
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv.w, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc0 + acc1;
+}
+
+// out[4][64 G] = X[4][4 KQ] * W for a 512-thread workgroup: wave w takes column group w % G and K slice w / G (8 / G slices); the slices meet in the
+// exchange tile S [8 / G][4][64 G] and epi(row, column, sum) is called once per output element.  Ends with a barrier (S and whatever epi wrote are settled).
+template <int KQ, int G, class Epi>
+__device__ __forceinline__ void fm_rows4_linear(const float* X, int ldx, const void* Wq4, float* S, Epi epi) {
+    constexpr int KS = 8 / G, NQ = KQ / KS, W = 64 * G;
+    static_assert(KQ % KS == 0 && (G == 1 || G == 2 || G == 4), "K quads must split evenly over the wave slices");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave % G, slice = wave / G;
+    const f32x4 acc = fm_wave_gemm4_at<NQ, G>(X, ldx, Wq4, slice * NQ, g, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(slice * 4 + r) * W + 64 * g + lane] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 4 * W; idx += FM_THREADS) {
+        const int r = idx / W, c = idx % W;
+        float v = S[r * W + c];
+#pragma unroll
+        for (int sl = 1; sl < KS; ++sl) v += S[(sl * 4 + r) * W + c];
+        epi(r, c, v);
+    }
+    __syncthreads();
+}
+
 // Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
 // are requested before the MFMAs of chunk c.  A 1x1 tile has only 2 MFMAs (64 cycles) per k-superstep, far less
 // than the L2 latency of its B fragment, so the one-step pipelining of fm_wave_gemm leaves it latency-bound

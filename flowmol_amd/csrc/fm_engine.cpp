@@ -64,6 +64,8 @@ struct fm_ctx {
     int n_cus = 256;
     int pair_mlps_forced = -1;      // fm_config.pair_mlps
     int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
+    int mlp4_forced = -1;           // fm_config.mlp_small_tiles = 2: the node-side MLPs on 4-row tiles (fm_k_mlp4) whatever the batch; 1 / -1: never
+    const void *sc_node_W1q = nullptr, *sc_node_W2q = nullptr, *node_head_W1q = nullptr, *node_head_W2q = nullptr;      // quad-row packed copies for fm_k_mlp4
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
     int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (self-conditioned models; fm_config.pair_slab = -1: 0)
     int node_rg = 0;          // this batch runs the node kernel on tiles of 4 * node_rg nodes (RG instances; 1, 2, 3 in the 16-row frame, 5 in the 32-row
@@ -175,13 +177,13 @@ std::vector<float> pack(int K, int N, const std::function<float(int, int)>& w) {
 
 // quad-row packing for fm_wave_gemm4 (4-row tiles on v_mfma_f32_4x4x1_16B_f32): W_logical[k][n] (K x 256, K%4==0); entry (kq, g, lane) = the four
 // weights W[4kq .. 4kq+3][64g + lane] -- one 1-KB buffer_load_dwordx4 per quad step and wave
-std::vector<float> pack4(int K, const std::function<float(int, int)>& w) {
+std::vector<float> pack4(int K, const std::function<float(int, int)>& w, int G = 4) {      // G column groups of 64: N = 64 G
     const int KQ = K / 4;
-    std::vector<float> out((size_t)KQ * 4 * 64 * 4);
+    std::vector<float> out((size_t)KQ * G * 64 * 4);
     for (int kq = 0; kq < KQ; ++kq)
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < G; ++g)
             for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 4; ++i) out[(((size_t)kq * 4 + g) * 64 + lane) * 4 + i] = w(4 * kq + i, 64 * g + lane);
+                for (int i = 0; i < 4; ++i) out[(((size_t)kq * G + g) * 64 + lane) * 4 + i] = w(4 * kq + i, 64 * g + lane);
     return out;
 }
 
@@ -238,12 +240,12 @@ void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int 
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
     }));
 }
-void pack_linear4(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, const std::function<int(int)>& kmap) {
+void pack_linear4(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, const std::function<int(int)>& kmap, int G = 4) {
     B.putv(slot, pack4(Kp, [&](int k, int n) -> float {
         if (n >= out) return 0.f;
         const int kk = kmap(k);
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
-    }));
+    }, G));
 }
 void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
     std::vector<float> t(np, 0.f);
@@ -401,6 +403,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const bool small_node = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (N + 15) / 16 <= 4 * c->n_cus;      // decided per side: the node side
     const bool small_pair = c->small_mlp_forced >= 0 ? c->small_mlp_forced != 0 : (U + 15) / 16 <= 4 * c->n_cus;      // stays small ~25x longer than the pair side
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
+    // node-side MLPs on 4-row tiles (fm_k_mlp4) while such tiles fit one per CU: a 16-row tile's two 256-wide layers are ~7 us of matrix time on one CU
+    // whatever the batch, four rows on v_mfma_f32_4x4x1 are the layers' weight stream; fm_config.mlp_small_tiles = 2 forces it (1 / -1: never)
+    const bool mlp4 = c->node_head_W1q && !dense && (c->mlp4_forced >= 0 ? c->mlp4_forced != 0 : (N + 3) / 4 <= c->n_cus);
+    const int tiles4 = (N + 3) / 4;
     // pair-slab convolutions of this evaluation (first pass only; FmMlpArgs::slabQ0): self-conditioned evaluations with at least four rounds of
     // 32-row pair tiles (measured neutral on small batches: the table costs a kernel phase, the saving is matrix-pipe time they are not bound by)
     const int n_pq = (HX == 0 && prev && !dense) ? pq_convs(c, U) : 0;
@@ -438,9 +444,21 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             e.slabW0 = c->conv[0].Ws_slab; e.slabQ0 = c->Q[0];
             if (n_pq > 1) { e.slabW1 = c->conv[1].Ws_slab; e.slabQ1 = c->Q[1]; }
         }
+        FmMlp4Args a4{};
+        a4.N = N; a4.W1q = c->sc_node_W1q; a4.b1 = c->sc_node.b1; a4.W2q = c->sc_node_W2q; a4.b2 = c->sc_node.b2;
+        a4.s_tab = a.s_tab; a4.tok_a = a.tok_a; a4.tok_c = a.tok_c; a4.n_c1 = nc1; a4.prev_a = a.prev_a; a4.prev_c = a.prev_c; a4.prev_x = a.prev_x; a4.x_t = a.x_t;
+        a4.na = c->na; a4.nc = c->nc; a4.rbf_mu_step = c->rbf_mu_step; a4.rbf_inv_sigma = c->rbf_inv_sigma; a4.out = c->s;
         // one row per unordered pair, written to both directed edges; node and pair tiles share one launch
-        if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U, small_mlp);
-        else { launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N, small_node); launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U, small_pair); }
+        if (pair_mlps && mlp4 && small_mlp && c->sc_node_W1q) {
+            fill_mlp(e, c->sc_edge, U);
+            const int tb = (U + 15) / 16;
+            L("sc", fm_k_mlp4_pair<FM_MLP4_SC_NODE, FM_MLP_SC_EDGE>, dim3(tiles4 + tb), dim3(FM_THREADS), std::max((size_t)FM_MLP4_LDS_BYTES, lds_mlp(e.ldx, e.ldh, 16)), a4, e, tiles4);
+        } else if (pair_mlps) launch_mlp_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>(L, "sc", a, c->sc_node, N, e, c->sc_edge, U, small_mlp);
+        else {
+            if (mlp4 && c->sc_node_W1q) L("sc_node", fm_k_mlp4<FM_MLP4_SC_NODE>, dim3(tiles4), dim3(FM_THREADS), (size_t)FM_MLP4_LDS_BYTES, a4);
+            else launch_mlp<FM_MLP_SC_NODE>(L, "sc_node", a, c->sc_node, N, small_node);
+            launch_mlp<FM_MLP_SC_EDGE>(L, "sc_edge", e, c->sc_edge, U, small_pair);
+        }
         tap("sc.s", c->s, (size_t)N * 256 * 4);
         tap("sc.ef", c->ef, (size_t)E * 128 * 4);
     } else {
@@ -465,7 +483,12 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             FmProjArgs pa{};
             pa.N = N; pa.s = c->s; pa.v = c->v; pa.Wps = cw.Wps; pa.Ps = c->Ps; pa.Wpv = cw.Wpv; pa.PV = c->PV; pa.pv_w = c->PVW;
             if (it == 0) { pa.v_init = c->v; pa.x_src = x_t; pa.x_dst = c->xw; }     // v = 0, working copy of x (no memset / memcpy nodes)
-            if (small_node) L("node_proj", fm_k_node_proj<V, 16>, dim3((N + 15) / 16), blk, lds_proj(V, 16), pa);
+            if (it == 0 && mlp4 && cw.Wps4) {
+                FmMlp4Args p4{};
+                p4.N = N; p4.in = c->s; p4.Wps4 = cw.Wps4; p4.Ps = c->Ps; p4.PV = c->PV; p4.pv_w = c->PVW; p4.v_init = c->v; p4.V = V; p4.x_src = x_t; p4.x_dst = c->xw;
+                L("node_proj", fm_k_mlp4<FM_MLP4_PROJ0>, dim3(tiles4), blk, (size_t)FM_MLP4_LDS_BYTES, p4);
+            }
+            else if (small_node) L("node_proj", fm_k_node_proj<V, 16>, dim3((N + 15) / 16), blk, lds_proj(V, 16), pa);
             else L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
         }
         FmMsgArgs m{};
@@ -574,8 +597,19 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         a.in = c->s; a.out = out->a; a.out2 = out->c;
         FmMlpArgs e = ma;
         e.ef = c->ef; e.p_e0 = b.p_e0; e.p_e1 = b.p_e1; e.out = out->e;
-        if (pair_mlps) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U, small_mlp);
-        else { launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N, small_node); launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U, small_pair); }
+        FmMlp4Args a4{};
+        a4.N = N; a4.W1q = c->node_head_W1q; a4.b1 = c->node_head.b1; a4.W2q = c->node_head_W2q; a4.b2 = c->node_head.b2;
+        a4.na = c->na; a4.nc = c->nc; a4.in = c->s; a4.out = out->a; a4.out2 = out->c;
+        if (pair_mlps && mlp4 && small_mlp) {
+            fill_mlp(e, c->edge_head, U);
+            const int tb = (U + 15) / 16;
+            L("heads", fm_k_mlp4_pair<FM_MLP4_NODE_HEAD, FM_MLP_EDGE_HEAD>, dim3(tiles4 + tb), dim3(FM_THREADS), std::max((size_t)FM_MLP4_LDS_BYTES, lds_mlp(e.ldx, e.ldh, 16)), a4, e, tiles4);
+        } else if (pair_mlps) launch_mlp_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>(L, "heads", a, c->node_head, N, e, c->edge_head, U, small_mlp);
+        else {
+            if (mlp4) L("node_head", fm_k_mlp4<FM_MLP4_NODE_HEAD>, dim3(tiles4), dim3(FM_THREADS), (size_t)FM_MLP4_LDS_BYTES, a4);
+            else launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N, small_node);
+            launch_mlp<FM_MLP_EDGE_HEAD>(L, "edge_head", e, c->edge_head, U, small_pair);
+        }
     }
     if (remove_com != 2) {       // 2: the caller's fused CTMC kernel centres the raw positions (c->xw) and writes out->x itself
         L.copy(out->x, c->xw, (size_t)N * 3 * 4);
@@ -685,7 +719,9 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
     if (frame) { f.sink_x = frame->x; f.sink_x1 = frame->x1; }
     if (sc->noise_mode == FM_NOISE_PHILOX) { f.philox = 1; f.seed_lo = sc->philox_seed_lo; f.seed_hi = sc->philox_seed_hi; f.step = sc->step_index; f.mol_gid = c->mol_gid; }
     else if (!nz->q_a || !nz->u1_a || !nz->q_e) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: noise tensors missing (noise_mode FM_NOISE_TENSORS)");
-    L("ctmc", fm_k_ctmc_fused, dim3(b.B, 4), dim3(256), 0, f);
+    // a few molecules: 1024-thread workgroups (one per molecule and modality is all the parallelism there is); else 256
+    if (b.B * 4 <= c->n_cus && c->nmax > 23) L("ctmc", fm_k_ctmc_fused<1024>, dim3(b.B, 4), dim3(1024), 0, f);
+    else L("ctmc", fm_k_ctmc_fused<256>, dim3(b.B, 4), dim3(256), 0, f);
     return L.rc;
 }
 
@@ -799,6 +835,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
         c->sc_node.K1p = pad8(kinp); c->sc_node.H = 256; c->sc_node.O = 256;
         pack_linear(B, c->sc_node.W1, W1, S, kin, pad8(kinp), 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : S + (k - 256); });
+        if (S == 256 && HX == 0 && cfg->precision == FM_PREC_F32) {      // 4-row node tiles of small batches (fm_k_mlp4): K padded to 320, quad-row packed
+            pack_linear4(B, c->sc_node_W1q, W1, S, kin, 320, [&](int k) { return k < 256 ? k : (k - 256 < na + nc + 32 ? S + (k - 256) : -1); });
+            pack_linear4(B, c->sc_node_W2q, W2, S, S, 256, ident);
+        }
         pad_vec(B, c->sc_node.b1, b1, S, 256);
         pack_linear(B, c->sc_node.W2, W2, S, S, 256, 256, ident);
         pad_vec(B, c->sc_node.b2, b2, S, 256);
@@ -948,6 +988,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         c->node_head.K1p = 256; c->node_head.H = 256; c->node_head.O = pad16(na + nc);
         pack_linear(B, c->node_head.W1, W1, S, S, 256, 256, ident); pad_vec(B, c->node_head.b1, b1, S, 256);
         pack_linear(B, c->node_head.W2, W2, na + nc, S, 256, pad16(na + nc), ident); pad_vec(B, c->node_head.b2, b2, na + nc, pad16(na + nc));
+        if (S == 256 && HX == 0 && cfg->precision == FM_PREC_F32) {
+            pack_linear4(B, c->node_head_W1q, W1, S, S, 256, ident);
+            pack_linear4(B, c->node_head_W2q, W2, na + nc, S, 256, ident, 1);      // N = 64 (na + nc <= 32 real columns): one column group, K over all eight waves
+        }
         c->edge_head.K1p = 128; c->edge_head.H = 128; c->edge_head.O = 16;
         pack_linear(B, c->edge_head.W1, E1, F, F, 128, 128, ident); pad_vec(B, c->edge_head.b1, eb1, F, 128);
         pack_linear(B, c->edge_head.W2, E2, ne, F, 128, 16, ident); pad_vec(B, c->edge_head.b2, eb2, ne, 16);
@@ -966,6 +1010,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     c->xcd_swizzle = cfg->xcd_swizzle >= 0; c->fuse_node = cfg->fuse_node >= 0;
     c->pair_mlps_forced = cfg->pair_mlps == 0 ? -1 : (cfg->pair_mlps > 0);
     c->small_mlp_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles > 0);
+    c->mlp4_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles == 2);
     // pair-slab hoist: the convolutions that run before any molecule update see pair-symmetric edge features and distances
     c->n_pq = 0;
     c->pq_forced = cfg->pair_slab > 0;
@@ -1012,6 +1057,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 32>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD, 32>, mlp_max);
     set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD>, mlp_max);
     const size_t mlp_small = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260, 16);
+    set_lds(fm_k_mlp4<FM_MLP4_SC_NODE>, FM_MLP4_LDS_BYTES); set_lds(fm_k_mlp4<FM_MLP4_NODE_HEAD>, FM_MLP4_LDS_BYTES); set_lds(fm_k_mlp4<FM_MLP4_PROJ0>, FM_MLP4_LDS_BYTES);
+    set_lds(fm_k_mlp4_pair<FM_MLP4_SC_NODE, FM_MLP_SC_EDGE>, mlp_small); set_lds(fm_k_mlp4_pair<FM_MLP4_NODE_HEAD, FM_MLP_EDGE_HEAD>, mlp_small);
     set_lds(fm_k_mlp2<FM_MLP_SC_NODE, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_TABLE, 16>, mlp_small);
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD, 16>, mlp_small); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 16>, mlp_small);
     set_lds(fm_k_mlp2_pair<FM_MLP_SC_NODE, FM_MLP_SC_EDGE, 16>, mlp_small); set_lds(fm_k_mlp2_pair<FM_MLP_NODE_HEAD, FM_MLP_EDGE_HEAD, 16>, mlp_small);

@@ -383,6 +383,122 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2_pair(FmMlpArgs a, FmMlpA
     else fm_mlp2_tile<MODE_B, TM>(b, (int)blockIdx.x - tiles_a, lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node-side MLPs of SMALL batches on 4-row tiles (one molecule .. ~21 molecules of 47 atoms: while (N + 3) / 4 tiles fit one per CU).  A 16-row tile's
+// two dependent 256-wide layers are 4 + 3.4 us of matrix time on ONE CU whatever the batch (v_mfma_f32_16x16x4 multiplies 16 rows or none); on four rows
+// with v_mfma_f32_4x4x1_16B_f32 a layer is its 0.3 MB weight stream at a CU's 150 GB/s, and a 47-atom molecule spreads over 12 CUs instead of 3 -- the
+// treatment round 4 gave fm_k_node_update (fm_wave_gemm4), here for the self-conditioning node layer (self_conditioning.py:49-58), the node output
+// head (vector_field.py:336-339) and the first convolution's hoisted projection.  Arithmetic per element as in fm_mlp2_tile / fm_k_node_proj; the K order of
+// the sums differs (two or eight K slices meeting in LDS), which f32 parity tolerates like every other tile shape.
+// ------------------------------------------------------------------------------------------------
+enum FmMlp4Mode { FM_MLP4_SC_NODE = 0, FM_MLP4_NODE_HEAD = 1, FM_MLP4_PROJ0 = 2 };
+struct FmMlp4Args {
+    int N;
+    const void* W1q; const float* b1;          // quad-row packed (fm_wave_gemm4_at): SC_NODE K = 320 ([s_tab (256) | p_a | p_c | rbf | 0]), NODE_HEAD K = 256; N = 256
+    const void* W2q; const float* b2;          // SC_NODE: K = 256, N = 256 (G = 4); NODE_HEAD: K = 256, N = 64 (G = 1; na + nc real columns)
+    // SC_NODE
+    const float* s_tab; const int* tok_a; const int* tok_c; int n_c1;
+    const float* prev_a; const float* prev_c; const float* prev_x; const float* x_t;
+    int na, nc; float rbf_mu_step, rbf_inv_sigma;
+    float* out; float* out2;                   // SC_NODE: s (N,256); NODE_HEAD: atom-type / charge probabilities
+    const float* in;                           // NODE_HEAD / PROJ0: s (N,256)
+    // PROJ0: the first convolution's Ps = s * Ws_src; v = 0 (vector_field.py:246), so PV = 0 as well; working copy of the positions
+    const void* Wps4; float* Ps; float* PV; int pv_w; float* v_init; int V; const float* x_src; float* x_dst;
+};
+#define FM_MLP4_LDX 324          // >= 320 columns, 16-byte rows
+#define FM_MLP4_LDH 260
+#define FM_MLP4_LDS_BYTES ((4 * FM_MLP4_LDX + 4 * FM_MLP4_LDH + 2048 + 16) * 4)
+
+template <int MODE>
+__device__ __forceinline__ void fm_mlp4_tile(const FmMlp4Args& a, int tile, float* lds) {
+    constexpr int LDX = FM_MLP4_LDX, LDH = FM_MLP4_LDH;
+    float* X = lds;                               // [4][324]
+    float* Hb = X + 4 * LDX;                      // [4][260]
+    float* S = Hb + 4 * LDH;                      // [8 / G][4][64 G]: K-slice exchange
+    int* meta = reinterpret_cast<int*>(S + 2048); // [4] token row
+    float* dd = reinterpret_cast<float*>(meta + 4);
+    const int tid = threadIdx.x, row0 = tile * 4;
+    const int rows = a.N - row0 < 4 ? a.N - row0 : 4;
+    if (MODE == FM_MLP4_SC_NODE) {
+        if (tid < 4) {
+            const int n = row0 + tid;
+            int tok = -1; float d = 0.f;
+            if (n < a.N) {
+                tok = a.tok_a[n] * a.n_c1 + a.tok_c[n];
+                d = fm_norm3(a.x_t[n * 3 + 0] - a.prev_x[n * 3 + 0], a.x_t[n * 3 + 1] - a.prev_x[n * 3 + 1], a.x_t[n * 3 + 2] - a.prev_x[n * 3 + 2]);
+            }
+            meta[tid] = tok; dd[tid] = d;
+        }
+        __syncthreads();
+        if (tid < 256) {         // columns 0..255: the (a,c)-token embedding row (rows without a node read 0 through the range check)
+            const int r = tid >> 6, c4 = tid & 63, tok = meta[r];
+            *reinterpret_cast<float4*>(X + r * LDX + c4 * 4) = fm_buf_f32x4(fm_buf(a.s_tab), tok >= 0 ? tok * 1024 + c4 * 16 : FM_BUF_OOB, 0);
+        } else {                 // columns 256..319: [p_a | p_c | rbf(|x_t - x1_prev|) | 0]
+            const int r = (tid - 256) >> 6, c = (tid - 256) & 63, n = row0 + r;
+            float v = 0.f;
+            if (meta[r] >= 0 && c < a.na + a.nc + 32) {
+                if (c < a.na) v = a.prev_a[(size_t)n * a.na + c];
+                else if (c < a.na + a.nc) v = a.prev_c[(size_t)n * a.nc + (c - a.na)];
+                else v = fm_rbf(dd[r], c - a.na - a.nc, a.rbf_mu_step, a.rbf_inv_sigma);
+            }
+            X[r * LDX + 256 + c] = v;
+        }
+    } else {
+        if (tid < 256)           // the tile's rows of s, 16-byte loads; rows beyond N read 0
+            *reinterpret_cast<float4*>(X + (tid >> 6) * LDX + (tid & 63) * 4) = fm_buf_f32x4(fm_buf(a.in + (size_t)row0 * 256, (unsigned)rows * 1024u), tid * 16, 0);
+        if (MODE == FM_MLP4_PROJ0) {
+            for (int i = tid; i < rows * 3; i += FM_THREADS) a.x_dst[row0 * 3 + i] = a.x_src[row0 * 3 + i];
+            for (int i = tid; i < rows * 3 * a.V; i += FM_THREADS) a.v_init[(size_t)row0 * 3 * a.V + i] = 0.f;
+            for (int i = tid; i < rows * 3 * a.pv_w; i += FM_THREADS) a.PV[(size_t)row0 * 3 * a.pv_w + i] = 0.f;      // v = 0: the hoisted hidden-vector rows are 0 * W
+        }
+    }
+    __syncthreads();
+    if (MODE == FM_MLP4_PROJ0) {
+        fm_rows4_linear<64, 4>(X, LDX, a.Wps4, S, [&](int r, int c, float v) { if (r < rows) a.Ps[(size_t)(row0 + r) * 256 + c] = v; });
+        return;
+    }
+    if (MODE == FM_MLP4_SC_NODE)
+        fm_rows4_linear<80, 4>(X, LDX, a.W1q, S, [&](int r, int c, float v) { Hb[r * LDH + c] = fm_silu(v + a.b1[c]); });
+    else
+        fm_rows4_linear<64, 4>(X, LDX, a.W1q, S, [&](int r, int c, float v) { Hb[r * LDH + c] = fm_silu(v + a.b1[c]); });
+    if (MODE == FM_MLP4_SC_NODE) {
+        fm_rows4_linear<64, 4>(Hb, LDH, a.W2q, S, [&](int r, int c, float v) {
+            if (r < rows) a.out[(size_t)(row0 + r) * 256 + c] = a.s_tab[(size_t)meta[r] * 256 + c] + fm_silu(v + a.b2[c]);
+        });
+    } else {
+        const int no = a.na + a.nc;
+        fm_rows4_linear<64, 1>(Hb, LDH, a.W2q, S, [&](int r, int c, float v) { if (c < no) X[r * LDX + c] = v + a.b2[c]; });
+        if (tid < rows) {        // softmax heads (vector_field.py:336-339,364-367): one lane per row, the arithmetic of fm_mlp2_tile
+            const float* lg = X + tid * LDX;
+            const int n = row0 + tid;
+            float m = lg[0];
+            for (int c = 1; c < a.na; ++c) m = fmaxf(m, lg[c]);
+            float sum = 0.f;
+            for (int c = 0; c < a.na; ++c) sum += expf(lg[c] - m);
+            for (int c = 0; c < a.na; ++c) a.out[(size_t)n * a.na + c] = expf(lg[c] - m) / sum;
+            m = lg[a.na];
+            for (int c = 1; c < a.nc; ++c) m = fmaxf(m, lg[a.na + c]);
+            sum = 0.f;
+            for (int c = 0; c < a.nc; ++c) sum += expf(lg[a.na + c] - m);
+            for (int c = 0; c < a.nc; ++c) a.out2[(size_t)n * a.nc + c] = expf(lg[a.na + c] - m) / sum;
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_mlp4(FmMlp4Args a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    fm_mlp4_tile<MODE>(a, blockIdx.x, lds);
+}
+
+// 4-row node tiles and 16-row pair tiles of the same stage in ONE launch (the small-batch counterpart of fm_k_mlp2_pair)
+template <int MODE4, int MODE_B>
+__global__ void __launch_bounds__(FM_THREADS) fm_k_mlp4_pair(FmMlp4Args a, FmMlpArgs b, int tiles_a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    if ((int)blockIdx.x < tiles_a) fm_mlp4_tile<MODE4>(a, blockIdx.x, lds);
+    else fm_mlp2_tile<MODE_B, 16>(b, (int)blockIdx.x - tiles_a, lds);
+}
+
 // gather-only initialisation when there is no self-conditioning input (bootstrap pass / non-SC models)
 __global__ void __launch_bounds__(256) fm_k_gather_rows(float* __restrict__ out, const float* __restrict__ tab, int width,
                                                          int rows, const int* __restrict__ tok_a, const int* __restrict__ tok_c,
@@ -1439,8 +1555,11 @@ struct FmCtmcFusedArgs {
     float* sink_x; float* sink_x1;
 };
 
-__global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
-    __shared__ int red[2][4];
+// NT threads per workgroup: 256, or 1024 for batches of a few molecules -- there one workgroup per (molecule, modality) is all the parallelism the kernel has,
+// and a 47-atom molecule's 1081 pair rows are five dependent load-compute rounds of 256 threads but two of 1024 (one molecule: 13.9 -> 8 us per step)
+template <int NT>
+__global__ void __launch_bounds__(NT) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
+    __shared__ int red[2][NT / 64];
     const int mol = blockIdx.x, job = blockIdx.y, tid = threadIdx.x;
     if (job == 3) {
         const int n0 = a.node_off[mol], n1 = a.node_off[mol + 1];
@@ -1455,7 +1574,7 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
                 if (tid == 0) { com[0] = sx * inv; com[1] = sy * inv; com[2] = sz * inv; }
             }
             __syncthreads();
-            for (int i = n0 * 3 + tid; i < n1 * 3; i += 256) {
+            for (int i = n0 * 3 + tid; i < n1 * 3; i += NT) {
                 const float x1 = a.x_raw[i] - com[(i - n0 * 3) % 3];
                 a.x1_out[i] = x1;
                 const float vf = fm_mul_rn(a.coef, fm_sub_rn(x1, a.x_t[i]));
@@ -1466,7 +1585,7 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
             }
             return;
         }
-        for (int i = n0 * 3 + tid; i < n1 * 3; i += 256) {
+        for (int i = n0 * 3 + tid; i < n1 * 3; i += NT) {
             const float x1 = a.x1[i];
             const float vf = fm_mul_rn(a.coef, fm_sub_rn(x1, a.x_t[i]));
             const float xn = fm_add_rn(a.x_t[i], fm_mul_rn(fm_mul_rn(a.dt, vf), a.scale));
@@ -1480,7 +1599,7 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
     const int r0 = md.off[mol], r1 = md.off[mol + 1], K = md.K;
     const unsigned gid = a.philox ? (unsigned)a.mol_gid[mol] : 0u, ctr2 = (unsigned)a.step * 4u + (unsigned)job;
     int cm = 0, ch = 0;
-    for (int i = r0 + tid; i < r1; i += 256) {
+    for (int i = r0 + tid; i < r1; i += NT) {
         float lp[16], qv[16];
         if (a.philox) {            // draws 0..K-1 of this row's stream: Exp(1) for the categorical sample
             for (int blk = 0; blk * 4 < K; ++blk) {
@@ -1512,8 +1631,9 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
         for (int o = 32; o > 0; o >>= 1) { cm += __shfl_xor(cm, o); ch += __shfl_xor(ch, o); }
         if ((tid & 63) == 0) { red[0][tid >> 6] = cm; red[1][tid >> 6] = ch; }
         __syncthreads();
-        cm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        ch = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        cm = ch = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { cm += red[0][w]; ch += red[1][w]; }
     }
     // per-molecule probabilities: ph = min(unmask_prob*m/h, 1) (inf when h == 0); pl = (unmask_prob*m - ph*h)/(m-h)
     const float m = (float)cm, h = (float)ch;
@@ -1521,7 +1641,7 @@ __global__ void __launch_bounds__(256) fm_k_ctmc_fused(FmCtmcFusedArgs a) {
     float ph = (ch == 0) ? INFINITY : fm_div_rn(um, h);
     ph = fminf(ph, 1.0f);
     const float pl = fm_div_rn(fm_sub_rn(um, fm_mul_rn(ph, h)), fm_sub_rn(m, h));
-    for (int i = r0 + tid; i < r1; i += 256) {
+    for (int i = r0 + tid; i < r1; i += NT) {
         const int packed = md.x1[i];
         const int x1 = packed & 255;
         const int tok = md.xt[i];

@@ -400,10 +400,11 @@ def test_error_tracks_the_reference_rounding_sensitivity_on_emulation(emu_lib):
     assert all(torch.isfinite(v).all() for v in out.values())
 
 
-@pytest.mark.parametrize('small', [-1, 1])
+@pytest.mark.parametrize('small', [-1, 1, 2])
 def test_mlp_tile_sizes_on_emulation(emu_lib, small):
-    """The node- / pair-side MLP kernels (self-conditioning layers, output heads) exist with 64-row tiles (throughput) and 16-row tiles
-    (small batches, chosen automatically): both against the oracle on the same batch, paired and separate launches."""
+    """The node- / pair-side MLP kernels (self-conditioning layers, output heads) exist with 64-row tiles (throughput), 16-row tiles
+    (small batches) and -- node side, round 5 -- 4-row tiles on v_mfma_f32_4x4x1 (fm_k_mlp4: the smallest batches, chosen automatically while
+    such tiles fit one per CU; mlp_small_tiles = 2 forces them): each against the oracle on the same batch, paired and separate launches."""
     from flowmol_amd.engine import Engine
     for pair in (-1, 1):
         cfg = presets.flowmol3()
@@ -506,3 +507,52 @@ def test_teacher_forced_decision_audit_on_emulation(emu_lib):
     res = audit_long_decisions(cfg, bad, traj, probs)
     kinds = sorted(e['kind'] for e in res['unexplained'])
     assert kinds == ['sampled token', 'state token'] and res['sample_diffs'] == 1 and res['state_diffs'] == 1, res
+
+
+@pytest.mark.parametrize('last', [False, True])
+def test_ctmc_kernel_1024_thread_instance_on_emulation(emu_lib, last):
+    """fm_k_ctmc_fused<1024> -- the instance for batches of a few molecules (one workgroup per molecule and modality is all the parallelism the
+    kernel has; chosen when 4 B workgroups do not fill the chip) -- against the oracle's campbell_step on two molecules of 26 / 25 atoms with
+    random endpoint probabilities and a half-unmasked state: every new state token and sampled token bit-exact, Euler step bit-exact."""
+    import torch.nn.functional as F
+    from flowmol_amd.engine import Engine, StepNoise, make_step_plan
+    cfg = presets.flowmol3()
+    sd = weights.synth_state_dict(cfg, 0)
+    eng = Engine(cfg, sd, device='cpu', lib=emu_lib)
+    n_atoms = torch.tensor([26, 25])
+    eng.bind(n_atoms)
+    batch = cpu_ref.build_batch(n_atoms)
+    orc = cpu_ref.OracleVF(cfg, sd)
+    g = torch.Generator().manual_seed(5)
+    N, U = eng.N, eng.U
+    T, s_idx = 30, 30 - 1 if last else 12
+    plan = make_step_plan(T, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature)
+    sc = plan.scalars[s_idx - 1]
+    dst = {'x': torch.randn(N, 3, generator=g), 'a': torch.softmax(3 * torch.randn(N, cfg.n_atom_types, generator=g), -1),
+           'c': torch.softmax(3 * torch.randn(N, cfg.n_charges, generator=g), -1), 'e': torch.softmax(3 * torch.randn(U, cfg.n_bond_types, generator=g), -1)}
+    tok = {}
+    for k, rows, K in (('a', N, cfg.n_atom_types), ('c', N, cfg.n_charges), ('e', U, cfg.n_bond_types)):
+        t_ = torch.randint(0, K, (rows,), generator=g)
+        t_[torch.rand(rows, generator=g) < 0.5] = K                      # half of the rows masked
+        tok[k] = t_
+    x_t = torch.randn(N, 3, generator=g)
+    torch.manual_seed(9)
+    nz = StepNoise.draw(N, U, cfg.n_atom_types, cfg.n_charges, cfg.n_bond_types, last, 'cpu')
+    state = eng.make_state(x_t, tok['a'], tok['c'], tok['e'])
+    i32 = dict(dtype=torch.int32)
+    smp = {'a1': torch.zeros(N, **i32), 'c1': torch.zeros(N, **i32), 'e1': torch.zeros(U, **i32)}
+    eng.ctmc_step(state, {k: v.contiguous() for k, v in dst.items()}, nz, sc, smp)
+    # the oracle's campbell_step with the same draws (tape order per modality: q, u1, u2)
+    t = plan.t
+    alpha, alpha_p = cpu_ref.alpha_tables(t.clone())
+    dt = t[s_idx] - t[s_idx - 1]
+    m = batch.upper_edge_mask
+    for fi, (k, K, bidx) in enumerate((('a', cfg.n_atom_types, batch.node_batch_idx), ('c', cfg.n_charges, batch.node_batch_idx), ('e', cfg.n_bond_types, batch.edge_batch_idx[m])), start=1):
+        tape = [getattr(nz, f'q_{k}'), getattr(nz, f'u1_{k}')] + ([] if last else [getattr(nz, f'u2_{k}')])
+        p = F.softmax(torch.log(dst[k]) / cfg.cat_temperature, dim=-1)
+        xt1h, x11h = orc.campbell_step(p, tok[k], cfg.stochasticity, cfg.high_confidence_threshold, alpha[s_idx - 1][fi], alpha_p[s_idx - 1][fi], dt,
+                                       2, K + 1, K, last, bidx, cpu_ref.TapeNoise(tape))
+        assert torch.equal(state[f'{k}_t'].long(), xt1h.argmax(-1)), k
+        assert torch.equal(smp[f'{k}1'].long(), x11h.argmax(-1)), k
+    vf = alpha_p[s_idx - 1][0] / (1 - alpha[s_idx - 1][0]) * (dst['x'] - x_t)
+    assert torch.equal(state['x_t'], x_t + dt * vf * 1.0)
