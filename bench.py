@@ -291,7 +291,7 @@ def cpu_baseline(cfg, sd, all_sizes, cpu_mols, steps, T, evals, ref_batch=128, r
 WORKLOADS = {'c3': dict(preset='flowmol3', mols=1024, n=47, T=250, traj=False, label='BASELINE.json configs[2]; configs[3] at 8 GPUs'),
              'c2': dict(preset='qm9', mols=256, n=18, T=100, traj=False, label='BASELINE.json configs[1]'),
              'c5': dict(preset='geom_ctmc', mols=128, n=None, T=500, traj=True, label='BASELINE.json configs[4], trajectory sink on (--xt_traj / --ep_traj)')}
-KERNEL_NAMES = ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head', 'node_head', 'sc',
+KERNEL_NAMES = ('edge_message', 'edge_message_pq', 'edge_update', 'edge_update_head', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head', 'node_head', 'sc',
                 'heads', 'ctmc', 'ctmc_gat', 'dst_proj', 'embed_table', 'gather_ef', 'gather_s', 'remove_com', 'x_step')
 
 

@@ -66,6 +66,7 @@ struct fm_ctx {
     int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
     int mlp4_forced = -1;           // fm_config.mlp_small_tiles = 2: the node-side MLPs on 4-row tiles (fm_k_mlp4) whatever the batch; 1 / -1: never
     const void *sc_node_W1q = nullptr, *sc_node_W2q = nullptr, *node_head_W1q = nullptr, *node_head_W2q = nullptr;      // quad-row packed copies for fm_k_mlp4
+    int fuse_head = 1;        // the evaluation's last EdgeUpdate also runs the edge output head on its pairs (fm_k_edge_update<32, false, true>; fm_config.fuse_node = 2 | -1: separate)
     int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
     int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (self-conditioned models; fm_config.pair_slab = -1: 0)
     int node_rg = 0;          // this batch runs the node kernel on tiles of 4 * node_rg nodes (RG instances; 1, 2, 3 in the 16-row frame, 5 in the 32-row
@@ -300,7 +301,7 @@ size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
 }
 size_t lds_mlp(int ldx, int ldh, int tm = FM_TM) { return ((size_t)tm * ldx + (size_t)tm * ldh) * 4 + 5 * (size_t)tm * 4; }
 size_t lds_proj(int V, int tm = FM_TM) { return ((size_t)tm * 260 + 3 * (size_t)tm * (V + 4)) * 4; }
-size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 3 * 4; }
+size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 4 * 4 + 16; }
 size_t lds_edge_upd_sp(int TM) { return (size_t)TM * 132 * 4 + (size_t)TM * 176 * 2 * 2 + TM * 3 * 4; }
 
 // ---------------------------------------------------------------------------------------- launch helper
@@ -476,6 +477,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     // fm_config.fuse_node = -1 keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own (0 / 1 = fused)
     const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
     const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
+    bool head_done = false;      // the edge head ran as the epilogue of the last EdgeUpdate
     for (int it = 0; it < n_pass; ++it) {
         const int i = it % cf.n_convs;
         const ConvW& cw = c->conv[i];
@@ -584,12 +586,17 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             if (cf.precision == FM_PREC_BF16X3) {
                 FmEdgeUpdSpW sw{uw.W1_sp, uw.W2_sp};
                 L("edge_update", fm_k_edge_update_sp<32>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
+            } else if (it == n_pass - 1 && c->fuse_head && c->F == 128 && c->tm_eupd == 32 && !(taps_on && c->taps.count("upd" + std::to_string(i) + ".ef"))) {
+                // the evaluation's last EdgeUpdate: its rows feed the edge head and nothing else -- tiles of 16 pairs, the head as the epilogue, no ef store
+                eu.hW1 = c->edge_head.W1; eu.hb1 = c->edge_head.b1; eu.hW2 = c->edge_head.W2; eu.hb2 = c->edge_head.b2; eu.out_e = out->e; eu.ne = c->ne;
+                L("edge_update_head", fm_k_edge_update<32, false, true>, dim3((U + 15) / 16), blk, lds_edge_upd(32), eu);
+                head_done = true;
             } else if (c->F != 128) L("edge_update", fm_k_edge_update<32, true>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             else if (c->tm_eupd == 32) L("edge_update", fm_k_edge_update<32, false>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             else L("edge_update", fm_k_edge_update<64, false>, dim3((E + 63) / 64), blk, lds_edge_upd(64), eu);
             const std::string ui = "upd" + std::to_string(i);
             tap(ui + ".x", c->xw, (size_t)N * 3 * 4);
-            tap(ui + ".ef", c->ef, (size_t)E * 128 * 4);
+            if (!head_done) tap(ui + ".ef", c->ef, (size_t)E * 128 * 4);
         }
     }
     {
@@ -600,7 +607,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         FmMlp4Args a4{};
         a4.N = N; a4.W1q = c->node_head_W1q; a4.b1 = c->node_head.b1; a4.W2q = c->node_head_W2q; a4.b2 = c->node_head.b2;
         a4.na = c->na; a4.nc = c->nc; a4.in = c->s; a4.out = out->a; a4.out2 = out->c;
-        if (pair_mlps && mlp4 && small_mlp) {
+        if (head_done) {          // only the node head is left
+            if (mlp4) L("node_head", fm_k_mlp4<FM_MLP4_NODE_HEAD>, dim3(tiles4), dim3(FM_THREADS), (size_t)FM_MLP4_LDS_BYTES, a4);
+            else launch_mlp<FM_MLP_NODE_HEAD>(L, "node_head", a, c->node_head, N, small_node);
+        } else if (pair_mlps && mlp4 && small_mlp) {
             fill_mlp(e, c->edge_head, U);
             const int tb = (U + 15) / 16;
             L("heads", fm_k_mlp4_pair<FM_MLP4_NODE_HEAD, FM_MLP_EDGE_HEAD>, dim3(tiles4 + tb), dim3(FM_THREADS), std::max((size_t)FM_MLP4_LDS_BYTES, lds_mlp(e.ldx, e.ldh, 16)), a4, e, tiles4);
@@ -1007,7 +1017,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     // launch-tuning overrides (fm_config, ABI 5; 0 = automatic everywhere)
     c->tm_edge_forced = cfg->tile_edge; c->tm_node_forced = cfg->tile_node;
     c->tm_eupd = cfg->tile_edge_update == 64 ? 64 : 32;
-    c->xcd_swizzle = cfg->xcd_swizzle >= 0; c->fuse_node = cfg->fuse_node >= 0;
+    c->xcd_swizzle = cfg->xcd_swizzle >= 0; c->fuse_node = cfg->fuse_node >= 0; c->fuse_head = cfg->fuse_node == 0 || cfg->fuse_node == 1;
     c->pair_mlps_forced = cfg->pair_mlps == 0 ? -1 : (cfg->pair_mlps > 0);
     c->small_mlp_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles > 0);
     c->mlp4_forced = cfg->mlp_small_tiles == 0 ? -1 : (cfg->mlp_small_tiles == 2);
@@ -1051,7 +1061,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
     set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
-    set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32));
+    set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32)); set_lds(fm_k_edge_update<32, false, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 32>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD, 32>, mlp_max);

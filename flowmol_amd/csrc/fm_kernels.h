@@ -329,7 +329,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        fm_buf_store_f32x2(rs, (i * 16 + 4 * (lane >> 4) + q) * 1024 + (lane & 15) * 8, wave * 128, acc[i][0][q], acc[i][1][q]);
+                        fm_buf_store_f32x2_q(rs, (i * 16 + 4 * (lane >> 4) + q) * 1024 + (lane & 15) * 8, wave * 128, acc[i][0][q], acc[i][1][q]);
             };
             slab_gemm(a.slabW0, a.slabQ0);
             if (a.slabQ1) slab_gemm(a.slabW1, a.slabQ1);
@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         for (int i = 0; i < TM / 16; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {       // one 8-byte load per row: the row's values for this lane's two column tiles sit side by side (accumulator order)
-                const float2 t = fm_buf_f32x2(rs, m_doff[i * 16 + 4 * (lane >> 4) + r] + (lane & 15) * 8, wave * 128);
+                const float2 t = fm_buf_f32x2_q(rs, m_doff[i * 16 + 4 * (lane >> 4) + r] + (lane & 15) * 8, wave * 128);
                 preq[i][0][r] = t.x; preq[i][1][r] = t.y;
             }
     }
@@ -1229,10 +1229,20 @@ struct FmEdgeUpdArgs {
     const float* ln_g; const float* ln_b;
     float rbf_mu_step, rbf_inv_sigma;
     int f_real;                // NARROW instances: real edge-feature width (< 128) of the LayerNorm statistics
+    // HEAD instances (the evaluation's LAST EdgeUpdate): the edge output head (vector_field.py:340-344,364-367) on the tile's pairs -- the updated features
+    // of a pair's two directed edges are on chip, nobody else reads them, so they are summed, sent through to_edge_logits and the softmax right here
+    // and never written to HBM
+    const float2* hW1; const float* hb1;    // K = 128, N = 128
+    const float2* hW2; const float* hb2;    // K = 128, N = 16 (ne real columns)
+    float* out_e; int ne;                   // (U, ne) bond-order probabilities
 };
 
-template <int TM, bool NARROW>
+// HEAD = false: a tile is TM consecutive directed edges (internal order).  HEAD = true (TM = 32): a tile is 16 consecutive unordered pairs, rows 2k / 2k + 1 =
+// the pair's two directed edges (src < dst first, the reference's upper edge): same per-row arithmetic, rows gathered instead of streamed, and the epilogue
+// is the edge head of those 16 pairs instead of the store of the rows.
+template <int TM, bool NARROW, bool HEAD = false>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) {
+    static_assert(!HEAD || (TM == 32 && !NARROW), "the fused edge head exists for 32-row tiles of full-width models");
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int LDX = 164, LDH = 132, MT = TM / 16, LPR = FM_THREADS / TM;
     float* X = lds;                       // [TM][164]: ef(128) | rbf(32)
@@ -1241,15 +1251,35 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     int* m_doff = m_soff + TM;                                // the range check returns 0 whatever column offset is added), same for the destination
     float* m_d = reinterpret_cast<float*>(m_doff + TM);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), e0 = blockIdx.x * TM;
+    constexpr int NEF = TM * 32 / FM_THREADS;
+    float4 efv[NEF];
     // the tile's ef rows depend only on the tile index: request them first.  Tile-relative descriptor; its range check
     // zero-fills the rows of a ragged last tile on load and drops them on the final store.
     const int left = a.b.E - e0;
-    const auto rs_ef = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
-    constexpr int NEF = TM * 32 / FM_THREADS;
-    float4 efv[NEF];
+    const auto rs_ef = fm_buf(a.ef + (size_t)(HEAD ? 0 : e0) * 128, HEAD ? 0u : (unsigned)(left < TM ? left : TM) * 512u);
+    if constexpr (!HEAD) {
 #pragma unroll
-    for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs_ef, tid * 16 + k * FM_THREADS * 16, 0);
-    if (tid < TM) {
+        for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs_ef, tid * 16 + k * FM_THREADS * 16, 0);
+    }
+    int* m_eoff = reinterpret_cast<int*>(m_d + TM);           // HEAD: [TM] byte offset of the row's edge in ef relative to the tile's smallest edge id, [TM] = that id
+    if (HEAD && tid < 64) {
+        const int p = blockIdx.x * (TM / 2) + (tid >> 1);
+        const int e = (tid < TM && p < a.b.U) ? ((tid & 1) ? a.b.p_e1[p] : a.b.p_e0[p]) : 0x7fffffff;
+        int mn = e;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }      // the tile's pairs lie within a few molecules: relative offsets stay below 2^31
+        if (tid < TM) {
+            int s = -1, d = -1; float dist = 0.f;
+            if (e != 0x7fffffff) {
+                s = a.b.e_src[e]; d = a.b.e_dst[e];
+                dist = fm_norm3(a.x[s * 3] - a.x[d * 3], a.x[s * 3 + 1] - a.x[d * 3 + 1], a.x[s * 3 + 2] - a.x[d * 3 + 2]) + 1e-8f;
+            }
+            m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB; m_doff[tid] = s >= 0 ? d * 1024 : FM_BUF_OOB; m_d[tid] = dist;
+            m_eoff[tid] = s >= 0 ? (e - mn) * 512 : FM_BUF_OOB;
+        }
+        if (tid == 0) m_eoff[TM] = mn;
+    }
+    if (!HEAD && tid < TM) {
         const int e = e0 + tid;
         int s = -1, d = -1; float dist = 0.f;
         if (e < a.b.E) {
@@ -1259,6 +1289,15 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
         m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB; m_doff[tid] = s >= 0 ? d * 1024 : FM_BUF_OOB; m_d[tid] = dist;
     }
     __syncthreads();
+    if constexpr (HEAD) {       // the rows of the tile's edges, gathered: 16-byte loads, all of a thread's requests back to back (rows without a pair read 0)
+        const int emin = __builtin_amdgcn_readfirstlane(m_eoff[TM]);
+        const auto rs_g = fm_buf(a.ef + (size_t)(emin == 0x7fffffff ? 0 : emin) * 128, 0x7ffffe00u);
+#pragma unroll
+        for (int k = 0; k < NEF; ++k) {
+            const int idx = tid + k * FM_THREADS;
+            efv[k] = fm_buf_f32x4(rs_g, m_eoff[idx >> 5] + (idx & 31) * 16, 0);
+        }
+    }
     // layer 1: wave w owns column tile w for all MT row tiles.  The hoisted node terms W1_src*s[src] + W1_dst*s[dst]
     // (+ bias) are requested before the GEMM so their L2 latency hides behind the fill and the MFMAs; rows without an
     // edge read 0 through the range check.
@@ -1281,7 +1320,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
 #ifdef FM_ALT_FILL
     // dev-only (-DFM_ALT_FILL): round 4's EARLIER arrangement of this fill (index arithmetic per pass, profiles/r04x).  Same arithmetic per element; under
     // -ffp-contract=fast the two arrangements produced different output bits (the compiler fused fm_rbf's d - k mu in one and not in the other), with
-    // contraction off they must not -- tools/fingerprint_matrix.py compares the two builds (profiles/r05a_*)
+    // contraction off they must not -- tools/fingerprint_matrix.py compares the two builds (profiles/r05b_*)
 #pragma unroll
     for (int k = 0; k < NEF; ++k) {
         const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
@@ -1341,7 +1380,55 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
         o.y = fm_fma((xv.y - mean) * rstd, g.y, bb.y);
         o.z = fm_fma((xv.z - mean) * rstd, g.z, bb.z);
         o.w = fm_fma((xv.w - mean) * rstd, g.w, bb.w);
-        fm_buf_store_f32x4(rs_ef, r * 512 + c * 4, 0, o);
+        if constexpr (HEAD) *reinterpret_cast<float4*>(X + r * LDX + c) = o;       // stays on chip: own elements, in place
+        else fm_buf_store_f32x4(rs_ef, r * 512 + c * 4, 0, o);
+    }
+    if constexpr (HEAD) {
+        // ---- edge output head on the tile's 16 pairs: x = ef[upper] + ef[lower] (vector_field.py:342), Linear(128,128) . SiLU . Linear(128,ne), softmax
+        constexpr int NP = TM / 2;
+        float* P = Hb;                          // [16][132]: pair inputs (the hidden tile is dead)
+        float* part = Hb + NP * LDH;            // [8][16][16]: K-slice partial logits (2048 floats <= the other half of Hb)
+        static_assert(NP * LDH + 2048 <= TM * LDH, "partial logits must fit into the hidden tile");
+        __syncthreads();
+        for (int idx = tid; idx < NP * 32; idx += FM_THREADS) {
+            const int k = idx >> 5, c4 = idx & 31;
+            const float4 u = *reinterpret_cast<const float4*>(X + (2 * k) * LDX + 4 * c4), l = *reinterpret_cast<const float4*>(X + (2 * k + 1) * LDX + 4 * c4);
+            *reinterpret_cast<float4*>(P + k * LDH + 4 * c4) = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
+        }
+        __syncthreads();
+        {   // layer 1: 16 x 128 -> 128, wave w owns column tile w; result (SiLU) into rows 0..15 of X (dead: every pair sum has been formed)
+            f32x4 acc[1][1];
+            const float hb1 = a.hb1[col];
+            acc[0][0] = f32x4{hb1, hb1, hb1, hb1};
+            fm_wave_gemm<1, 1>(acc, P, LDH, 128 / 8, a.hW1, 8, wave, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xo[q * LDX] = fm_silu(acc[0][0][q]);
+        }
+        __syncthreads();
+        {   // layer 2: 16 x 128 -> 16 (ne real columns): ONE column tile, its K = 128 split over the eight waves (two k-steps each)
+            f32x4 acc[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
+            fm_wave_gemm<1, 1>(acc, X + 16 * wave, LDX, 2, a.hW2 + (size_t)(2 * wave) * 64, 1, 0, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[(wave * 16 + 4 * (lane >> 4) + q) * 16 + (lane & 15)] = acc[0][0][q];
+        }
+        __syncthreads();
+        if (tid < NP) {
+            const int p = blockIdx.x * NP + tid;
+            if (p < a.b.U) {
+                float lg[16];
+                for (int c = 0; c < a.ne; ++c) {
+                    float v = part[tid * 16 + c];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) v += part[(w * 16 + tid) * 16 + c];
+                    lg[c] = v + a.hb2[c];
+                }
+                float m = lg[0];
+                for (int c = 1; c < a.ne; ++c) m = fmaxf(m, lg[c]);
+                float sum = 0.f;
+                for (int c = 0; c < a.ne; ++c) sum += expf(lg[c] - m);
+                for (int c = 0; c < a.ne; ++c) a.out_e[(size_t)p * a.ne + c] = expf(lg[c] - m) / sum;
+            }
+        }
     }
 }
 

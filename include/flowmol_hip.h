@@ -102,7 +102,8 @@ typedef struct fm_config {
                                    * on v_mfma_f32_4x4x1: the automatic choice is the smallest of 4 / 8 / 12 / 16 / 20 whose tiles fit one per CU */
     int32_t tile_edge_update;     /* EdgeUpdate tile: 0 = 32 | 32 | 64 */
     int32_t xcd_swizzle;          /* edge-message tile -> workgroup map: 0 / 1 = one contiguous tile range per XCD | -1 = identity */
-    int32_t fuse_node;            /* 0 / 1 = node_update also runs the next conv's projections + NodePositionUpdate | -1 = separate launches */
+    int32_t fuse_node;            /* 0 / 1 = node_update also runs the next conv's projections + NodePositionUpdate, and the last EdgeUpdate the edge output head
+                                     | 2 = the node fusion only (edge head as a kernel of its own) | -1 = separate launches */
     int32_t pair_mlps;            /* node-side and pair-side MLPs of a stage in ONE launch: 0 = while the pair tiles do not fill the chip | 1 always | -1 never */
     int32_t mlp_small_tiles;      /* 16-row tiles for the MLP kernels: 0 = while they do not fill the chip (and 4-row NODE tiles, fm_k_mlp4, while those fit one per CU)
                                      | 1 always 16 rows | -1 never | 2 = 16-row pair tiles + 4-row node tiles whatever the batch */

@@ -66,7 +66,13 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
             bufs[f'conv{i}.agg.v'] = torch.zeros(N, 3, V, device=dev)
             if cfg.update_schedule()[i] >= 0:
                 bufs[f'upd{i}.x'] = torch.zeros(N, 3, device=dev)
-                bufs[f'upd{i}.ef'] = torch.zeros(E, 128, device=dev)
+                # the evaluation's LAST EdgeUpdate runs the edge head as its epilogue and does not store its rows (fm_k_edge_update<32, false, true>); asking
+                # for that tap selects the separate kernels instead, so it is only requested where the fusion is off anyway (fuse_node = 2 | -1, narrow
+                # models, split precision) -- everywhere else the fused kernel is what runs and `out.e` is what checks it
+                last = i == cfg.n_convs - 1 and getattr(cfg, 'n_recycles', 1) <= 1
+                fused_head = eng.tuning.get('fuse_node', 0) in (0, 1) and cfg.n_hidden_edge_feats == 128 and eng.precision == 'f32' and eng.tuning.get('tile_edge_update', 0) != 64
+                if not (last and fused_head):
+                    bufs[f'upd{i}.ef'] = torch.zeros(E, 128, device=dev)
         bootstrap_ = (t_val == 0) and prev is None and cfg.self_conditioning
         first = 'sc' if (prev is not None or bootstrap_) else 'embed'   # the bootstrap result feeds the SC layer
         bufs[f'{first}.s'] = torch.zeros(N, 256, device=dev)

@@ -87,7 +87,7 @@ def test_forward_matches_oracle(name, sizes, t, prev, tile):
                                     {'pair_slab': -1}, {'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': -1, 'mlp_small_tiles': -1}, {'xcd_swizzle': -1, 'fuse_node': -1},
                                     {'tile_edge': 64, 'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': 1, 'mlp_small_tiles': -1},      # the PQ instance on 64-row tiles, the slab in the shared 64-row SC launch
                                     {'tile_node': 4}, {'tile_node': 4, 'tile_edge': 32, 'pair_slab': 1}, {'tile_node': 8}, {'tile_node': 12}, {'tile_node': 20}, {'tile_node': 16},
-                                    {'mlp_small_tiles': 2}, {'mlp_small_tiles': 2, 'pair_mlps': -1}, {'mlp_small_tiles': 1}])      # r5: node-side MLPs on 4-row tiles (automatic up to 1024 nodes) forced / off
+                                    {'mlp_small_tiles': 2}, {'mlp_small_tiles': 2, 'pair_mlps': -1}, {'mlp_small_tiles': 1}, {'fuse_node': 2}])      # r5: node-side MLPs on 4-row tiles (automatic up to 1024 nodes) forced / off
 @pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [70, 2, 47, 130], 0.3, True), ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False), ('flowmol3', [5, 9, 12, 3, 2], 0.0, False)])
 def test_forward_matches_oracle_under_every_accepted_tuning(name, sizes, t, prev, tuning):
     """Every launch-tuning value fm_config accepts is parity-tested (VERDICT r3 hygiene #14): 64-row tiles of the GVP kernels and of EdgeUpdate

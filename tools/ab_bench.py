@@ -59,7 +59,7 @@ for _ in range(3):
     eng.forward(st, 0.3, prev=prev, out=out)
 eng.synchronize()
 kern = {}
-for k in ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc', 'heads', 'sc_edge', 'sc_node', 'edge_head', 'node_head',
+for k in ('edge_message', 'edge_message_pq', 'edge_update', 'edge_update_head', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc', 'heads', 'sc_edge', 'sc_node', 'edge_head', 'node_head',
           'embed_table', 'gather_rows', 'event_overhead'):
     ms, cnt = eng.profile_get(k)
     if cnt:

@@ -28,7 +28,7 @@ TUNINGS = [{}, {'tile_edge': 64, 'tile_node': 64}, {'tile_edge_update': 64}, {'t
            {'pair_slab': -1}, {'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': -1, 'mlp_small_tiles': -1}, {'xcd_swizzle': -1, 'fuse_node': -1},
            {'tile_edge': 64, 'pair_slab': 1}, {'pair_slab': 1, 'pair_mlps': 1, 'mlp_small_tiles': -1},
            {'tile_node': 4}, {'tile_node': 4, 'tile_edge': 32, 'pair_slab': 1}, {'tile_node': 8}, {'tile_node': 12}, {'tile_node': 20}, {'tile_node': 16},
-           {'mlp_small_tiles': 2}, {'mlp_small_tiles': 2, 'pair_mlps': -1}, {'mlp_small_tiles': 1}]
+           {'mlp_small_tiles': 2}, {'mlp_small_tiles': 2, 'pair_mlps': -1}, {'mlp_small_tiles': 1}, {'fuse_node': 2}]
 cfg = presets.flowmol3()
 sd = weights.synth_state_dict(cfg, 0)
 lib = _lib.load(args.lib)
