@@ -181,26 +181,6 @@ __device__ __forceinline__ void fm_buf_store_f32x4(R rs, int voff, int soff, flo
     d[2] = __builtin_bit_cast(unsigned, v.z); d[3] = __builtin_bit_cast(unsigned, v.w);
     __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
 }
-// dev-only cache-policy experiments (-DFM_NT_Q=1: non-temporal stores of the pair-slab table, =2: non-temporal loads as well; profiles/r05b_*): aux bit 1 = nt on gfx94x/95x
-#ifndef FM_NT_Q
-#define FM_NT_Q 0
-#endif
-template <class R>
-__device__ __forceinline__ void fm_buf_store_f32x2_q(R rs, int voff, int soff, float x, float y) {
-    typedef unsigned fm_u32x2 __attribute__((ext_vector_type(2)));
-    fm_u32x2 d;
-    d[0] = __builtin_bit_cast(unsigned, x); d[1] = __builtin_bit_cast(unsigned, y);
-    __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, FM_NT_Q >= 1 ? 2 : 0);
-}
-template <class R>
-__device__ __forceinline__ float2 fm_buf_f32x2_q(R rs, int voff, int soff) {
-    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, FM_NT_Q >= 2 ? 2 : 0);
-    const unsigned r0 = r[0], r1 = r[1];
-    float2 out;
-    out.x = __builtin_bit_cast(float, r0);
-    out.y = __builtin_bit_cast(float, r1);
-    return out;
-}
 __device__ __forceinline__ float2 fm_wload(const float2* __restrict__ base /*wave-uniform*/, int byte_off /*wave-uniform*/, int lane) {
     return fm_buf_f32x2(fm_buf(base), lane * 8, byte_off);
 }
@@ -646,17 +626,6 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // a global load inside that loop sat on the critical path of every GVP of a small batch (profiles/r04i: 0.5 us of an 8.8-us GVP)
     static_assert(NTH % VOUT == 0, "one gate channel per thread");
     const float bias_g = w.bg[tid % VOUT];
-#ifdef FM_PQ_PRELOAD
-    // dev-only (-DFM_PQ_PRELOAD, profiles/r05b_*): the pair-slab instance's first scalar GEMM has K = 40 -- five k-steps, too short to cover the L2 latency of its own
-    // weight fragments -- so all of them (5 x 2 fragments per wave) are requested here, behind the biases, and the GEMM runs from registers
-    float2 pqb[PQ ? K8S : 1][PQ ? NTW : 1];
-    if constexpr (PQ) {
-#pragma unroll
-        for (int ks = 0; ks < K8S; ++ks)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) pqb[ks][j] = fm_wload(w.Ws + (size_t)(NTW * wave) * 64, (int)(((size_t)ks * 16 * 64 + (size_t)j * 64) * sizeof(float2)), lane);
-    }
-#endif
 
     if (!FIRST && !(FM_ABLATE & 4)) {
         // Vh[:, 0..V+15] = Vin(3TM x V) * [Wh | Wcp | 0]
@@ -783,21 +752,6 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         }
         FM_MARKB(2);
         if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
-#ifdef FM_PQ_PRELOAD
-        else if constexpr (PQ) {
-            const float* ap = X + (lane & 15) * FM_LDX + 2 * (lane >> 4);
-#pragma unroll
-            for (int ks = 0; ks < K8S; ++ks) {
-                float2 af[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const f32x2 t = *(const volatile __attribute__((address_space(3))) f32x2*)(ap + mt * 16 * FM_LDX + 8 * ks);
-                    af[mt].x = t[0]; af[mt].y = t[1];
-                }
-                fm_frag_mma<MT, NTW>(acc, af, pqb[ks]);
-            }
-        }
-#endif
         else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW, !FIRST>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)

@@ -336,7 +336,7 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        fm_buf_store_f32x2_q(rs, (i * 16 + 4 * (lane >> 4) + q) * 1024 + (lane & 15) * 8, wave * 128, acc[i][0][q], acc[i][1][q]);
+                        fm_buf_store_f32x2(rs, (i * 16 + 4 * (lane >> 4) + q) * 1024 + (lane & 15) * 8, wave * 128, acc[i][0][q], acc[i][1][q]);
             };
             slab_gemm(a.slabW0, a.slabQ0);
             if (a.slabQ1) slab_gemm(a.slabW1, a.slabQ1);
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         for (int i = 0; i < TM / 16; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {       // one 8-byte load per row: the row's values for this lane's two column tiles sit side by side (accumulator order)
-                const float2 t = fm_buf_f32x2_q(rs, m_doff[i * 16 + 4 * (lane >> 4) + r] + (lane & 15) * 8, wave * 128);
+                const float2 t = fm_buf_f32x2(rs, m_doff[i * 16 + 4 * (lane >> 4) + r] + (lane & 15) * 8, wave * 128);
                 preq[i][0][r] = t.x; preq[i][1][r] = t.y;
             }
     }

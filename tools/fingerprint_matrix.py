@@ -31,10 +31,11 @@ TUNINGS = [{}, {'tile_edge': 64, 'tile_node': 64}, {'tile_edge_update': 64}, {'t
            {'mlp_small_tiles': 2}, {'mlp_small_tiles': 2, 'pair_mlps': -1}, {'mlp_small_tiles': 1}, {'fuse_node': 2}]
 cfg = presets.flowmol3()
 sd = weights.synth_state_dict(cfg, 0)
-lib = _lib.load(args.lib)
+lib_path = Path(args.lib) if Path(args.lib).is_absolute() else ROOT / args.lib          # gpu_run.sh runs its steps from /tmp
+lib = _lib.load(lib_path)
 gsz = torch.Generator().manual_seed(3)
 sizes = torch.cat([torch.tensor([70, 2, 47, 130]), torch.randint(5, 90, (36,), generator=gsz)])
-out = {'lib': args.tag or Path(args.lib).parent.name + '/' + Path(args.lib).name, 'molecules': int(sizes.numel()), 'fingerprints': {}}
+out = {'lib': args.tag or lib_path.parent.name + '/' + lib_path.name, 'molecules': int(sizes.numel()), 'fingerprints': {}}
 for tn in TUNINGS:
     eng = Engine(cfg, sd, device='cuda:0', lib=lib, precision='f32', tuning=tn)
     eng.bind(sizes)
