@@ -73,7 +73,6 @@ struct fm_ctx {
                               // frame): chosen per bound batch, fm_config.tile_node = 4 / 8 / 12 / 20 forces it
     int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
-    float* efp = nullptr;                  // (U,128) pair rows of the self-conditioning layer's output (pair_rows_ok batches), in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
     // ---- weights (one device arena)
@@ -383,17 +382,6 @@ inline int pq_convs(const fm_ctx* c, long long U) {
     return (c->pq_forced || (U + 31) / 32 >= 16LL * c->n_cus) ? c->n_pq : 0;
 }
 
-// Pair-row edge features between the self-conditioning layer and the first EdgeUpdate: possible when every convolution before that EdgeUpdate is a pair-slab
-// instance (none of them reads ef) and the EdgeUpdate is not also the evaluation's last one (that one gathers by edge for its head epilogue).
-inline bool pair_rows_ok(const fm_ctx* c, long long U) {
-    const int npq = pq_convs(c, U);
-    const fm_config& cf = c->cfg;
-    if (npq == 0 || c->F != 128 || c->tm_eupd != 32 || !c->fuse_head || cf.n_recycles > 1) return false;
-    if (cf.update_after[npq - 1] < 0) return false;                       // the convolution after the slab ones would read ef
-    for (int i = npq; i < cf.n_convs; ++i) if (cf.update_after[i] >= 0) return true;      // a later EdgeUpdate exists: the first one is not the last
-    return false;
-}
-
 // ---------------------------------------------------------------------------------------- one network evaluation
 template <int V, int TE, int TN, int HX>
 int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
@@ -423,7 +411,6 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     // pair-slab convolutions of this evaluation (first pass only; FmMlpArgs::slabQ0): self-conditioned evaluations with at least four rounds of
     // 32-row pair tiles (measured neutral on small batches: the table costs a kernel phase, the saving is matrix-pipe time they are not bound by)
     const int n_pq = (HX == 0 && prev && !dense) ? pq_convs(c, U) : 0;
-    bool pair_rows = false;      // the self-conditioning layer wrote its rows per pair (c->efp): the first EdgeUpdate gathers them
     FmMlpArgs ma{};
     ma.na = c->na; ma.nc = c->nc; ma.ne = c->ne;
     ma.rbf_mu_step = c->rbf_mu_step; ma.rbf_inv_sigma = c->rbf_inv_sigma;
@@ -457,9 +444,6 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         if (n_pq > 0) {      // the self-conditioning layer produces the edge features the first convolutions see: their pair slab in the same kernel
             e.slabW0 = c->conv[0].Ws_slab; e.slabQ0 = c->Q[0];
             if (n_pq > 1) { e.slabW1 = c->conv[1].Ws_slab; e.slabQ1 = c->Q[1]; }
-            // ... and, while only slab convolutions stand between it and the first EdgeUpdate, its rows once per pair (unless a tap asks for the full ef of this stage)
-            pair_rows = pair_rows_ok(c, U) && !(taps_on && c->taps.count("sc.ef"));
-            if (pair_rows) e.out_pair = c->efp;
         }
         FmMlp4Args a4{};
         a4.N = N; a4.W1q = c->sc_node_W1q; a4.b1 = c->sc_node.b1; a4.W2q = c->sc_node_W2q; a4.b2 = c->sc_node.b2;
@@ -607,9 +591,6 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
                 eu.hW1 = c->edge_head.W1; eu.hb1 = c->edge_head.b1; eu.hW2 = c->edge_head.W2; eu.hb2 = c->edge_head.b2; eu.out_e = out->e; eu.ne = c->ne;
                 L("edge_update_head", fm_k_edge_update<32, false, true>, dim3((U + 15) / 16), blk, lds_edge_upd(32), eu);
                 head_done = true;
-            } else if (pair_rows && it == n_pq - 1) {
-                eu.ef_pair = c->efp;
-                L("edge_update", fm_k_edge_update<32, false, false, true>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             } else if (c->F != 128) L("edge_update", fm_k_edge_update<32, true>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             else if (c->tm_eupd == 32) L("edge_update", fm_k_edge_update<32, false>, dim3((E + 31) / 32), blk, lds_edge_upd(32), eu);
             else L("edge_update", fm_k_edge_update<64, false>, dim3((E + 63) / 64), blk, lds_edge_upd(64), eu);
@@ -1080,7 +1061,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
     set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
-    set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32)); set_lds(fm_k_edge_update<32, false, true>, lds_edge_upd(32)); set_lds(fm_k_edge_update<32, false, false, true>, lds_edge_upd(32));
+    set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32)); set_lds(fm_k_edge_update<32, false, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
     set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_EDGE, 32>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_EDGE_HEAD, 32>, mlp_max);
@@ -1111,7 +1092,7 @@ struct WsLayout {
     int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node, node_rg;
     size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_Psd, off_PVd, off_stab, off_bx, off_ba,
-        off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, off_Q0, off_Q1, off_efp, total;
+        off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, off_Q0, off_Q1, total;
 };
 
 static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
@@ -1171,7 +1152,6 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     w.off_sa1 = take((size_t)N * 4); w.off_sc1 = take((size_t)N * 4); w.off_se1 = take((size_t)w.U * 4);
     const int npq = pq_convs(c, w.U);      // the pair-slab tables are as large as `ef` each: only batches that use them pay for them (8192 x 47 atoms: 13.3 GB without, 31.5 GB with)
     w.off_Q0 = take(npq > 0 ? (size_t)w.U * 256 * 4 : 0); w.off_Q1 = take(npq > 1 ? (size_t)w.U * 256 * 4 : 0);
-    w.off_efp = take(pair_rows_ok(c, w.U) ? (size_t)w.U * 128 * 4 : 0);
     w.total = o;
     return FM_OK;
 }
@@ -1249,7 +1229,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     c->tap_s = (float*)(base + w.off_tap_s); c->tap_v = (float*)(base + w.off_tap_v);
     c->mol_gid = (int*)(base + w.off_gid);
     c->sa1 = (int32_t*)(base + w.off_sa1); c->sc1 = (int32_t*)(base + w.off_sc1); c->se1 = (int32_t*)(base + w.off_se1);
-    c->Q[0] = (float*)(base + w.off_Q0); c->Q[1] = (float*)(base + w.off_Q1); c->efp = (float*)(base + w.off_efp);
+    c->Q[0] = (float*)(base + w.off_Q0); c->Q[1] = (float*)(base + w.off_Q1);
     c->n_tiles_e = (w.E + FM_TM - 1) / FM_TM; c->n_tiles_n = (w.N + FM_TM - 1) / FM_TM; c->n_tiles_u = (w.U + FM_TM - 1) / FM_TM;
     Launch L{c, st};
     const int work = w.E > w.N ? w.E : w.N;

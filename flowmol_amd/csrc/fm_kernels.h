@@ -103,10 +103,6 @@ struct FmMlpArgs {
     // first one or two convolutions -> Q0 / Q1 (U,256), which the PQ instances of fm_k_edge_message gather like the hoisted Ps[src]:
     // 40,960 of 248,064 executed MAC per edge leave the edge kernel for 20,480 per edge here.  null = off
     const float2* slabW0; float* slabQ0; const float2* slabW1; float* slabQ1;
-    // SC_EDGE, pair rows: when every convolution before the first EdgeUpdate is a pair-slab instance, nobody reads the edge features between this layer and that
-    // EdgeUpdate -- and the two directed edges of a pair carry the same row -- so the row is written ONCE, per pair, to out_pair (U,128) and the first
-    // EdgeUpdate gathers it by pair id (FmEdgeUpdArgs::ef_pair): 512 instead of 1024 bytes stored per pair.  null = rows to both directed edges of `out`
-    float* out_pair;
     // TABLE, several tables in one launch (the embedding tables of a whole chunk of integration steps): workgroup b builds tile
     // b % tab_tiles of table b / tab_tiles, whose time embedding is temb + table * tt and whose rows start at out + table * tab_stride
     int tab_tiles; int tab_stride;
@@ -302,11 +298,8 @@ __device__ __forceinline__ void fm_mlp2_tile(const FmMlpArgs& a, int tile, float
                 const float4 t = *reinterpret_cast<const float4*>(a.ef_tab + tok * 128 + c);
                 const float4 x = *reinterpret_cast<const float4*>(X + r * a.ldx + c);
                 const float4 o = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
-                if (a.out_pair) *reinterpret_cast<float4*>(a.out_pair + (size_t)grow * 128 + c) = o;
-                else {
-                    *reinterpret_cast<float4*>(a.out + (size_t)ea * 128 + c) = o;
-                    *reinterpret_cast<float4*>(a.out + (size_t)eb * 128 + c) = o;
-                }
+                *reinterpret_cast<float4*>(a.out + (size_t)ea * 128 + c) = o;
+                *reinterpret_cast<float4*>(a.out + (size_t)eb * 128 + c) = o;
                 if (slab) *reinterpret_cast<float4*>(Hb + r * a.ldh + 32 + c) = o;      // the hidden layer is dead: its tile receives [rbf | ef]
             }
         }
@@ -1242,18 +1235,14 @@ struct FmEdgeUpdArgs {
     const float2* hW1; const float* hb1;    // K = 128, N = 128
     const float2* hW2; const float* hb2;    // K = 128, N = 16 (ne real columns)
     float* out_e; int ne;                   // (U, ne) bond-order probabilities
-    // PAIRIN instances (the evaluation's FIRST EdgeUpdate behind pair-slab convolutions): the input rows come from the per-pair table the self-conditioning
-    // layer wrote (FmMlpArgs::out_pair), gathered by e_pair; the updated rows go to ef as always
-    const float* ef_pair;
 };
 
 // HEAD = false: a tile is TM consecutive directed edges (internal order).  HEAD = true (TM = 32): a tile is 16 consecutive unordered pairs, rows 2k / 2k + 1 =
 // the pair's two directed edges (src < dst first, the reference's upper edge): same per-row arithmetic, rows gathered instead of streamed, and the epilogue
 // is the edge head of those 16 pairs instead of the store of the rows.
-template <int TM, bool NARROW, bool HEAD = false, bool PAIRIN = false>
+template <int TM, bool NARROW, bool HEAD = false>
 __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) {
     static_assert(!HEAD || (TM == 32 && !NARROW), "the fused edge head exists for 32-row tiles of full-width models");
-    static_assert(!PAIRIN || (TM == 32 && !NARROW && !HEAD), "the pair-row input exists for 32-row tiles of full-width models");
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int LDX = 164, LDH = 132, MT = TM / 16, LPR = FM_THREADS / TM;
     float* X = lds;                       // [TM][164]: ef(128) | rbf(32)
@@ -1268,20 +1257,11 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
     // zero-fills the rows of a ragged last tile on load and drops them on the final store.
     const int left = a.b.E - e0;
     const auto rs_ef = fm_buf(a.ef + (size_t)(HEAD ? 0 : e0) * 128, HEAD ? 0u : (unsigned)(left < TM ? left : TM) * 512u);
-    if constexpr (!HEAD && !PAIRIN) {
+    if constexpr (!HEAD) {
 #pragma unroll
         for (int k = 0; k < NEF; ++k) efv[k] = fm_buf_f32x4(rs_ef, tid * 16 + k * FM_THREADS * 16, 0);
     }
-    int* m_eoff = reinterpret_cast<int*>(m_d + TM);           // HEAD / PAIRIN: [TM] byte offset of the row's source row relative to the tile's smallest edge / pair id, [TM] = that id
-    if (PAIRIN && tid < 64) {
-        const int e = e0 + tid;
-        const int pr = (tid < TM && e < a.b.E) ? a.b.e_pair[e] : 0x7fffffff;
-        int mn = pr;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
-        if (tid < TM) m_eoff[tid] = pr != 0x7fffffff ? (pr - mn) * 512 : FM_BUF_OOB;
-        if (tid == 0) m_eoff[TM] = mn;
-    }
+    int* m_eoff = reinterpret_cast<int*>(m_d + TM);           // HEAD: [TM] byte offset of the row's edge in ef relative to the tile's smallest edge id, [TM] = that id
     if (HEAD && tid < 64) {
         const int p = blockIdx.x * (TM / 2) + (tid >> 1);
         const int e = (tid < TM && p < a.b.U) ? ((tid & 1) ? a.b.p_e1[p] : a.b.p_e0[p]) : 0x7fffffff;
@@ -1309,9 +1289,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
         m_soff[tid] = s >= 0 ? s * 1024 : FM_BUF_OOB; m_doff[tid] = s >= 0 ? d * 1024 : FM_BUF_OOB; m_d[tid] = dist;
     }
     __syncthreads();
-    if constexpr (HEAD || PAIRIN) {       // the rows of the tile's edges (HEAD) / pairs (PAIRIN), gathered: 16-byte loads, all of a thread's requests back to back (rows without an edge read 0)
+    if constexpr (HEAD) {       // the rows of the tile's edges, gathered: 16-byte loads, all of a thread's requests back to back (rows without a pair read 0)
         const int emin = __builtin_amdgcn_readfirstlane(m_eoff[TM]);
-        const auto rs_g = fm_buf((PAIRIN ? a.ef_pair : a.ef) + (size_t)(emin == 0x7fffffff ? 0 : emin) * 128, 0x7ffffe00u);
+        const auto rs_g = fm_buf(a.ef + (size_t)(emin == 0x7fffffff ? 0 : emin) * 128, 0x7ffffe00u);
 #pragma unroll
         for (int k = 0; k < NEF; ++k) {
             const int idx = tid + k * FM_THREADS;

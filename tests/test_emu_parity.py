@@ -441,11 +441,6 @@ def test_pair_slab_hoist_on_emulation(emu_lib, name, sizes, prev):
         bad = {k: v for k, v in errs.items() if not v < 2e-5}
         assert not bad, (flag, bad)
         outs[flag] = {k: v.clone() for k, v in out.items()}
-        if flag >= 1:
-            # without the `sc.ef` tap the self-conditioning layer writes its rows once per PAIR and the first EdgeUpdate gathers them (round 5): pure data
-            # movement, so the outputs must equal the tapped run's bit for bit
-            _, out2, _ = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), 0.5, prev, taps=False)
-            assert all(torch.equal(out2[k], outs[flag][k]) for k in 'xace'), flag
     for k in 'xace':
         torch.testing.assert_close(outs[1][k], outs[-1][k], rtol=1e-4, atol=2e-6)
     same = all(torch.equal(outs[1][k], outs[-1][k]) for k in 'xace')
