@@ -196,7 +196,11 @@ def test_teacher_forced_decisions_differ_from_the_reference_only_at_near_ties(go
     res = audit_long_decisions(cfg, g, traj, probs)
     _report(f'teacher_forced_audit[{tag},{tuning}]', {k: v for k, v in res.items()})
     assert not res['unexplained'], res['unexplained'][:5]
-    assert len(res['events']) <= 8, res['events']
+    # the measured constants of this library (profiles/r05b_gpu_parity_report.jsonl): of the 20,185,683 decisions of the 64-molecule fixture ONE differs --
+    # step 113, a charge row of molecule 31 whose purity sits 1.8e-7 (3 ulp) above the 0.9 threshold -- plus, with the pair slab forced on, one sampled
+    # charge token at step 79 (margin 2.7e-6); none of the 4,733,490 decisions of the position-heads fixture.  The arithmetic is
+    # deterministic, so the bound is the measured count.
+    assert len(res['events']) <= (0 if 'pos128' in tag else 2 if tuning else 1), res['events']
     x = traj['x'][-1].cpu()
     assert float((x - g['x_1']).abs().max() / g['x_1'].abs().max()) < 1e-4
     eng.close()
