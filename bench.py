@@ -657,9 +657,9 @@ def main():
     ap.add_argument('--timesteps', type=int, default=None)
     ap.add_argument('--preset', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', choices=('f32', 'bf16x3'), default='f32',
+    ap.add_argument('--precision', choices=('f32', 'bf16x3', 'bf16x6'), default='f32',
                     help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
-                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) -- a separately reported mode")
+                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) / 'bf16x6' (hi+mid+lo, six products, edge messages only) -- separately reported modes")
     ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (size distribution, C2, C5, latency sweep) of the default one-GPU run')
     ap.add_argument('--secondary-steps', type=int, default=10, help='timed steps of the size-distribution leg (C2 / C5: 4x, latency sweep: 64)')
@@ -796,19 +796,20 @@ def main():
     pmc = load_pmc(args.workload, N, E, args.size_dist is None and args.precision == 'f32' and world == 1)
     ex = executed_macs(cfg, U, torch.cuda.get_device_properties(dev).multi_processor_count)
     roofline = None
-    if 'edge_message' in kern and args.precision == 'bf16x3':
+    if 'edge_message' in kern and args.precision in ('bf16x3', 'bf16x6'):
         # opt-in mode: the scalar and gate GEMMs issue 3 bf16 products per term on padded K (7 / 10 / 10 k32 blocks); the vector path stays f32
         us = kern['edge_message']['raw_event_pair_us']
         V = cfg.n_vec_channels
         ku0 = (V + 1 + 4 + 7) // 8 * 8
         kb = [(160 + ku0 + 31) // 32, (256 + V + 8 + 31) // 32, (256 + V + 8 + 31) // 32]
-        bf16_mac = 3 * (sum(k * 32 * 256 for k in kb) + 3 * 256 * V)
+        n_prod = 3 if args.precision == 'bf16x3' else 6          # products per term: hi*hi + hi*lo + lo*hi | + hi*mid, mid*hi, mid*mid (three-term split)
+        bf16_mac = n_prod * (sum(k * 32 * 256 for k in kb) + 3 * 256 * V)
         f32_mac = 3 * (V + 8) * V * 3 + 2 * 3 * V * (V + 16)
         roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message (split precision)', 'unit': 'TFLOP/s', 'peak': BF16_PEAK_TFLOPS,
                     'achieved': 2 * bf16_mac * E / (us * 1e-6) / 1e12, 'frac': 2 * bf16_mac * E / (us * 1e-6) / 1e12 / BF16_PEAK_TFLOPS,
                     'traffic': None, 'avg_launch_us': us, 'executed_bf16_flop_per_launch': 2 * bf16_mac * E, 'executed_f32_flop_per_launch': 2 * f32_mac * E,
                     'f32_equivalent_tflops': conv_message_flops_per_edge(V) * E / (us * 1e-6) / 1e12,
-                    'note': 'OPT-IN split precision, not the headline: achieved = bf16 MFMA FLOPs actually issued (3 products per term) against the dense bf16 peak; the '
+                    'note': f'OPT-IN split precision ({args.precision}), not the headline: achieved = bf16 MFMA FLOPs actually issued ({n_prod} products per term) against the dense bf16 peak; the '
                             'kernel is bound by the L1/L2 weight stream, the f32 vector-path GEMMs and VALU, not by the bf16 pipe. f32_equivalent_tflops = the reference '
                             'FLOP count of the op / launch time (exceeds the f32 peak because the work is not done in f32).'}
     elif 'edge_message' in kern:
@@ -825,7 +826,8 @@ def main():
     out = {
         'metric': (f'molecules/sec at {T} timesteps ' + ('(GEOM-drugs-sized graphs)' if args.workload == 'c3' else f'[secondary workload {args.workload}]')) + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else 'bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else ('bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)' if args.precision == 'bf16x3' else
+                                                         'bf16x6 three-term split precision of the edge-message GEMMs (opt-in; f32 operands as hi+mid+lo bf16, 6 products per term, f32 accumulate; node kernels and EdgeUpdate f32)'), 'data': 'synthetic',
         'config': {'workload': f'{args.preset} model, {B} molecules/GPU x ' + (f'{n} atoms' if not ragged else (f'sizes ~ {args.size_dist} histogram' if args.size_dist else 'sizes randint(5, 61, seed 0)') + f' (mean {float(all_sizes.double().mean()):.1f}, max {int(all_sizes.max())}; ONE global list dealt to the ranks by shard.partition_lpt)') + f', n_timesteps={T} '
                                f"({wl['label']})",
                    'shard_cost_max_over_mean': float(shard_cost.max() / shard_cost.mean()), 'molecules_per_rank': [int(len(p_)) for p_ in parts],

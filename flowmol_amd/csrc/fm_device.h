@@ -545,6 +545,86 @@ __device__ __forceinline__ void fm_wave_gemm_sp(f32x4 (&acc)[MT][NT], const unsi
 }
 
 // ---------------------------------------------------------------------------------------------
+// Opt-in THREE-term split ("bf16x6", edge-message kernel only; VERDICT r4 #5: can the f32 roof be beaten at f32-class accuracy?): every f32 value v is
+// carried as hi + mid + lo, three bf16 = all 24 mantissa bits (the residual after three round-to-nearest steps is <= 2^-27 |v|), every product as
+// hi*hi + (hi*mid + mid*hi) + (hi*lo + mid*mid + lo*hi) in f32 accumulators; the three dropped products are <= 3 * 2^-24 |ab| -- f32 rounding class (a
+// K = 296 GEMM measured on the host: rms error 1.2e-7 against f64, plain f32 3.1e-7, the two-term mode 4.4e-6).  The price: six matrix instructions per
+// k32 block instead of three, three planes per operand -- 6 bytes per weight in the stream and per activation in LDS, which at 32-row tiles leaves room
+// for ONE workgroup per CU.  Planes are consecutive: plane k of a tile = XH + k * (XL - XH).
+// ---------------------------------------------------------------------------------------------
+template <int LDP = FM_LDP>
+__device__ __forceinline__ void fm_split3_store(unsigned short* XH, unsigned short* XL, int row, int col, float v) {
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;                  // exact
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);       // exact subtraction, one rounding
+    unsigned short* X2 = XL + (XL - XH);
+    XH[row * LDP + col] = __builtin_bit_cast(unsigned short, h);
+    XL[row * LDP + col] = __builtin_bit_cast(unsigned short, m);
+    X2[row * LDP + col] = __builtin_bit_cast(unsigned short, l);
+}
+template <int MT, int NT, int LDP>
+__device__ __forceinline__ void fm_sp3_frag_load(fm_h8 (&a)[3][MT], fm_h8 (&b)[3][NT], const unsigned short* ap, int pstride, const void* wsp, int ntiles, int nt0, int kb, int lane) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[p][mt] = *(const volatile __attribute__((address_space(3))) fm_h8*)(ap + p * pstride + mt * 16 * LDP + kb * 32);
+    const auto rs = fm_buf(wsp);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int e = ((kb * ntiles + nt0 + nt) * 3) * 64 * 16;          // bytes: entry (kb, tile, plane 0); the planes of an entry are 1 KB apart
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p][nt] = fm_buf_h8(rs, lane * 16, e + p * 64 * 16);
+    }
+}
+// The five correction products -- 2^-8 ... 2^-16 of the result -- go to an accumulator of their own (accs), only hi * hi to the main one: a rounding of accs is
+// 2^-8 of a rounding of the full sum, so the split result carries one full-magnitude rounding per k32 block like an f32 chain carries one per k
+template <int MT, int NT>
+__device__ __forceinline__ void fm_sp3_frag_mma(f32x4 (&acc)[MT][NT], f32x4 (&accs)[MT][NT], const fm_h8 (&a)[3][MT], const fm_h8 (&b)[3][NT]) {
+    constexpr int PA[5] = {2, 0, 1, 1, 0}, PB[5] = {0, 2, 1, 0, 1};          // (lo, hi), (hi, lo), (mid, mid), (mid, hi), (hi, mid): smallest first
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = fm_mfma_bf16(a[PA[q]][mt], b[PB[q]][nt], accs[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(a[0][mt], b[0][nt], acc[mt][nt]);
+}
+// acc += A (three planes XH, XL, XL + (XL - XH); rows row0.., KB k32 blocks) * W (three-plane packing, column tiles nt0 .. nt0 + NT - 1)
+template <int MT, int NT, int LDP = FM_LDP>
+__device__ __forceinline__ void fm_wave_gemm_sp3(f32x4 (&acc)[MT][NT], const unsigned short* XH, const unsigned short* XL, int row0, int KB,
+                                                 const void* wsp, int ntiles, int nt0, int lane) {
+    const unsigned short* ap = XH + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
+    const int pstride = (int)(XL - XH);
+    fm_h8 a0[3][MT], b0[3][NT], a1[3][MT], b1[3][NT];
+    f32x4 accs[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fm_sp3_frag_load<MT, NT, LDP>(a0, b0, ap, pstride, wsp, ntiles, nt0, 0, lane);
+    int kb = 0;
+    for (; kb + 2 <= KB; kb += 2) {
+        fm_sp3_frag_load<MT, NT, LDP>(a1, b1, ap, pstride, wsp, ntiles, nt0, kb + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        fm_sp3_frag_mma<MT, NT>(acc, accs, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < KB) fm_sp3_frag_load<MT, NT, LDP>(a0, b0, ap, pstride, wsp, ntiles, nt0, kb + 2, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        fm_sp3_frag_mma<MT, NT>(acc, accs, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kb < KB) fm_sp3_frag_mma<MT, NT>(acc, accs, a0, b0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += accs[mt][nt];
+}
+
+// ---------------------------------------------------------------------------------------------
 // One Geometric Vector Perceptron on a 64-row tile (reference flowmol/models/gvp.py:90-133)
 // ---------------------------------------------------------------------------------------------
 struct FmGvpW {
@@ -679,7 +759,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(0 * TM + r) * T::LDVH + H + p] = cx;
         Vh[(1 * TM + r) * T::LDVH + H + p] = cy;
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
-        if (SP) fm_split_store(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
+        if (SP == 2) fm_split3_store(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
+        else if (SP) fm_split_store(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
         else X[r * FM_LDX + SOFF + H + CPS * p] = fm_norm3(cx, cy, cz);
     }
     // thread -> (row, 16-column group): no integer division by V+8 in the index math
@@ -691,10 +772,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 const float vx = Vh[(0 * TM + r) * T::LDVH + c];
                 const float vy = Vh[(1 * TM + r) * T::LDVH + c];
                 const float vz = Vh[(2 * TM + r) * T::LDVH + c];
-                if (SP) fm_split_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
+                if (SP == 2) fm_split3_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
+                else if (SP) fm_split_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
                 else X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
             } else if (FIRST ? (c >= H + 4 && c < KUC) : (c < KUC && ((c - H) & 1))) {      // K padding (first GVP) / the odd slots between the cross-product norms
-                if (SP) { XH[r * FM_LDP + SOFF + c] = 0; XL[r * FM_LDP + SOFF + c] = 0; }
+                if (SP) { XH[r * FM_LDP + SOFF + c] = 0; XL[r * FM_LDP + SOFF + c] = 0; if (SP == 2) XL[TM * FM_LDP + r * FM_LDP + SOFF + c] = 0; }
                 else X[r * FM_LDX + SOFF + c] = 0.f;
             }
         }
@@ -751,7 +833,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = FIRST ? pre[i][j][r] + bias : bias;
         }
         FM_MARKB(2);
-        if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
+        if (SP == 2) fm_wave_gemm_sp3<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane);
+        else if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
         else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW, !FIRST>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
@@ -765,7 +848,8 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                     for (int r = 0; r < 4; ++r) {
                         const float y = fm_silu(acc[i][j][r]);
                         if constexpr (SP && LAST) keep[i][j][r] = y;
-                        fm_split_store(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
+                        if (SP == 2) fm_split3_store(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
+                        else fm_split_store(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
                     }
         } else {
             float* xo = X + (4 * (lane >> 4)) * FM_LDX + NTW * wave * 16 + (lane & 15);
@@ -798,7 +882,9 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         f32x4 g;
         if (SP) {
             f32x4 ga[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
-            fm_wave_gemm_sp<1, 1>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
+            if (SP == 2) fm_wave_gemm_sp3<1, 1>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
+                                                static_cast<const char*>(w.Wg_sp) + (size_t)half * (8 / KS) * (VOP / 16) * 3 * 64 * 16, VOP / 16, n0, lane);
+            else fm_wave_gemm_sp<1, 1>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
                                   static_cast<const char*>(w.Wg_sp) + (size_t)half * (8 / KS) * (VOP / 16) * 2 * 64 * 16, VOP / 16, n0, lane);
             g = ga[0][0];
         } else {

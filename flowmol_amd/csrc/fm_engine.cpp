@@ -197,18 +197,20 @@ inline uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 inline float bf16_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
-std::vector<float> pack_sp(int K, int N, const std::function<float(int, int)>& w) {
+std::vector<float> pack_sp(int K, int N, const std::function<float(int, int)>& w, int npl = 2) {      // npl planes: hi, lo (| hi, mid, lo of the three-term mode)
     const int KB = K / 32, NT = N / 16;
-    std::vector<uint16_t> out((size_t)KB * NT * 2 * 64 * 8);
+    std::vector<uint16_t> out((size_t)KB * NT * npl * 64 * 8);
     for (int kb = 0; kb < KB; ++kb)
         for (int nt = 0; nt < NT; ++nt)
             for (int lane = 0; lane < 64; ++lane)
                 for (int q = 0; q < 8; ++q) {
-                    const float v = w(32 * kb + 8 * (lane >> 4) + q, 16 * nt + (lane & 15));
-                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_f32(hi));
-                    const size_t e = (((size_t)kb * NT + nt) * 2) * 64 * 8;
-                    out[e + (size_t)lane * 8 + q] = hi;
-                    out[e + 64 * 8 + (size_t)lane * 8 + q] = lo;
+                    float r = w(32 * kb + 8 * (lane >> 4) + q, 16 * nt + (lane & 15));
+                    const size_t e = (((size_t)kb * NT + nt) * npl) * 64 * 8;
+                    for (int p_ = 0; p_ < npl; ++p_) {
+                        const uint16_t h = bf16_rne(r);
+                        out[e + (size_t)p_ * 64 * 8 + (size_t)lane * 8 + q] = h;
+                        r -= bf16_f32(h);          // exact in f32
+                    }
                 }
     std::vector<float> f(out.size() / 2);
     memcpy(f.data(), out.data(), out.size() * 2);
@@ -233,13 +235,13 @@ void pack_linear(Builder& B, const float2*& slot, const float* W, int out, int i
     }));
 }
 // the same logical matrix as pack_linear, K padded to a multiple of 32, as split-precision planes
-void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, int Np, const std::function<int(int)>& kmap) {
+void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, int Np, const std::function<int(int)>& kmap, int npl = 2) {
     const int K32 = (Kp + 31) / 32 * 32;
     B.putv(slot, pack_sp(K32, Np, [&](int k, int n) -> float {
         if (n >= out || k >= Kp) return 0.f;
         const int kk = kmap(k);
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
-    }));
+    }, npl));
 }
 void pack_linear4(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, const std::function<int(int)>& kmap, int G = 4) {
     B.putv(slot, pack4(Kp, [&](int k, int n) -> float {
@@ -255,7 +257,7 @@ void pad_vec(Builder& B, const float*& slot, const float* v, int n, int np) {
 }
 
 // one non-first GVP (vin = V, hidden = V, S real scalar channels in a 256-wide tile): reference gvp.py:30-88 parameter shapes
-bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g, bool sp = false, bool rows4 = false) {
+bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vout, FmGvpW& g, int sp = 0 /* bf16 planes of the split-precision copies: 0 | 2 | 3 */, bool rows4 = false) {
     const int vop = vout < 16 ? 16 : vout;
     const float* Wh = bl.get(key + ".Wh", V, V);
     const float* Wcp = bl.get(key + ".Wcp", V, 8);
@@ -282,8 +284,8 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vo
     pack_linear(B, g.Wg, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
     pad_vec(B, g.bg, bg, vout, vop);
     if (sp) {
-        pack_linear_sp(B, g.Ws_sp, Ws, S, V + 4 + S, 256 + V + 8, 256, kmap_s);
-        pack_linear_sp(B, g.Wg_sp, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; });
+        pack_linear_sp(B, g.Ws_sp, Ws, S, V + 4 + S, 256 + V + 8, 256, kmap_s, sp);
+        pack_linear_sp(B, g.Wg_sp, Wg, vout, S, 256, vop, [&](int k) { return k < S ? k : -1; }, sp);
     }
     return true;
 }
@@ -291,8 +293,8 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vo
 template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
 int pvw_of(int V, int HX) { return (pad8(V + 1 + HX + 4) + 8 + 15) / 16 * 16; }     // FmGvpTile::PVW
-size_t lds_gvp_sp(int V, int TM) {       // split-precision edge message: bf16 planes instead of the f32 scalar tile, gates inside Vh
-    size_t fl = (size_t)TM * FM_LDP + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, 0) + 4);
+size_t lds_gvp_sp(int V, int TM, int npl = 2) {       // split-precision edge message: npl bf16 planes instead of the f32 scalar tile, gates inside Vh
+    size_t fl = (size_t)TM * FM_LDP * npl / 2 + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, 0) + 4);
     return fl * 4 + (size_t)TM * 9 * 4;
 }
 size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
@@ -511,6 +513,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
         if constexpr (HX == 0) {
             if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
+            else if (cf.precision == FM_PREC_BF16X6) {
+                if constexpr (TE <= 32) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 2>, gmsg, dim3(512), lds_gvp_sp(V, TE, 3), m);
+                else return fail(c, FM_ERR_INVALID, "the three-term split precision runs 16- or 32-row edge tiles (three planes of a 64-row tile exceed the LDS)");
+            }
             else if (it < n_pq) {
                 m.Q = c->Q[it]; m.g0.Ws = cw.Ws_sh;          // GVP0's scalar GEMM: K = KU0 (hidden-vector norms); the rest arrives through Q
                 L("edge_message_pq", fm_k_edge_message<V, TE, 512, 0, 0, 1>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
@@ -771,8 +777,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if ((HX > 0) != (SD > 0) || HX < 0 || HX > 8 || SD > 256 || (HX > 0 && HX != V / 4))
         { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: destination-feature widths must be both 0 or v = n_vec_channels/4 (<= 8), s <= 256"); }
     const int H0 = V + 1 + HX, KU0 = pad8(H0 + 4), PVW = c->PVW = pvw_of(V, HX);
-    if (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_BF16X3) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: unknown precision %d", cfg->precision); }
-    if (cfg->precision == FM_PREC_BF16X3 && HX > 0) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: split precision is built for models without destination features"); }
+    if (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_BF16X3 && cfg->precision != FM_PREC_BF16X6) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: unknown precision %d", cfg->precision); }
+    if (cfg->precision != FM_PREC_F32 && HX > 0) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: split precision is built for models without destination features"); }
     const int na = c->na = cfg->n_atom_types, nc = c->nc = cfg->n_charges, ne = c->ne = cfg->n_bond_types;
     c->rbf_mu_step = cfg->rbf_dmax / (float)(cfg->rbf_dim - 1);
     c->rbf_inv_sigma = 1.0f / (cfg->rbf_dmax / (float)cfg->rbf_dim);
@@ -845,7 +851,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
         c->sc_node.K1p = pad8(kinp); c->sc_node.H = 256; c->sc_node.O = 256;
         pack_linear(B, c->sc_node.W1, W1, S, kin, pad8(kinp), 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : S + (k - 256); });
-        if (S == 256 && HX == 0 && cfg->precision == FM_PREC_F32) {      // 4-row node tiles of small batches (fm_k_mlp4): K padded to 320, quad-row packed
+        if (S == 256 && HX == 0 && cfg->precision != FM_PREC_BF16X3) {      // 4-row node tiles of small batches (fm_k_mlp4): K padded to 320, quad-row packed
             pack_linear4(B, c->sc_node_W1q, W1, S, kin, 320, [&](int k) { return k < 256 ? k : (k - 256 < na + nc + 32 ? S + (k - 256) : -1); });
             pack_linear4(B, c->sc_node_W2q, W2, S, S, 256, ident);
         }
@@ -908,13 +914,14 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         pad_vec(B, g0.bs, bs, S, 256);
         pack_linear(B, g0.Wg, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
         pad_vec(B, g0.bg, bg, V, V);
-        const bool sp = cfg->precision == FM_PREC_BF16X3;
-        if (sp) {
+        const bool sp = cfg->precision == FM_PREC_BF16X3;                                     // split-precision NODE / EdgeUpdate kernels: the two-term mode only
+        const int sp_msg = cfg->precision == FM_PREC_BF16X3 ? 2 : cfg->precision == FM_PREC_BF16X6 ? 3 : 0;      // bf16 planes of the edge-message GEMM operands
+        if (sp_msg) {
             pack_linear_sp(B, g0.Ws_sp, Ws, S, kin0, 160 + KU0, 256, [&](int k) {
                 if (k < 32) return S + k;
                 if (k < 160) return k - 32 < F ? S + 32 + (k - 32) : -1;
-                return k < 160 + H0 + 4 ? S + 32 + F + SD + (k - 160) : -1; });
-            pack_linear_sp(B, g0.Wg_sp, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
+                return k < 160 + H0 + 4 ? S + 32 + F + SD + (k - 160) : -1; }, sp_msg);
+            pack_linear_sp(B, g0.Wg_sp, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; }, sp_msg);
         }
         if (HX > 0) {
             // destination-node terms of the first edge GVP, hoisted per node: vectors through [Wh | Wcp] rows V+1.., scalars through Ws columns S+32+F..
@@ -934,9 +941,9 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             pack_linear(B, dp.Wg, pWg, HX, SD, 256, 16, [&](int k) { return k < SD ? k : -1; });
             pad_vec(B, dp.bg, pbg, HX, 16);
         }
-        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g], sp)) return bail(bl.err);
+        for (int g = 1; g < 3; ++g) if (!pack_gvp(B, bl, p + "edge_message." + std::to_string(g), V, S, V, cw.msg[g], sp_msg)) return bail(bl.err);
         const bool rows4 = S == 256 && HX == 0 && !sp;       // 4-node tiles exist for full-width f32 models on the fused node sequence
-        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g], sp, rows4)) return bail(bl.err);
+        for (int g = 0; g < 3; ++g) if (!pack_gvp(B, bl, p + "node_update." + std::to_string(g), V, S, V, cw.upd[g], sp ? 2 : 0, rows4)) return bail(bl.err);
         if (rows4) pack_linear4(B, cw.Wps4, Ws, S, kin0, 256, [&](int k) { return k < S ? k : -1; });
         if (sp) pack_linear_sp(B, cw.Wps_sp, Ws, S, kin0, 256, 256, [&](int k) { return k < S ? k : -1; });
         const float* l1g = bl.get(p + "message_layer_norm.feat_norm.weight", S); const float* l1b = bl.get(p + "message_layer_norm.feat_norm.bias", S);
@@ -955,7 +962,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         const std::string p = "node_position_updaters." + std::to_string(u) + ".gvps.";
         const bool spu = cfg->precision == FM_PREC_BF16X3;
         const bool rows4u = S == 256 && HX == 0 && !spu;
-        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu, rows4u) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu, rows4u) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu, rows4u))
+        if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu ? 2 : 0, rows4u) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu ? 2 : 0, rows4u) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu ? 2 : 0, rows4u))
             return bail(bl.err);
         const std::string q = "edge_updaters." + std::to_string(u) + ".";
         const bool with_d = !cfg->edge_update_no_distance;
@@ -998,7 +1005,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         c->node_head.K1p = 256; c->node_head.H = 256; c->node_head.O = pad16(na + nc);
         pack_linear(B, c->node_head.W1, W1, S, S, 256, 256, ident); pad_vec(B, c->node_head.b1, b1, S, 256);
         pack_linear(B, c->node_head.W2, W2, na + nc, S, 256, pad16(na + nc), ident); pad_vec(B, c->node_head.b2, b2, na + nc, pad16(na + nc));
-        if (S == 256 && HX == 0 && cfg->precision == FM_PREC_F32) {
+        if (S == 256 && HX == 0 && cfg->precision != FM_PREC_BF16X3) {
             pack_linear4(B, c->node_head_W1q, W1, S, S, 256, ident);
             pack_linear4(B, c->node_head_W2q, W2, na + nc, S, 256, ident, 1);      // N = 64 (na + nc <= 32 real columns): one column group, K over all eight waves
         }
@@ -1052,6 +1059,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
+    set_lds(fm_k_edge_message<32, 16, 512, 0, 2>, lds_gvp_sp(32, 16, 3)); set_lds(fm_k_edge_message<32, 32, 512, 0, 2>, lds_gvp_sp(32, 32, 3));
+    set_lds(fm_k_edge_message<16, 16, 512, 0, 2>, lds_gvp_sp(16, 16, 3)); set_lds(fm_k_edge_message<16, 32, 512, 0, 2>, lds_gvp_sp(16, 32, 3));
     set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
 #define FM_SET_RG(V_) set_lds(fm_k_node_update<V_, 16, false, 0, 1>, lds_gvp(V_, 16, false) + 4096); set_lds(fm_k_node_update<V_, 16, false, 0, 2>, lds_gvp(V_, 16, false) + 8192); \

@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     typedef FmGvpTile<V, TM, HX> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
-    float* Vin = X + (SP ? TM * FM_LDP : T::X_FLOATS);
+    float* Vin = X + (SP ? TM * FM_LDP * (SP + 1) / 2 : T::X_FLOATS);          // SP: SP + 1 bf16 planes of TM x FM_LDP
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = SP ? Vh + TM * FM_LDG : Vh + T::VH_FLOATS;
     int* m_src = reinterpret_cast<int*>(SP ? Vh + T::VH_FLOATS : G + T::G_FLOATS);   // [64]
@@ -793,18 +793,24 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         constexpr int Z0 = 160 + T::KU0, Z1 = 256 + T::KU;
         for (int idx = tid; idx < TM * 24; idx += NTH) {
             const int r = idx / 24, c = idx % 24;
-            if (Z0 + c < (Z0 + 31) / 32 * 32) { XH[r * FM_LDP + Z0 + c] = 0; XL[r * FM_LDP + Z0 + c] = 0; }
-            if (Z1 + c < 320) { XH[r * FM_LDP + Z1 + c] = 0; XL[r * FM_LDP + Z1 + c] = 0; }
+            if (Z0 + c < (Z0 + 31) / 32 * 32) { XH[r * FM_LDP + Z0 + c] = 0; XL[r * FM_LDP + Z0 + c] = 0; if (SP == 2) XL[TM * FM_LDP + r * FM_LDP + Z0 + c] = 0; }
+            if (Z1 + c < 320) { XH[r * FM_LDP + Z1 + c] = 0; XL[r * FM_LDP + Z1 + c] = 0; if (SP == 2) XL[TM * FM_LDP + r * FM_LDP + Z1 + c] = 0; }
         }
         for (int idx = tid; idx < TM * 32; idx += NTH) {
             const int r = idx >> 5, k = idx & 31;
-            fm_split_store(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
+            if (SP == 2) fm_split3_store(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
+            else fm_split_store(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
         }
 #pragma unroll
         for (int k = 0; k < NEF; ++k) {
             const int idx = tid + k * NTH, r = idx >> 5, c4 = idx & 31;
-            fm_split_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
-            fm_split_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
+            if (SP == 2) {
+                fm_split3_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split3_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
+                fm_split3_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split3_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
+            } else {
+                fm_split_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
+                fm_split_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
+            }
         }
     } else if constexpr (!PQ) {
     for (int idx = tid; idx < TM * 32; idx += NTH) {

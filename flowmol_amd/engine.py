@@ -205,14 +205,15 @@ class Engine:
 
     def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], device='cuda:0', prefix: str = '', lib=None, precision: Optional[str] = None,
                  tuning: Optional[Dict[str, int]] = None):
-        """``precision``: 'f32' (default, also for None; the reference's arithmetic) or 'bf16x3' (OPT-IN split precision of the edge-message
-        GEMMs on the bf16 matrix cores: faster, ~10x larger per-stage error, never used for parity claims).  It is an explicit argument
+        """``precision``: 'f32' (default, also for None; the reference's arithmetic), 'bf16x3' (OPT-IN split precision of the edge-message
+        GEMMs on the bf16 matrix cores: faster, ~10x larger per-stage error, never used for parity claims) or 'bf16x6' (OPT-IN three-term split of the
+        edge-message GEMMs only: f32-class accuracy on the bf16 matrix cores; round 5's measurement of whether that beats the f32 roof).  It is an explicit argument
         only -- no environment variable changes what an Engine computes -- and is recorded in ``self.precision``.
         ``tuning``: launch-tuning overrides of fm_config (ABI 5 / 6: tile_edge, tile_node, tile_edge_update, xcd_swizzle, fuse_node, pair_mlps, pair_slab,
         mlp_small_tiles; 0 / absent = automatic) for A/B measurements and the parity tests that run every tile size."""
         precision = precision or 'f32'
-        if precision not in ('f32', 'bf16x3'):
-            raise ValueError(f"precision must be 'f32' or 'bf16x3', got {precision!r}")
+        if precision not in ('f32', 'bf16x3', 'bf16x6'):
+            raise ValueError(f"precision must be 'f32', 'bf16x3' or 'bf16x6', got {precision!r}")
         self.precision = precision
         self.tuning = {k: int(v) for k, v in (tuning or {}).items() if int(v) != 0}
         unknown = set(self.tuning) - set(_lib.TUNING_FIELDS)
@@ -257,7 +258,7 @@ class Engine:
         c.msg_z = float(cfg.msg_z)
         c.s_dst_feats, c.v_dst_feats = cfg.s_dst_feats, cfg.v_dst_feats
         c.has_mask = int(cfg.has_mask)
-        c.precision = _lib.FM_PREC_BF16X3 if precision == 'bf16x3' else _lib.FM_PREC_F32
+        c.precision = {'f32': _lib.FM_PREC_F32, 'bf16x3': _lib.FM_PREC_BF16X3, 'bf16x6': _lib.FM_PREC_BF16X6}[precision]
         c.n_recycles = int(cfg.n_recycles)
         c.edge_update_no_distance = int(not cfg.update_edge_w_distance)
         for k, v in self.tuning.items():

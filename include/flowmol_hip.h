@@ -89,7 +89,10 @@ typedef struct fm_config {
     /* --- ABI 3: arithmetic of the edge-message GEMMs.  FM_PREC_F32 (default): exact f32 MFMAs, the reference's arithmetic.
      * FM_PREC_BF16X3: OPT-IN split precision -- the scalar and gate GEMMs of GVPConv.message run on the bf16 matrix cores with every
      * f32 operand carried as hi + lo bf16 and three products per term (~2^-17 relative per product instead of 2^-24).  Not f32
-     * arithmetic: per-stage errors are ~10x larger; meant for throughput runs, never for parity claims. */
+     * arithmetic: per-stage errors are ~10x larger; meant for throughput runs, never for parity claims.
+     * FM_PREC_BF16X6 (round 5, OPT-IN, edge-message kernel only; node kernels and EdgeUpdate stay f32): three-term split -- hi + mid + lo bf16 = all 24
+     * mantissa bits, six products per term, dropped products <= 3 * 2^-24 relative: f32-class accuracy on the bf16 matrix cores at the price of 6-byte
+     * operands (weight stream, LDS).  Measured in profiles/r05c_*; a separately reported mode like FM_PREC_BF16X3. */
     int32_t precision;
     /* --- ABI 4: remaining architecture switches of EndpointVectorField.__init__ that no shipped YAML enables */
     int32_t n_recycles;           /* vector_field.py:307: the conv / update stack runs n_recycles times over the same weights (0 or 1 = once) */
@@ -113,7 +116,7 @@ typedef struct fm_config {
                                    * whose pair tiles fill the chip | 1 = in every self-conditioned evaluation | -1 = off */
 } fm_config;
 
-enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1 };
+enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1, FM_PREC_BF16X6 = 2 };
 
 /* one tensor of the reference state dict inside the host weight blob */
 typedef struct fm_tensor_desc {

@@ -33,8 +33,9 @@ def edge_perm(eng, batch):
     return perm
 
 
-def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_masked=0.4, taps=True):
-    """Returns {stage: relative error (max abs diff / max abs ref)} for every tap and the outputs."""
+def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_masked=0.4, taps=True, dtype=torch.float32):
+    """Returns {stage: relative error (max abs diff / max abs ref)} for every tap and the outputs.  dtype = torch.float64 with an oracle whose
+    parameters are float64 (oracle_f64): the kernels' error against the EXACT result instead of against the f32 reference arithmetic."""
     dev = eng.device
     batch = cpu_ref.build_batch(n_atoms)
     eng.bind(n_atoms)
@@ -52,8 +53,13 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
                 'e': torch.softmax(torch.randn(U, cfg.n_bond_types, generator=gen), -1)}
     a1h, c1h, e1h = onehots(cfg, batch, a, c, eu)
     orc.taps = {}
-    with torch.no_grad():
-        ref = orc.forward(batch, x, a1h, c1h, e1h, torch.full((batch.B,), float(t_val)), prev=prev, apply_softmax=True, remove_com=True)
+    try:
+        torch.set_default_dtype(dtype)
+        with torch.no_grad():
+            ref = orc.forward(batch, x.to(dtype), a1h.to(dtype), c1h.to(dtype), e1h.to(dtype), torch.full((batch.B,), float(t_val), dtype=dtype),
+                              prev=None if prev is None else {k: v.to(dtype) for k, v in prev.items()}, apply_softmax=True, remove_com=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
     taps_o, orc.taps = orc.taps, None
     state = eng.make_state(x, a, c, eu)
     V = cfg.n_vec_channels
@@ -94,7 +100,7 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
             if float(got[:, want.shape[-1]:].abs().max()) != 0.0:
                 return float('inf')
             got = got[:, :want.shape[-1]]
-        return float((got - want).abs().max() / want.abs().max().clamp(min=1e-20))
+        return float((got.to(want.dtype) - want).abs().max() / want.abs().max().clamp(min=1e-20))
     for k, v in bufs.items():
         if k.endswith('.msg.s'):
             want = taps_o['conv0.msg2.s'][perm]
@@ -694,3 +700,14 @@ def oracle_long_fixture(cfg, sd, n_atoms, T, seed_prior, seed_noise):
     for k, v in rec.items():
         g[f'traj.{k}'] = torch.stack(v).to(torch.uint8)
     return g
+
+
+def oracle_f64(cfg, sd):
+    """The CPU oracle evaluated in float64 (parameters converted): the exact-arithmetic yardstick for kernel errors (forward_compare(..., dtype=torch.float64))."""
+    try:
+        torch.set_default_dtype(torch.float64)
+        orc = cpu_ref.OracleVF(cfg, sd)
+        orc.p = {k: v.to(torch.float64) for k, v in orc.p.items()}
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return orc

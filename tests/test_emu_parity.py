@@ -556,3 +556,26 @@ def test_ctmc_kernel_1024_thread_instance_on_emulation(emu_lib, last):
         assert torch.equal(smp[f'{k}1'].long(), x11h.argmax(-1)), k
     vf = alpha_p[s_idx - 1][0] / (1 - alpha[s_idx - 1][0]) * (dst['x'] - x_t)
     assert torch.equal(state['x_t'], x_t + dt * vf * 1.0)
+
+
+@pytest.mark.parametrize('tile', [16, 32])
+@pytest.mark.parametrize('name,sizes', [('flowmol3', [4, 7, 2]), ('geom_ctmc', [6, 3])])
+def test_three_term_split_precision_on_emulation(emu_lib, name, sizes, tile):
+    """Opt-in THREE-term split (precision='bf16x6', edge-message kernel only: hi + mid + lo bf16 operands, six products per term on the emulated
+    v_mfma_f32_16x16x32_bf16): f32-CLASS accuracy -- every stage inside the f32 kernels' own gate (2e-5 per stage, 1e-5 on the outputs; the two-term
+    mode needs 5e-5) -- and it really is other arithmetic than the exact f32 path (the per-edge messages differ in their last bits)."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    orc = cpu_ref.OracleVF(cfg, sd)
+    errs = {}
+    outs = {}
+    for prec in ('f32', 'bf16x6'):
+        eng = Engine(cfg, sd, device='cpu', lib=emu_lib, precision=prec, tuning={'tile_edge': tile})
+        errs[prec], out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), 0.5, True)
+        outs[prec] = {k: v.clone() for k, v in out.items()}
+    bad = {k: v for k, v in errs['bf16x6'].items() if not (v < (1e-5 if k.startswith('out.') else 2e-5))}
+    assert not bad, bad
+    worst = max(errs['bf16x6'][k] / max(errs['f32'][k], 2e-7) for k in errs['f32'])
+    assert worst < 3, (worst, errs)                                  # per stage within a small factor of the f32 kernels' own error
+    assert not all(torch.equal(outs['f32'][k], outs['bf16x6'][k]) for k in 'xace')
