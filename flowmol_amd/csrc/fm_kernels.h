@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
 #ifdef FM_ALT_FILL
     // dev-only (-DFM_ALT_FILL): round 4's EARLIER arrangement of this fill (index arithmetic per pass, profiles/r04x).  Same arithmetic per element; under
     // -ffp-contract=fast the two arrangements produced different output bits (the compiler fused fm_rbf's d - k mu in one and not in the other), with
-    // contraction off they must not -- tools/fingerprint_matrix.py compares the two builds (profiles/r05b_*)
+    // contraction off they must not -- tools/fingerprint_matrix.py compares the two builds: identical under every tuning (profiles/r05c_fingerprint_matrix_fill_arrangements.jsonl)
 #pragma unroll
     for (int k = 0; k < NEF; ++k) {
         const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
