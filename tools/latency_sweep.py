@@ -37,7 +37,7 @@ for B in sizes:
     gpu_ms = 0.0
     nl = 0
     per_kernel = {}
-    for k in ('edge_message', 'edge_message_pq', 'edge_update', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head',
+    for k in ('edge_message', 'edge_message_pq', 'edge_update', 'edge_update_head', 'node_update', 'pos_update', 'node_proj', 'node_proj_asd', 'sc_edge', 'sc_node', 'edge_head',
               'node_head', 'sc', 'heads', 'ctmc', 'embed_table', 'remove_com', 'x_step'):
         ms, cnt = eng.profile_get(k)
         gpu_ms += ms
