@@ -657,9 +657,9 @@ def main():
     ap.add_argument('--timesteps', type=int, default=None)
     ap.add_argument('--preset', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', choices=('f32', 'bf16x3', 'bf16x6'), default='f32',
+    ap.add_argument('--precision', choices=('f32', 'bf16x3', 'bf16x6', 'f16x3'), default='f32',
                     help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
-                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) / 'bf16x6' (hi+mid+lo, six products, edge messages only) -- separately reported modes")
+                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) / 'bf16x6' (hi+mid+lo, six products, edge messages only) / 'f16x3' (hi+lo IEEE half, three products) -- separately reported modes")
     ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (size distribution, C2, C5, latency sweep) of the default one-GPU run')
     ap.add_argument('--secondary-steps', type=int, default=10, help='timed steps of the size-distribution leg (C2 / C5: 4x, latency sweep: 64)')
@@ -796,13 +796,13 @@ def main():
     pmc = load_pmc(args.workload, N, E, args.size_dist is None and args.precision == 'f32' and world == 1)
     ex = executed_macs(cfg, U, torch.cuda.get_device_properties(dev).multi_processor_count)
     roofline = None
-    if 'edge_message' in kern and args.precision in ('bf16x3', 'bf16x6'):
+    if 'edge_message' in kern and args.precision in ('bf16x3', 'bf16x6', 'f16x3'):
         # opt-in mode: the scalar and gate GEMMs issue 3 bf16 products per term on padded K (7 / 10 / 10 k32 blocks); the vector path stays f32
         us = kern['edge_message']['raw_event_pair_us']
         V = cfg.n_vec_channels
         ku0 = (V + 1 + 4 + 7) // 8 * 8
         kb = [(160 + ku0 + 31) // 32, (256 + V + 8 + 31) // 32, (256 + V + 8 + 31) // 32]
-        n_prod = 3 if args.precision == 'bf16x3' else 6          # products per term: hi*hi + hi*lo + lo*hi | + hi*mid, mid*hi, mid*mid (three-term split)
+        n_prod = 6 if args.precision == 'bf16x6' else 3          # products per term: hi*hi + hi*lo + lo*hi | + hi*mid, mid*hi, mid*mid (three-term split)
         bf16_mac = n_prod * (sum(k * 32 * 256 for k in kb) + 3 * 256 * V)
         f32_mac = 3 * (V + 8) * V * 3 + 2 * 3 * V * (V + 16)
         roofline = {'bound': 'mfma', 'kernel': 'fm_k_edge_message (split precision)', 'unit': 'TFLOP/s', 'peak': BF16_PEAK_TFLOPS,
@@ -827,6 +827,7 @@ def main():
         'metric': (f'molecules/sec at {T} timesteps ' + ('(GEOM-drugs-sized graphs)' if args.workload == 'c3' else f'[secondary workload {args.workload}]')) + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else ('bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)' if args.precision == 'bf16x3' else
+                                                         'f16x3 split precision (opt-in; f32 operands as hi+lo IEEE half = 22 mantissa bits, 3 products per term on v_mfma_f32_16x16x32_f16, f32 accumulate; |activations| clamped to 65504)' if args.precision == 'f16x3' else
                                                          'bf16x6 three-term split precision of the edge-message GEMMs (opt-in; f32 operands as hi+mid+lo bf16, 6 products per term, f32 accumulate; node kernels and EdgeUpdate f32)'), 'data': 'synthetic',
         'config': {'workload': f'{args.preset} model, {B} molecules/GPU x ' + (f'{n} atoms' if not ragged else (f'sizes ~ {args.size_dist} histogram' if args.size_dist else 'sizes randint(5, 61, seed 0)') + f' (mean {float(all_sizes.double().mean()):.1f}, max {int(all_sizes.max())}; ONE global list dealt to the ranks by shard.partition_lpt)') + f', n_timesteps={T} '
                                f"({wl['label']})",

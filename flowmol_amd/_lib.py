@@ -14,7 +14,7 @@ from pathlib import Path
 FM_ABI_VERSION = 6
 FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
 FM_NOISE_TENSORS, FM_NOISE_PHILOX = 0, 1
-FM_PREC_F32, FM_PREC_BF16X3, FM_PREC_BF16X6 = 0, 1, 2
+FM_PREC_F32, FM_PREC_BF16X3, FM_PREC_BF16X6, FM_PREC_F16X3 = 0, 1, 2, 3
 FM_MAX_CONVS = 16
 
 LIB_NAME = 'libflowmol_hip.so'

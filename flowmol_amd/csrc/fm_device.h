@@ -469,16 +469,40 @@ typedef __bf16 fm_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 fm_mfma_bf16(fm_h8 a, fm_h8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fm_bf16x8, a), __builtin_bit_cast(fm_bf16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ void fm_split(float v, unsigned short& hi, unsigned short& lo) {
-    const __bf16 h = (__bf16)v;                    // round-to-nearest-even
-    const __bf16 l = (__bf16)(v - (float)h);       // v - hi is exact in f32
-    hi = __builtin_bit_cast(unsigned short, h);
-    lo = __builtin_bit_cast(unsigned short, l);
+// Plane formats of the two-plane split modes: FMT 0 = bf16 (8 + 8 mantissa bits: "bf16x3"), FMT 1 = IEEE half (11 + 11 bits: "f16x3", round 5).  Half carries 22
+// of f32's 24 mantissa bits in the same 4 bytes per element and the same three products on v_mfma_f32_16x16x32_f16 (subnormal inputs are kept by the
+// instruction: tools/ubench/mfma_f16_denorm.cpp) -- its price is RANGE: |v| is clamped to the largest half, 65504, before the split (a finite, wrong result for
+// activations beyond that instead of an infinity), and the low parts of values below 2^-3 are subnormal halves with an absolute resolution of 2^-25.
+// The half-plane WEIGHTS are packed times 2^6 (fm_engine.cpp:pack_sp): the low part of a weight of magnitude 0.04 is 5e-6, a subnormal half with an absolute
+// resolution of 3e-8 (7.5e-7 of the weight) -- times 64 it is a normal half and the pair carries 22 bits; accumulators start at (bias) * 2^6 and the sums are
+// multiplied by 2^-6 (both exact).  With it a K = 296 product measures the f32 chain's own error (3.07e-7 rms against float64; 4.3e-7 without).
+#define FM_F16_WSCALE 64.0f
+template <int FMT> __device__ __forceinline__ constexpr float fm_sp_wscale() { return FMT == 1 ? FM_F16_WSCALE : 1.0f; }
+typedef _Float16 fm_f16x8 __attribute__((ext_vector_type(8)));
+template <int FMT>
+__device__ __forceinline__ f32x4 fm_mfma_16(fm_h8 a, fm_h8 b, f32x4 c) {
+    if constexpr (FMT == 1) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fm_f16x8, a), __builtin_bit_cast(fm_f16x8, b), c, 0, 0, 0);
+    else return fm_mfma_bf16(a, b, c);
 }
-template <int LDP = FM_LDP>
+template <int FMT = 0>
+__device__ __forceinline__ void fm_split(float v, unsigned short& hi, unsigned short& lo) {
+    if constexpr (FMT == 1) {
+        v = fminf(fmaxf(v, -65504.f), 65504.f);        // one v_med3_f32
+        const _Float16 h = (_Float16)v;                // round-to-nearest-even
+        const _Float16 l = (_Float16)(v - (float)h);   // v - hi is exact in f32
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, l);
+    } else {
+        const __bf16 h = (__bf16)v;                    // round-to-nearest-even
+        const __bf16 l = (__bf16)(v - (float)h);       // v - hi is exact in f32
+        hi = __builtin_bit_cast(unsigned short, h);
+        lo = __builtin_bit_cast(unsigned short, l);
+    }
+}
+template <int LDP = FM_LDP, int FMT = 0>
 __device__ __forceinline__ void fm_split_store(unsigned short* XH, unsigned short* XL, int row, int col, float v) {
     unsigned short hi, lo;
-    fm_split(v, hi, lo);
+    fm_split<FMT>(v, hi, lo);
     XH[row * LDP + col] = hi;
     XL[row * LDP + col] = lo;
 }
@@ -506,42 +530,81 @@ __device__ __forceinline__ void fm_sp_frag_load(fm_h8 (&ah)[MT], fm_h8 (&al)[MT]
         bl[nt] = fm_buf_h8(rs, lane * 16, e + 64 * 16);
     }
 }
-template <int MT, int NT>
+template <int MT, int NT, int FMT = 0>
 __device__ __forceinline__ void fm_sp_frag_mma(f32x4 (&acc)[MT][NT], const fm_h8 (&ah)[MT], const fm_h8 (&al)[MT], const fm_h8 (&bh)[NT], const fm_h8 (&bl)[NT]) {
     // the two small products first, the big one last; three passes over the accumulators keep dependent MFMAs apart
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(al[mt], bh[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_16<FMT>(al[mt], bh[nt], acc[mt][nt]);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(ah[mt], bl[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_16<FMT>(ah[mt], bl[nt], acc[mt][nt]);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_bf16(ah[mt], bh[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_16<FMT>(ah[mt], bh[nt], acc[mt][nt]);
 }
-template <int MT, int NT, int LDP = FM_LDP>
+template <int MT, int NT, int LDP = FM_LDP, int FMT = 0>
 __device__ __forceinline__ void fm_wave_gemm_sp(f32x4 (&acc)[MT][NT], const unsigned short* XH, const unsigned short* XL, int row0, int KB,
                                                 const void* wsp, int ntiles, int nt0, int lane) {
     static_assert(LDP % 16 == 0 && (LDP / 16) % 2 == 1, "plane pitch must be 32 bytes * odd");
     const unsigned short* aph = XH + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
     const unsigned short* apl = XL + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
     fm_h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+    // half planes: the two cross products (2^-11 of the result) go to an accumulator of their own, like the three-term mode's corrections -- its roundings are
+    // 2^-11 of a rounding of the full sum, which leaves one full-magnitude rounding per k32 block (the bf16 mode keeps its single accumulator: its error is
+    // the 16-bit representation, not the accumulation)
+#ifdef FM_F16_ONE_ACC          // dev-only: the half mode with ONE accumulator (16 VGPRs less in the edge kernel: 118 instead of 134, i.e. two workgroups per CU); profiles/r05f_*
+    constexpr bool SEP = false;
+#else
+    constexpr bool SEP = FMT == 1;
+#endif
+    f32x4 accs[SEP ? MT : 1][SEP ? NT : 1];
+    if constexpr (SEP) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto mma = [&](const fm_h8 (&ah)[MT], const fm_h8 (&al)[MT], const fm_h8 (&bh)[NT], const fm_h8 (&bl)[NT]) {
+        if constexpr (SEP) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = fm_mfma_16<1>(al[mt], bh[nt], accs[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = fm_mfma_16<1>(ah[mt], bl[nt], accs[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_16<1>(ah[mt], bh[nt], acc[mt][nt]);
+        } else {
+            fm_sp_frag_mma<MT, NT, FMT>(acc, ah, al, bh, bl);
+        }
+    };
     fm_sp_frag_load<MT, NT, LDP>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, 0, lane);
     int kb = 0;
     for (; kb + 2 <= KB; kb += 2) {          // double-buffered: the fragments of block kb+1 are requested before the MFMAs of block kb issue
         fm_sp_frag_load<MT, NT, LDP>(ah1, al1, bh1, bl1, aph, apl, wsp, ntiles, nt0, kb + 1, lane);
         __builtin_amdgcn_sched_barrier(0);
-        fm_sp_frag_mma<MT, NT>(acc, ah0, al0, bh0, bl0);
+        mma(ah0, al0, bh0, bl0);
         __builtin_amdgcn_sched_barrier(0);
         if (kb + 2 < KB) fm_sp_frag_load<MT, NT, LDP>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, kb + 2, lane);
         __builtin_amdgcn_sched_barrier(0);
-        fm_sp_frag_mma<MT, NT>(acc, ah1, al1, bh1, bl1);
+        mma(ah1, al1, bh1, bl1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (kb < KB) fm_sp_frag_mma<MT, NT>(acc, ah0, al0, bh0, bl0);
+    if (kb < KB) mma(ah0, al0, bh0, bl0);
+    if constexpr (SEP) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += accs[mt][nt];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -681,6 +744,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     typedef FmGvpTile<V, TM, HX> T;
     unsigned short* const XH = reinterpret_cast<unsigned short*>(X);
     unsigned short* const XL = XH + TM * FM_LDP;
+    constexpr int FMT = SP == 3 ? 1 : 0;                 // SP: 1 = two bf16 planes, 2 = three bf16 planes, 3 = two half planes
     constexpr int MT = TM / 16;                          // row tiles of the scalar GEMM
     constexpr int NW = NTH / 64;                         // waves per workgroup
     constexpr int NTW = 16 / NW;                         // column tiles of the scalar GEMM per wave (16 tiles = 256 columns)
@@ -760,7 +824,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         Vh[(1 * TM + r) * T::LDVH + H + p] = cy;
         Vh[(2 * TM + r) * T::LDVH + H + p] = cz;
         if (SP == 2) fm_split3_store(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
-        else if (SP) fm_split_store(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
+        else if (SP) fm_split_store<FM_LDP, FMT>(XH, XL, r, SOFF + H + CPS * p, fm_norm3(cx, cy, cz));
         else X[r * FM_LDX + SOFF + H + CPS * p] = fm_norm3(cx, cy, cz);
     }
     // thread -> (row, 16-column group): no integer division by V+8 in the index math
@@ -773,7 +837,7 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 const float vy = Vh[(1 * TM + r) * T::LDVH + c];
                 const float vz = Vh[(2 * TM + r) * T::LDVH + c];
                 if (SP == 2) fm_split3_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
-                else if (SP) fm_split_store(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
+                else if (SP) fm_split_store<FM_LDP, FMT>(XH, XL, r, SOFF + c, fm_norm3(vx, vy, vz));
                 else X[r * FM_LDX + SOFF + c] = fm_norm3(vx, vy, vz);
             } else if (FIRST ? (c >= H + 4 && c < KUC) : (c < KUC && ((c - H) & 1))) {      // K padding (first GVP) / the odd slots between the cross-product norms
                 if (SP) { XH[r * FM_LDP + SOFF + c] = 0; XL[r * FM_LDP + SOFF + c] = 0; if (SP == 2) XL[TM * FM_LDP + r * FM_LDP + SOFF + c] = 0; }
@@ -830,11 +894,11 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = FIRST ? pre[i][j][r] + bias : bias;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (FIRST ? pre[i][j][r] + bias : bias) * fm_sp_wscale<FMT>();
         }
         FM_MARKB(2);
         if (SP == 2) fm_wave_gemm_sp3<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane);
-        else if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
+        else if (SP) { if (!(FM_ABLATE & 32)) fm_wave_gemm_sp<MT, NTW, FM_LDP, FMT>(acc, XH, XL, 0, (SOFF + KUC + 31) / 32, w.Ws_sp, 16, NTW * wave, lane); }
         else if (!(FM_ABLATE & 32)) fm_wave_gemm<MT, NTW, !FIRST>(acc, X, FM_LDX, K8S, w.Ws, 16, NTW * wave, lane);
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
@@ -846,10 +910,10 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float y = fm_silu(acc[i][j][r]);
+                        const float y = fm_silu(acc[i][j][r] * (1.0f / fm_sp_wscale<FMT>()));
                         if constexpr (SP && LAST) keep[i][j][r] = y;
                         if (SP == 2) fm_split3_store(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
-                        else fm_split_store(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
+                        else fm_split_store<FM_LDP, FMT>(XH, XL, i * 16 + 4 * (lane >> 4) + r, (NTW * wave + j) * 16 + (lane & 15), y);
                     }
         } else {
             float* xo = X + (4 * (lane >> 4)) * FM_LDX + NTW * wave * 16 + (lane & 15);
@@ -884,9 +948,9 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
             f32x4 ga[1][1] = {{f32x4{0.f, 0.f, 0.f, 0.f}}};
             if (SP == 2) fm_wave_gemm_sp3<1, 1>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
                                                 static_cast<const char*>(w.Wg_sp) + (size_t)half * (8 / KS) * (VOP / 16) * 3 * 64 * 16, VOP / 16, n0, lane);
-            else fm_wave_gemm_sp<1, 1>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
+            else fm_wave_gemm_sp<1, 1, FM_LDP, FMT>(ga, XH + half * (256 / KS), XL + half * (256 / KS), m0 * 16, 8 / KS,
                                   static_cast<const char*>(w.Wg_sp) + (size_t)half * (8 / KS) * (VOP / 16) * 2 * 64 * 16, VOP / 16, n0, lane);
-            g = ga[0][0];
+            g = ga[0][0] * (1.0f / fm_sp_wscale<FMT>());
         } else {
             g = fm_wave_gemm_1x1<32 / KS, 8>(X + (size_t)m0 * 16 * FM_LDX + half * (256 / KS), FM_LDX,
                                              w.Wg + (size_t)half * (32 / KS) * (VOP / 16) * 64, VOP / 16, n0, lane);

@@ -121,6 +121,7 @@ int fail(fm_ctx* c, int code, const char* fmt, ...) {
 #define FM_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
     return fail((c), FM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+inline bool prec_two_plane(int p) { return p == FM_PREC_BF16X3 || p == FM_PREC_F16X3; }      // the modes whose node / EdgeUpdate kernels run split precision too
 inline int pad8(int k) { return (k + 7) / 8 * 8; }
 inline int pad16(int k) { return (k + 15) / 16 * 16; }
 inline int ld_for(int k) { int ld = (k + 3) / 4 * 4; while (((ld / 4) & 1) == 0) ld += 4; return ld; }
@@ -197,19 +198,22 @@ inline uint16_t bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 inline float bf16_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
-std::vector<float> pack_sp(int K, int N, const std::function<float(int, int)>& w, int npl = 2) {      // npl planes: hi, lo (| hi, mid, lo of the three-term mode)
+// 16-bit plane formats of the split modes (fm_device.h): 0 = bf16, 1 = IEEE half (round to nearest even, subnormals kept, clamped to +-65504)
+inline uint16_t f16_rne(float f) { f = std::fmin(std::fmax(f, -65504.f), 65504.f); const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+inline float f16_f32(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+std::vector<float> pack_sp(int K, int N, const std::function<float(int, int)>& w, int npl = 2, int fmt = 0) {      // npl planes: hi, lo (| hi, mid, lo of the three-term mode)
     const int KB = K / 32, NT = N / 16;
     std::vector<uint16_t> out((size_t)KB * NT * npl * 64 * 8);
     for (int kb = 0; kb < KB; ++kb)
         for (int nt = 0; nt < NT; ++nt)
             for (int lane = 0; lane < 64; ++lane)
                 for (int q = 0; q < 8; ++q) {
-                    float r = w(32 * kb + 8 * (lane >> 4) + q, 16 * nt + (lane & 15));
+                    float r = w(32 * kb + 8 * (lane >> 4) + q, 16 * nt + (lane & 15)) * (fmt == 1 ? FM_F16_WSCALE : 1.0f);      // half planes: weights times 2^6 (fm_device.h)
                     const size_t e = (((size_t)kb * NT + nt) * npl) * 64 * 8;
                     for (int p_ = 0; p_ < npl; ++p_) {
-                        const uint16_t h = bf16_rne(r);
+                        const uint16_t h = fmt == 1 ? f16_rne(r) : bf16_rne(r);
                         out[e + (size_t)p_ * 64 * 8 + (size_t)lane * 8 + q] = h;
-                        r -= bf16_f32(h);          // exact in f32
+                        r -= fmt == 1 ? f16_f32(h) : bf16_f32(h);          // exact in f32
                     }
                 }
     std::vector<float> f(out.size() / 2);
@@ -235,13 +239,14 @@ void pack_linear(Builder& B, const float2*& slot, const float* W, int out, int i
     }));
 }
 // the same logical matrix as pack_linear, K padded to a multiple of 32, as split-precision planes
+thread_local int g_sp_fmt = 0;          // plane format of the split-precision copies being packed (set by fm_create for the duration of its packing: single-threaded per call)
 void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, int Np, const std::function<int(int)>& kmap, int npl = 2) {
     const int K32 = (Kp + 31) / 32 * 32;
     B.putv(slot, pack_sp(K32, Np, [&](int k, int n) -> float {
         if (n >= out || k >= Kp) return 0.f;
         const int kk = kmap(k);
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
-    }, npl));
+    }, npl, g_sp_fmt));
 }
 void pack_linear4(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, const std::function<int(int)>& kmap, int G = 4) {
     B.putv(slot, pack4(Kp, [&](int k, int n) -> float {
@@ -513,6 +518,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
         if constexpr (HX == 0) {
             if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
+            else if (cf.precision == FM_PREC_F16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 3>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
             else if (cf.precision == FM_PREC_BF16X6) {
                 if constexpr (TE <= 32) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 2>, gmsg, dim3(512), lds_gvp_sp(V, TE, 3), m);
                 else return fail(c, FM_ERR_INVALID, "the three-term split precision runs 16- or 32-row edge tiles (three planes of a 64-row tile exceed the LDS)");
@@ -546,10 +552,11 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         nu.s_real = c->S;
         bool launched = false;
         if constexpr (HX == 0 && TN <= 32) {
-            if (cf.precision == FM_PREC_BF16X3 && fuse) {      // split-precision node kernel (fused sequence only)
+            if (prec_two_plane(cf.precision) && fuse) {      // split-precision node kernel (fused sequence only)
                 if (it + 1 < n_pass) nu.Wps_sp = c->conv[(i + 1) % cf.n_convs].Wps_sp;
                 if (u >= 0) nu.Wasd_sp = c->upd[u].Wasd_sp;
-                L("node_update", fm_k_node_update<V, TN, true, 1>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
+                if (cf.precision == FM_PREC_F16X3) L("node_update", fm_k_node_update<V, TN, true, 3>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
+                else L("node_update", fm_k_node_update<V, TN, true, 1>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
                 launched = true;
             }
         }
@@ -589,9 +596,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
             eu.ln_g = uw.ln_g; eu.ln_b = uw.ln_b; eu.rbf_mu_step = c->rbf_mu_step; eu.rbf_inv_sigma = c->rbf_inv_sigma;
             eu.f_real = c->F;
-            if (cf.precision == FM_PREC_BF16X3) {
+            if (prec_two_plane(cf.precision)) {
                 FmEdgeUpdSpW sw{uw.W1_sp, uw.W2_sp};
-                L("edge_update", fm_k_edge_update_sp<32>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
+                if (cf.precision == FM_PREC_F16X3) L("edge_update", fm_k_edge_update_sp<32, 1>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
+                else L("edge_update", fm_k_edge_update_sp<32>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
             } else if (it == n_pass - 1 && c->fuse_head && c->F == 128 && c->tm_eupd == 32 && !(taps_on && c->taps.count("upd" + std::to_string(i) + ".ef"))) {
                 // the evaluation's last EdgeUpdate: its rows feed the edge head and nothing else -- tiles of 16 pairs, the head as the epilogue, no ef store
                 eu.hW1 = c->edge_head.W1; eu.hb1 = c->edge_head.b1; eu.hW2 = c->edge_head.W2; eu.hb2 = c->edge_head.b2; eu.out_e = out->e; eu.ne = c->ne;
@@ -777,8 +785,9 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     if ((HX > 0) != (SD > 0) || HX < 0 || HX > 8 || SD > 256 || (HX > 0 && HX != V / 4))
         { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: destination-feature widths must be both 0 or v = n_vec_channels/4 (<= 8), s <= 256"); }
     const int H0 = V + 1 + HX, KU0 = pad8(H0 + 4), PVW = c->PVW = pvw_of(V, HX);
-    if (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_BF16X3 && cfg->precision != FM_PREC_BF16X6) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: unknown precision %d", cfg->precision); }
+    if (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_BF16X3 && cfg->precision != FM_PREC_BF16X6 && cfg->precision != FM_PREC_F16X3) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: unknown precision %d", cfg->precision); }
     if (cfg->precision != FM_PREC_F32 && HX > 0) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: split precision is built for models without destination features"); }
+    g_sp_fmt = cfg->precision == FM_PREC_F16X3 ? 1 : 0;
     const int na = c->na = cfg->n_atom_types, nc = c->nc = cfg->n_charges, ne = c->ne = cfg->n_bond_types;
     c->rbf_mu_step = cfg->rbf_dmax / (float)(cfg->rbf_dim - 1);
     c->rbf_inv_sigma = 1.0f / (cfg->rbf_dmax / (float)cfg->rbf_dim);
@@ -851,7 +860,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!W1 || !b1 || !W2 || !b2 || !E1 || !eb1 || !E2 || !eb2) return bail(bl.err);
         c->sc_node.K1p = pad8(kinp); c->sc_node.H = 256; c->sc_node.O = 256;
         pack_linear(B, c->sc_node.W1, W1, S, kin, pad8(kinp), 256, [&](int k) { return k < 256 ? (k < S ? k : -1) : S + (k - 256); });
-        if (S == 256 && HX == 0 && cfg->precision != FM_PREC_BF16X3) {      // 4-row node tiles of small batches (fm_k_mlp4): K padded to 320, quad-row packed
+        if (S == 256 && HX == 0 && !prec_two_plane(cfg->precision)) {      // 4-row node tiles of small batches (fm_k_mlp4): K padded to 320, quad-row packed
             pack_linear4(B, c->sc_node_W1q, W1, S, kin, 320, [&](int k) { return k < 256 ? k : (k - 256 < na + nc + 32 ? S + (k - 256) : -1); });
             pack_linear4(B, c->sc_node_W2q, W2, S, S, 256, ident);
         }
@@ -914,8 +923,8 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         pad_vec(B, g0.bs, bs, S, 256);
         pack_linear(B, g0.Wg, Wg, V, S, 256, V, [&](int k) { return k < S ? k : -1; });
         pad_vec(B, g0.bg, bg, V, V);
-        const bool sp = cfg->precision == FM_PREC_BF16X3;                                     // split-precision NODE / EdgeUpdate kernels: the two-term mode only
-        const int sp_msg = cfg->precision == FM_PREC_BF16X3 ? 2 : cfg->precision == FM_PREC_BF16X6 ? 3 : 0;      // bf16 planes of the edge-message GEMM operands
+        const bool sp = prec_two_plane(cfg->precision);                                       // split-precision NODE / EdgeUpdate kernels: the two-plane modes only
+        const int sp_msg = prec_two_plane(cfg->precision) ? 2 : cfg->precision == FM_PREC_BF16X6 ? 3 : 0;      // 16-bit planes of the edge-message GEMM operands
         if (sp_msg) {
             pack_linear_sp(B, g0.Ws_sp, Ws, S, kin0, 160 + KU0, 256, [&](int k) {
                 if (k < 32) return S + k;
@@ -960,7 +969,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (!used) continue;
         UpdW& uw = c->upd[u];
         const std::string p = "node_position_updaters." + std::to_string(u) + ".gvps.";
-        const bool spu = cfg->precision == FM_PREC_BF16X3;
+        const bool spu = prec_two_plane(cfg->precision);
         const bool rows4u = S == 256 && HX == 0 && !spu;
         if (!pack_gvp(B, bl, p + "0", V, S, V, uw.pos[0], spu ? 2 : 0, rows4u) || !pack_gvp(B, bl, p + "1", V, S, V, uw.pos[1], spu ? 2 : 0, rows4u) || !pack_gvp(B, bl, p + "2", V, S, 1, uw.pos[2], spu ? 2 : 0, rows4u))
             return bail(bl.err);
@@ -985,11 +994,11 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         pad_vec(B, uw.b1, b1, F, 128);
         pack_linear(B, uw.W2, W2, F, F, 128, 128, ident);
         pad_vec(B, uw.b2, b2, F, 128);
-        if (cfg->precision == FM_PREC_BF16X3) {
+        if (prec_two_plane(cfg->precision)) {
             B.putv(uw.Wasd_sp, pack_sp(256, 256, [&](int k, int n) -> float {
                 const int o = n < 128 ? n : n - 128;
                 if (k >= S || o >= F) return 0.f;
-                return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }));
+                return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }, 2, g_sp_fmt));
             pack_linear_sp(B, uw.W1_sp, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : (with_d ? 2 * S + F + (k - 128) : -1); });
             pack_linear_sp(B, uw.W2_sp, W2, F, F, 128, 128, ident);
         }
@@ -1005,7 +1014,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         c->node_head.K1p = 256; c->node_head.H = 256; c->node_head.O = pad16(na + nc);
         pack_linear(B, c->node_head.W1, W1, S, S, 256, 256, ident); pad_vec(B, c->node_head.b1, b1, S, 256);
         pack_linear(B, c->node_head.W2, W2, na + nc, S, 256, pad16(na + nc), ident); pad_vec(B, c->node_head.b2, b2, na + nc, pad16(na + nc));
-        if (S == 256 && HX == 0 && cfg->precision != FM_PREC_BF16X3) {
+        if (S == 256 && HX == 0 && !prec_two_plane(cfg->precision)) {
             pack_linear4(B, c->node_head_W1q, W1, S, S, 256, ident);
             pack_linear4(B, c->node_head_W2q, W2, na + nc, S, 256, ident, 1);      // N = 64 (na + nc <= 32 real columns): one column group, K over all eight waves
         }
@@ -1059,6 +1068,12 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
+    set_lds(fm_k_edge_message<32, 16, 512, 0, 3>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 3>, lds_gvp_sp(32, 32));
+    set_lds(fm_k_edge_message<16, 16, 512, 0, 3>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 3>, lds_gvp_sp(16, 32));
+    set_lds(fm_k_edge_message<32, 64, 512, 0, 3>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 3>, lds_gvp_sp(16, 64));
+    set_lds(fm_k_node_update<32, 16, true, 3>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 3>, lds_gvp_sp(32, 32));
+    set_lds(fm_k_node_update<16, 16, true, 3>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 3>, lds_gvp_sp(16, 32));
+    set_lds(fm_k_edge_update_sp<32, 1>, lds_edge_upd_sp(32));
     set_lds(fm_k_edge_message<32, 16, 512, 0, 2>, lds_gvp_sp(32, 16, 3)); set_lds(fm_k_edge_message<32, 32, 512, 0, 2>, lds_gvp_sp(32, 32, 3));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 2>, lds_gvp_sp(16, 16, 3)); set_lds(fm_k_edge_message<16, 32, 512, 0, 2>, lds_gvp_sp(16, 32, 3));
     set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));

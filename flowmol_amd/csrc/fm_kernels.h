@@ -677,7 +677,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     typedef FmGvpTile<V, TM, HX> T;
     HIP_DYNAMIC_SHARED(float, lds)
     float* X = lds;
-    float* Vin = X + (SP ? TM * FM_LDP * (SP + 1) / 2 : T::X_FLOATS);          // SP: SP + 1 bf16 planes of TM x FM_LDP
+    constexpr int FMT = SP == 3 ? 1 : 0, NPL = SP == 2 ? 3 : 2;                 // SP: 1 = two bf16 planes, 2 = three bf16 planes, 3 = two half planes (fm_device.h)
+    float* Vin = X + (SP ? TM * FM_LDP * NPL / 2 : T::X_FLOATS);
     float* Vh = Vin + T::VIN_FLOATS;
     float* G = SP ? Vh + TM * FM_LDG : Vh + T::VH_FLOATS;
     int* m_src = reinterpret_cast<int*>(SP ? Vh + T::VH_FLOATS : G + T::G_FLOATS);   // [64]
@@ -799,7 +800,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         for (int idx = tid; idx < TM * 32; idx += NTH) {
             const int r = idx >> 5, k = idx & 31;
             if (SP == 2) fm_split3_store(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
-            else fm_split_store(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
+            else fm_split_store<FM_LDP, FMT>(XH, XL, r, k, fm_rbf(m_geo[4 * r + 3], k, a.rbf_mu_step, a.rbf_inv_sigma));
         }
 #pragma unroll
         for (int k = 0; k < NEF; ++k) {
@@ -808,8 +809,8 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
                 fm_split3_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split3_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
                 fm_split3_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split3_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
             } else {
-                fm_split_store(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split_store(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
-                fm_split_store(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split_store(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
+                fm_split_store<FM_LDP, FMT>(XH, XL, r, 32 + 4 * c4 + 0, efv[k].x); fm_split_store<FM_LDP, FMT>(XH, XL, r, 32 + 4 * c4 + 1, efv[k].y);
+                fm_split_store<FM_LDP, FMT>(XH, XL, r, 32 + 4 * c4 + 2, efv[k].z); fm_split_store<FM_LDP, FMT>(XH, XL, r, 32 + 4 * c4 + 3, efv[k].w);
             }
         }
     } else if constexpr (!PQ) {
@@ -948,7 +949,7 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
         unsigned short* XH = reinterpret_cast<unsigned short*>(X);
         unsigned short* XL = XH + TM * FM_LDP;
 #pragma unroll
-        for (int k = 0; k < 256 / LPR; ++k) fm_split_store(XH, XL, r, sub + k * LPR, ys[k]);
+        for (int k = 0; k < 256 / LPR; ++k) fm_split_store<FM_LDP, (SP == 3 ? 1 : 0)>(XH, XL, r, sub + k * LPR, ys[k]);
         for (int c = 256 + V + 8 + sub; c < 320; c += LPR) { XH[r * FM_LDP + c] = 0; XL[r * FM_LDP + c] = 0; }      // K padding of the [s | sh] layout
     } else {
     for (int c = sub; c < 256; c += LPR) {
@@ -1103,7 +1104,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            fm_wave_gemm_sp<MT, 2>(acc, XH, XL, 0, 8, wsp, 16, 2 * wave, lane);
+            fm_wave_gemm_sp<MT, 2, FM_LDP, (SP == 3 ? 1 : 0)>(acc, XH, XL, 0, 8, wsp, 16, 2 * wave, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1111,7 +1112,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = i * 16 + 4 * (lane >> 4) + r;
-                        if (row0 + row < N) out[(size_t)(row0 + row) * 256 + (2 * wave + j) * 16 + (lane & 15)] = acc[i][j][r];
+                        if (row0 + row < N) out[(size_t)(row0 + row) * 256 + (2 * wave + j) * 16 + (lane & 15)] = acc[i][j][r] * (1.0f / fm_sp_wscale<(SP == 3 ? 1 : 0)>());
                     }
         };
         if (a.Ps) project(a.Wps_sp, a.Ps);
@@ -1442,7 +1443,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
 // the f32 copy of ef stays in LDS for the residual and the LayerNorm.  With the matrix work off the f32 ALU the kernel is bound by
 // its 1 KB per edge of HBM traffic and by VALU (SiLU, LayerNorm, the splits).
 struct FmEdgeUpdSpW { const void* W1; const void* W2; };
-template <int TM>
+template <int TM, int FMT = 0>      // FMT: 0 = bf16 planes, 1 = half planes
 __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update_sp(FmEdgeUpdArgs a, FmEdgeUpdSpW w) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int LDF = 132, LD1 = 176, LD2 = 144, MT = TM / 16, LPR = FM_THREADS / TM;     // f32 ef tile; planes of [ef | rbf] (K = 160) and of the hidden layer (K = 128)
@@ -1490,9 +1491,9 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update_sp(FmEdgeUpdArgs 
     for (int k = 0; k < NEF; ++k) {
         const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
         *reinterpret_cast<float4*>(Xf + r * LDF + 4 * c4) = efv[k];
-        fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 0, efv[k].x); fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 1, efv[k].y);
-        fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 2, efv[k].z); fm_split_store<LD1>(P1H, P1L, r, 4 * c4 + 3, efv[k].w);
-        fm_split_store<LD1>(P1H, P1L, r, 128 + c4, fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma));
+        fm_split_store<LD1, FMT>(P1H, P1L, r, 4 * c4 + 0, efv[k].x); fm_split_store<LD1, FMT>(P1H, P1L, r, 4 * c4 + 1, efv[k].y);
+        fm_split_store<LD1, FMT>(P1H, P1L, r, 4 * c4 + 2, efv[k].z); fm_split_store<LD1, FMT>(P1H, P1L, r, 4 * c4 + 3, efv[k].w);
+        fm_split_store<LD1, FMT>(P1H, P1L, r, 128 + c4, fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma));
     }
     __syncthreads();
     {
@@ -1500,25 +1501,25 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update_sp(FmEdgeUpdArgs 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][0][r] = (pre_s[i][r] + pre_d[i][r]) + b1;
-        fm_wave_gemm_sp<MT, 1, LD1>(acc, P1H, P1L, 0, 5, w.W1, 8, wave, lane);
+            for (int r = 0; r < 4; ++r) acc[i][0][r] = ((pre_s[i][r] + pre_d[i][r]) + b1) * fm_sp_wscale<FMT>();
+        fm_wave_gemm_sp<MT, 1, LD1, FMT>(acc, P1H, P1L, 0, 5, w.W1, 8, wave, lane);
         __syncthreads();                     // every wave has read the layer-1 planes: the hidden layer's planes take their place
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fm_split_store<LD2>(P2H, P2L, i * 16 + 4 * (lane >> 4) + r, col, fm_silu(acc[i][0][r]));
+            for (int r = 0; r < 4; ++r) fm_split_store<LD2, FMT>(P2H, P2L, i * 16 + 4 * (lane >> 4) + r, col, fm_silu(acc[i][0][r] * (1.0f / fm_sp_wscale<FMT>())));
     }
     __syncthreads();
     {
         f32x4 acc[MT][1];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{b2, b2, b2, b2};
-        fm_wave_gemm_sp<MT, 1, LD2>(acc, P2H, P2L, 0, 4, w.W2, 8, wave, lane);
+        for (int i = 0; i < MT; ++i) { const float b2s = b2 * fm_sp_wscale<FMT>(); acc[i][0] = f32x4{b2s, b2s, b2s, b2s}; }
+        fm_wave_gemm_sp<MT, 1, LD2, FMT>(acc, P2H, P2L, 0, 4, w.W2, 8, wave, lane);
         float* xo = Xf + (4 * (lane >> 4)) * LDF + col;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * LDF] += fm_silu(acc[i][0][r]);   // own element: ef + update
+            for (int r = 0; r < 4; ++r) xo[(i * 16 + r) * LDF] += fm_silu(acc[i][0][r] * (1.0f / fm_sp_wscale<FMT>()));   // own element: ef + update
     }
     __syncthreads();
     const int r = tid / LPR, sub = tid % LPR;

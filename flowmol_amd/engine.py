@@ -212,8 +212,8 @@ class Engine:
         ``tuning``: launch-tuning overrides of fm_config (ABI 5 / 6: tile_edge, tile_node, tile_edge_update, xcd_swizzle, fuse_node, pair_mlps, pair_slab,
         mlp_small_tiles; 0 / absent = automatic) for A/B measurements and the parity tests that run every tile size."""
         precision = precision or 'f32'
-        if precision not in ('f32', 'bf16x3', 'bf16x6'):
-            raise ValueError(f"precision must be 'f32', 'bf16x3' or 'bf16x6', got {precision!r}")
+        if precision not in ('f32', 'bf16x3', 'bf16x6', 'f16x3'):
+            raise ValueError(f"precision must be 'f32', 'bf16x3', 'bf16x6' or 'f16x3', got {precision!r}")
         self.precision = precision
         self.tuning = {k: int(v) for k, v in (tuning or {}).items() if int(v) != 0}
         unknown = set(self.tuning) - set(_lib.TUNING_FIELDS)
@@ -258,7 +258,7 @@ class Engine:
         c.msg_z = float(cfg.msg_z)
         c.s_dst_feats, c.v_dst_feats = cfg.s_dst_feats, cfg.v_dst_feats
         c.has_mask = int(cfg.has_mask)
-        c.precision = {'f32': _lib.FM_PREC_F32, 'bf16x3': _lib.FM_PREC_BF16X3, 'bf16x6': _lib.FM_PREC_BF16X6}[precision]
+        c.precision = {'f32': _lib.FM_PREC_F32, 'bf16x3': _lib.FM_PREC_BF16X3, 'bf16x6': _lib.FM_PREC_BF16X6, 'f16x3': _lib.FM_PREC_F16X3}[precision]
         c.n_recycles = int(cfg.n_recycles)
         c.edge_update_no_distance = int(not cfg.update_edge_w_distance)
         for k, v in self.tuning.items():

@@ -93,7 +93,9 @@ typedef struct fm_config {
      * FM_PREC_BF16X6 (round 5, OPT-IN, edge-message kernel only; node kernels and EdgeUpdate stay f32): three-term split -- hi + mid + lo bf16 = all 24
      * mantissa bits, six products per term, dropped products <= 3 * 2^-24 relative: f32-class accuracy on the bf16 matrix cores at the price of 6-byte
      * operands (weight stream, LDS).  Measured (profiles/r05c_*): every stage within 1.32x the f32 kernels' error against float64,
-     * 71 molecules/s at C3 (f32: 63): three planes leave room for ONE workgroup per CU.  A separately reported mode like FM_PREC_BF16X3. */
+     * 71 molecules/s at C3 (f32: 63): three planes leave room for ONE workgroup per CU.  A separately reported mode like FM_PREC_BF16X3.
+     * FM_PREC_F16X3 (round 5, OPT-IN): FM_PREC_BF16X3's kernels with IEEE-half planes -- hi + lo half = 22 of f32's 24 mantissa bits in the same 4 bytes per
+     * element and the same three products (v_mfma_f32_16x16x32_f16).  RANGE is the price: |activations| beyond 65504 are clamped (a finite, wrong result). */
     int32_t precision;
     /* --- ABI 4: remaining architecture switches of EndpointVectorField.__init__ that no shipped YAML enables */
     int32_t n_recycles;           /* vector_field.py:307: the conv / update stack runs n_recycles times over the same weights (0 or 1 = once) */
@@ -117,7 +119,7 @@ typedef struct fm_config {
                                    * whose pair tiles fill the chip | 1 = in every self-conditioned evaluation | -1 = off */
 } fm_config;
 
-enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1, FM_PREC_BF16X6 = 2 };
+enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1, FM_PREC_BF16X6 = 2, FM_PREC_F16X3 = 3 };
 
 /* one tensor of the reference state dict inside the host weight blob */
 typedef struct fm_tensor_desc {

@@ -196,6 +196,20 @@ void mfma16_bf16(const unsigned short* a8, const unsigned short* b8, float* c4) 
         c4[r] = acc;
     }
 }
+void mfma16_f16(const unsigned short* a8, const unsigned short* b8, float* c4) {
+    Worker* w = tw; Lane* l = w->cur; WaveScratch& ws = w->waves[l->wave];
+    int p = ws.gen & 1;
+    for (int q = 0; q < 8; ++q) { ws.ha[p][l->lane][q] = a8[q]; ws.hb[p][l->lane][q] = b8[q]; }
+    wave_rendezvous(ws);
+    auto f = [](unsigned short h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; };
+    int col = l->lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l->lane >> 4) * 4 + r;
+        float acc = c4[r];
+        for (int k = 0; k < 32; ++k) acc += f(ws.ha[p][(k >> 3) * 16 + row][k & 7]) * f(ws.hb[p][(k >> 3) * 16 + col][k & 7]);
+        c4[r] = acc;
+    }
+}
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
 void mfma32(float a, float b, float* c16) {
     Worker* w = tw; Lane* l = w->cur; WaveScratch& ws = w->waves[l->wave];

@@ -60,6 +60,7 @@ void mfma16(float a, float b, float* c4);          // 16x16x4 f32
 void mfma4(float a, float b, float* c4);           // 4x4x1, 16 blocks
 void mfma32(float a, float b, float* c16);         // 32x32x2 f32
 void mfma16_bf16(const unsigned short* a8, const unsigned short* b8, float* c4);   // 16x16x32 bf16
+void mfma16_f16(const unsigned short* a8, const unsigned short* b8, float* c4);    // 16x16x32 f16 (subnormals kept)
 unsigned long long ballot(int pred);
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 int lane_id();
@@ -123,6 +124,16 @@ static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f
     return emu_f32x4{t[0], t[1], t[2], t[3]};
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x4 emu_mfma_16x16x32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x4 c, int, int, int) {
+    const emu_u16x8 ai = __builtin_bit_cast(emu_u16x8, a), bi = __builtin_bit_cast(emu_u16x8, b);
+    unsigned short ha[8], hb[8];
+    for (int q = 0; q < 8; ++q) { ha[q] = ai[q]; hb[q] = bi[q]; }
+    float t[4] = {c[0], c[1], c[2], c[3]};
+    emu::mfma16_f16(ha, hb, t);
+    return emu_f32x4{t[0], t[1], t[2], t[3]};
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_mfma_16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
 

@@ -579,3 +579,23 @@ def test_three_term_split_precision_on_emulation(emu_lib, name, sizes, tile):
     worst = max(errs['bf16x6'][k] / max(errs['f32'][k], 2e-7) for k in errs['f32'])
     assert worst < 3, (worst, errs)                                  # per stage within a small factor of the f32 kernels' own error
     assert not all(torch.equal(outs['f32'][k], outs['bf16x6'][k]) for k in 'xace')
+
+
+@pytest.mark.parametrize('name,sizes', [('flowmol3', [4, 7, 2]), ('geom_ctmc', [6, 3]), ('dev_narrow', [5, 3])])
+def test_half_split_precision_on_emulation(emu_lib, name, sizes):
+    """Opt-in precision='f16x3' (round 5): the two-plane split kernels with IEEE-half planes (hi + lo half = 22 mantissa bits, three products on the emulated
+    v_mfma_f32_16x16x32_f16; edge messages, node kernel, EdgeUpdate): every stage inside the f32 kernels' own gate (2e-5 per stage, 1e-5 on the outputs), i.e.
+    f32-class where the bf16 planes need 5e-5 -- and not the exact f32 path bit for bit."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    orc = cpu_ref.OracleVF(cfg, sd)
+    errs, outs = {}, {}
+    for prec in ('f32', 'bf16x3', 'f16x3'):
+        eng = Engine(cfg, sd, device='cpu', lib=emu_lib, precision=prec)
+        errs[prec], out, ref = forward_compare(eng, orc, cfg, torch.tensor(sizes), 0.5, True)
+        outs[prec] = {k: v.clone() for k, v in out.items()}
+    bad = {k: v for k, v in errs['f16x3'].items() if not (v < (1e-5 if k.startswith('out.') else 2e-5))}
+    assert not bad, bad
+    assert errs['f16x3']['conv0.msg.s'] < 0.5 * errs['bf16x3']['conv0.msg.s'], (errs['f16x3']['conv0.msg.s'], errs['bf16x3']['conv0.msg.s'])
+    assert not all(torch.equal(outs['f32'][k], outs['f16x3'][k]) for k in 'xace')

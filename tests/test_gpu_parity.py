@@ -1113,31 +1113,32 @@ def test_three_term_split_is_f32_class_against_float64(regime, scale):
     sizes = torch.tensor([5, 12, 47, 2, 33])
     o64 = oracle_f64(cfg, sd)
     errs = {}
-    for prec in ('f32', 'bf16x3', 'bf16x6'):
+    for prec in ('f32', 'bf16x3', 'bf16x6', 'f16x3'):
         eng = Engine(cfg, sd, device='cuda:0', precision=prec)
         errs[prec], out, _ = forward_compare(eng, o64, cfg, sizes, 0.5, True, dtype=torch.float64)
         assert all(torch.isfinite(v).all() for v in out.values())
         eng.close()
-    common = [k for k in errs['f32'] if k in errs['bf16x6']]
-    ratio6 = {k: errs['bf16x6'][k] / errs['f32'][k] for k in common if errs['f32'][k] > 0}
-    ratio3 = {k: errs['bf16x3'][k] / errs['f32'][k] for k in common if k in errs['bf16x3'] and errs['f32'][k] > 0}
-    _report(f'three_term_split_vs_float64[{regime}]', {'stage_errors_vs_float64': {k: [errs['f32'][k], errs['bf16x3'].get(k), errs['bf16x6'][k]] for k in common},
-                                                       'worst_ratio_bf16x6_over_f32': max(ratio6.values()), 'worst_ratio_bf16x3_over_f32': max(ratio3.values())})
-    bad = {k: (errs['bf16x6'][k], errs['f32'][k]) for k in common if not errs['bf16x6'][k] <= 1.5 * errs['f32'][k] + 2e-7 * (scale ** 2)}
-    assert not bad, bad
+    common = [k for k in errs['f32'] if all(k in errs[p_] for p_ in ('bf16x3', 'bf16x6', 'f16x3'))]
+    worst = {p_: max(errs[p_][k] / errs['f32'][k] for k in common if errs['f32'][k] > 0) for p_ in ('bf16x3', 'bf16x6', 'f16x3')}
+    _report(f'three_term_split_vs_float64[{regime}]', {'stage_errors_vs_float64 [f32, bf16x3, bf16x6, f16x3]': {k: [errs[p_][k] for p_ in ('f32', 'bf16x3', 'bf16x6', 'f16x3')] for k in common},
+                                                       'worst_ratio_bf16x6_over_f32': worst['bf16x6'], 'worst_ratio_bf16x3_over_f32': worst['bf16x3'], 'worst_ratio_f16x3_over_f32': worst['f16x3']})
+    for p_, factor in (('bf16x6', 1.5), ('f16x3', 2.0)):          # the half split (22 of 24 mantissa bits) is held to 2x
+        bad = {k: (errs[p_][k], errs['f32'][k]) for k in common if not errs[p_][k] <= factor * errs['f32'][k] + 2e-7 * (scale ** 2)}
+        assert not bad, (p_, bad)
 
 
-def test_three_term_split_decisions_on_the_20m_fixture(golden_dir):
-    """... and its categorical decisions on the 64-molecule reference trajectory, audited like the f32 kernels' (teacher-forced, every differing
-    decision must be a near-tie): the count is reported next to f32's one event."""
+@pytest.mark.parametrize('precision', ['bf16x6', 'f16x3'])
+def test_three_term_split_decisions_on_the_20m_fixture(golden_dir, precision):
+    """... and the f32-class modes' categorical decisions on the 64-molecule reference trajectory, audited like the f32 kernels' (teacher-forced, every
+    differing decision must be a near-tie): the count is reported next to f32's one event."""
     from flowmol_amd.engine import Engine
     from parity_util import audit_long_decisions, integrate_long_teacher_forced
     g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / 'long_flowmol3_geom64_T250.npz').items()}
     cfg = presets.flowmol3()
-    eng = Engine(cfg, weights.long_fixture_weights(cfg, g), device='cuda:0', precision='bf16x6')
+    eng = Engine(cfg, weights.long_fixture_weights(cfg, g), device='cuda:0', precision=precision)
     traj, probs = integrate_long_teacher_forced(eng, cfg, g)
     res = audit_long_decisions(cfg, g, traj, probs)
-    _report('teacher_forced_audit[flowmol3_geom64_T250, bf16x6]', res)
+    _report(f'teacher_forced_audit[flowmol3_geom64_T250, {precision}]', res)
     assert not res['unexplained'], res['unexplained'][:5]
     assert len(res['events']) <= 4, res['events']
     x = traj['x'][-1].cpu()
@@ -1147,7 +1148,7 @@ def test_three_term_split_decisions_on_the_20m_fixture(golden_dir):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x6', 'f16x3'])
 def test_error_tracks_the_reference_rounding_sensitivity(precision):
     """Ill-conditioned regime (all weight matrices x3: rounding differences grow ~10x per convolution, the f32 reference itself drifts
     percent-level from its own float64 evaluation by the last conv): every stage's error against the f32 oracle stays within a small
