@@ -553,39 +553,10 @@ __device__ __forceinline__ void fm_wave_gemm_sp(f32x4 (&acc)[MT][NT], const unsi
     const unsigned short* aph = XH + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
     const unsigned short* apl = XL + (row0 + (lane & 15)) * LDP + 8 * (lane >> 4);
     fm_h8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-    // half planes: the two cross products (2^-11 of the result) go to an accumulator of their own, like the three-term mode's corrections -- its roundings are
-    // 2^-11 of a rounding of the full sum, which leaves one full-magnitude rounding per k32 block (the bf16 mode keeps its single accumulator: its error is
-    // the 16-bit representation, not the accumulation)
-#ifdef FM_F16_ONE_ACC          // dev-only: the half mode with ONE accumulator (16 VGPRs less in the edge kernel: 118 instead of 134, i.e. two workgroups per CU); profiles/r05f_*
-    constexpr bool SEP = false;
-#else
-    constexpr bool SEP = FMT == 1;
-#endif
-    f32x4 accs[SEP ? MT : 1][SEP ? NT : 1];
-    if constexpr (SEP) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    auto mma = [&](const fm_h8 (&ah)[MT], const fm_h8 (&al)[MT], const fm_h8 (&bh)[NT], const fm_h8 (&bl)[NT]) {
-        if constexpr (SEP) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = fm_mfma_16<1>(al[mt], bh[nt], accs[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) accs[mt][nt] = fm_mfma_16<1>(ah[mt], bl[nt], accs[mt][nt]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = fm_mfma_16<1>(ah[mt], bh[nt], acc[mt][nt]);
-        } else {
-            fm_sp_frag_mma<MT, NT, FMT>(acc, ah, al, bh, bl);
-        }
-    };
+    // One accumulator for all three products, in both plane formats.  (A separate accumulator for the half mode's two cross products was measured: no
+    // better on the hardware -- worst stage 1.42 x the f32 kernels' error against float64 vs 1.38 x with one -- and its 16 VGPRs push the edge kernel
+    // from 118 to 134, i.e. to ONE workgroup per CU: 93 instead of 107 molecules/s; profiles/r05f_*.)
+    auto mma = [&](const fm_h8 (&ah)[MT], const fm_h8 (&al)[MT], const fm_h8 (&bh)[NT], const fm_h8 (&bl)[NT]) { fm_sp_frag_mma<MT, NT, FMT>(acc, ah, al, bh, bl); };
     fm_sp_frag_load<MT, NT, LDP>(ah0, al0, bh0, bl0, aph, apl, wsp, ntiles, nt0, 0, lane);
     int kb = 0;
     for (; kb + 2 <= KB; kb += 2) {          // double-buffered: the fragments of block kb+1 are requested before the MFMAs of block kb issue
@@ -599,12 +570,6 @@ __device__ __forceinline__ void fm_wave_gemm_sp(f32x4 (&acc)[MT][NT], const unsi
         __builtin_amdgcn_sched_barrier(0);
     }
     if (kb < KB) mma(ah0, al0, bh0, bl0);
-    if constexpr (SEP) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += accs[mt][nt];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
