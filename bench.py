@@ -491,6 +491,29 @@ def secondary_legs(engines, dev, lib_digest, steps):
         sweep.append({k: o[k] for k in ('molecules', 'ms_per_step', 'value', 'steps', 'launches_per_step', 'kernels_us', 'event_pair_overhead_us', 'workload')
                       } | {'roofline': o.get('roofline')})
     out['latency_sweep'] = sweep
+    # the opt-in split-precision modes on the headline workload, each a short window (NOT the headline: `value` of the line is f32; these modes are
+    # selected by an explicit argument only -- accuracy of each against float64 and on the reference trajectories: DESIGN.md section 3, profiles/r05c_*, r05f_*)
+    opt = {}
+    c3_sizes = torch.full((1024,), 47, dtype=torch.int64)
+    for prec in ('f16x3', 'bf16x3', 'bf16x6'):
+        cfg3 = presets.flowmol3()
+        eng_p = Engine(cfg3, weights.synth_state_dict(cfg3, 0), device=dev, precision=prec)
+        L = Leg(eng_p, cfg3, c3_sizes, 250, False, 0, dev)
+        L.advance(3)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        L.advance(steps)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        opt[prec] = {'ms_per_step': ms, 'value': 1024 / (250 * ms / 1e3), 'unit': 'molecules/s at 250 timesteps', 'steps': steps, 'warmup': 3,
+                     'finite': bool(torch.isfinite(L.state['x_t']).all().item())}
+        del L
+        eng_p.close()
+        del eng_p
+        torch.cuda.empty_cache()
+    opt['note'] = ('opt-in arithmetic, never the default: f16x3 = hi + lo IEEE-half operands (22 mantissa bits, <= 1.4x the f32 kernels\' error per stage, operands clamped to +-65504); '
+                   'bf16x3 = hi + lo bf16 (16 bits, up to 21.6x); bf16x6 = hi + mid + lo bf16 for the edge messages only (24 bits, <= 1.32x)')
+    out['opt_in_precisions'] = opt
     out['note'] = ('secondary legs of the same run (rank 0, one GPU): windows of real trajectories after the headline leg; ms_per_step = wall clock over `steps` consecutive '
                    'integration steps between device synchronisations; value = molecules / (network evaluations per sample x ms_per_step)')
     return out
