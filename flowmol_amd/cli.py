@@ -32,6 +32,8 @@ def parse_args(argv=None):
     p.add_argument('--model_dir', type=Path, default=None, help='model directory holding checkpoints/last.ckpt')
     p.add_argument('--checkpoint', type=Path, default=None, help='path to a Lightning checkpoint')
     p.add_argument('--preset', type=str, default=None, help='architecture preset with synthetic weights: ' + ', '.join(sorted(__import__('flowmol_amd.presets', fromlist=['PRESETS']).PRESETS)))
+    p.add_argument('--precision', choices=('f32', 'f16x3', 'bf16x3', 'bf16x6'), default='f32',
+                   help="(not a reference flag) arithmetic of the big GEMMs: f32 = the reference's (default); f16x3 / bf16x3 / bf16x6 = opt-in split precision on the 16-bit matrix cores (DESIGN.md section 3)")
     p.add_argument('--output_file', type=Path, default=None)
     p.add_argument('--n_mols', type=int, default=100)
     p.add_argument('--n_atoms_per_mol', type=int, default=None)
@@ -58,6 +60,8 @@ def parse_args(argv=None):
 
 def load_model(args, engine_lib=None) -> FlowMol:
     kw = {'_engine_lib': engine_lib} if engine_lib is not None else {}
+    if getattr(args, 'precision', 'f32') != 'f32':
+        kw['precision'] = args.precision
     if args.preset is not None:
         return FlowMol.from_preset(args.preset, **kw)
     ckpt = args.checkpoint if args.checkpoint is not None else args.model_dir / 'checkpoints' / 'last.ckpt'

@@ -129,7 +129,7 @@ class FlowMol:
     def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], prefix: str = 'vector_field.',
                  n_atoms_hist: Optional[str] = None, _engine_lib=None, precision: Optional[str] = None):
         self.cfg = cfg.validate()
-        self.precision = precision or 'f32'  # 'bf16x3' = opt-in split-precision edge messages (Engine); explicit argument only, recorded in last_timing
+        self.precision = precision or 'f32'  # 'f16x3' / 'bf16x3' / 'bf16x6' = opt-in split precision (Engine); explicit argument only, recorded in last_timing
         self._sd = state_dict
         self._prefix = prefix
         self._lib = _engine_lib
@@ -542,8 +542,9 @@ pretrained_model_names = [
 ]
 
 
-def load_pretrained(model_name: str = 'flowmol3') -> FlowMol:
-    """Load ``<models_dir>/<model_name>/checkpoints/last.ckpt`` (reference flowmol/__init__.py:30-56).
+def load_pretrained(model_name: str = 'flowmol3', precision: Optional[str] = None) -> FlowMol:
+    """Load ``<models_dir>/<model_name>/checkpoints/last.ckpt`` (reference flowmol/__init__.py:30-56).  ``precision`` (not a reference argument;
+    None = 'f32', the reference's arithmetic) selects an opt-in split-precision mode of the engine ('f16x3', 'bf16x3', 'bf16x6').
 
     ``models_dir`` is ``$FLOWMOL_MODELS_DIR`` or ``flowmol_amd/trained_models``.  The reference downloads
     missing models with wget; there is no network in this environment, so a missing directory is an error
@@ -559,4 +560,6 @@ def load_pretrained(model_name: str = 'flowmol3') -> FlowMol:
     kw = {}
     if 'qm9' in model_name:
         kw['n_atoms_hist'] = 'qm9'
+    if precision is not None:
+        kw['precision'] = precision
     return FlowMol.load_from_checkpoint(ckpt, **kw)
