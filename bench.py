@@ -447,14 +447,15 @@ def secondary_legs(engines, dev, lib_digest, steps):
     from flowmol_amd import presets, weights
     from flowmol_amd.engine import Engine
 
-    def engine(preset):
-        if preset not in engines:
+    def engine(preset, tuning=None):
+        key = preset if not tuning else (preset, tuple(sorted(tuning.items())))
+        if key not in engines:
             cfg = presets.PRESETS[preset]()
-            engines[preset] = (cfg, Engine(cfg, weights.synth_state_dict(cfg, 0), device=dev, precision='f32'))
-        return engines[preset]
+            engines[key] = (cfg, Engine(cfg, weights.synth_state_dict(cfg, 0), device=dev, precision='f32', tuning=tuning))
+        return engines[key]
 
-    def leg(name, preset, sizes, T, traj, label, k_steps, warm=3, philox=False):
-        cfg, eng = engine(preset)
+    def leg(name, preset, sizes, T, traj, label, k_steps, warm=3, philox=False, tuning=None):
+        cfg, eng = engine(preset, tuning)
         L = Leg(eng, cfg, sizes, T, traj, 0, dev, philox=philox)
         L.advance(warm)
         torch.cuda.synchronize(dev)
@@ -484,13 +485,18 @@ def secondary_legs(engines, dev, lib_digest, steps):
     out['c2'] = leg('c2', 'qm9', torch.full((256,), 18, dtype=torch.int64), 100, False, 'qm9 model, 256 molecules x 18 atoms, n_timesteps=100 (BASELINE.json configs[1])', 4 * steps)
     c5_sizes, _, _ = job_sizes(1, 128, None, None)
     out['c5'] = leg('c5', 'geom_ctmc', c5_sizes, 500, True, 'geom_ctmc model, 128 molecules with sizes randint(5, 61, seed 0), n_timesteps=500, trajectory sink on (BASELINE.json configs[4])', 4 * steps)
-    sweep = []
-    for B in (1, 8, 32, 128):
-        o = leg(f'latency_{B}', 'flowmol3', torch.full((B,), 47, dtype=torch.int64), 250, False,
-                f"flowmol3 model, {B} molecule(s) x 47 atoms: per-step latency of network evaluation + CTMC update, in-kernel Philox noise (sample(rng='philox'): no torch RNG launches between the steps)", 64, warm=8, philox=True)
-        sweep.append({k: o[k] for k in ('molecules', 'ms_per_step', 'value', 'steps', 'launches_per_step', 'kernels_us', 'event_pair_overhead_us', 'workload')
-                      } | {'roofline': o.get('roofline')})
-    out['latency_sweep'] = sweep
+    # per-step latency in BOTH arithmetic modes: the default (canonical: a molecule's bits do not depend on its batch; launch choices that select another
+    # summation order are fixed) and the latency mode (FlowMol(canonical=False) / fm_config.canonical = -1: 4-node tiles, K-sliced 4-row node MLPs and the
+    # pair slab follow the batch size -- round 5's behaviour)
+    for key, tuning, what in (('latency_sweep', None, 'canonical arithmetic (default)'), ('latency_sweep_latency_mode', {'canonical': -1}, 'latency mode (canonical=False)')):
+        sweep = []
+        for B in (1, 8, 32, 128):
+            o = leg(f'latency_{B}', 'flowmol3', torch.full((B,), 47, dtype=torch.int64), 250, False,
+                    f"flowmol3 model, {B} molecule(s) x 47 atoms, {what}: per-step latency of network evaluation + CTMC update, in-kernel Philox noise (sample(rng='philox'): no torch RNG launches between the steps)",
+                    64, warm=8, philox=True, tuning=tuning)
+            sweep.append({k: o[k] for k in ('molecules', 'ms_per_step', 'value', 'steps', 'launches_per_step', 'kernels_us', 'event_pair_overhead_us', 'workload')
+                          } | {'roofline': o.get('roofline')})
+        out[key] = sweep
     # the opt-in split-precision modes on the headline workload, each a short window (NOT the headline: `value` of the line is f32; these modes are
     # selected by an explicit argument only -- accuracy of each against float64 and on the reference trajectories: DESIGN.md section 3, profiles/r05c_*, r05f_*)
     opt = {}
@@ -517,6 +523,37 @@ def secondary_legs(engines, dev, lib_digest, steps):
     out['note'] = ('secondary legs of the same run (rank 0, one GPU): windows of real trajectories after the headline leg; ms_per_step = wall clock over `steps` consecutive '
                    'integration steps between device synchronisations; value = molecules / (network evaluations per sample x ms_per_step)')
     return out
+
+
+def size_dist_leg(eng, cfg, world, rank, dev, B, T, steps, warm=3):
+    """The metric's own wording -- "molecules/sec at 250 timesteps (GEOM-drugs size dist)" -- on N ranks: ONE global list of B x N sizes drawn from the shipped
+    GEOM-drugs histogram (reference flowmol.py:461-471), dealt to the ranks by shard.partition_lpt (the only leg whose load balance is not trivially 1.0),
+    `steps` integration steps timed between barriers, MAX over ranks.  Returns the fields rank 0 puts at the top level of the line."""
+    sizes, parts, _ = job_sizes(world, B, None, 'geom_full_kekulized')
+    mine = sizes[parts[rank]]
+    L = Leg(eng, cfg, mine, T, False, rank, dev)
+    L.advance(warm)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    L.advance(steps)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ms = float(el.item()) * 1e3 / steps
+    evals = T if cfg.self_conditioning else T - 1
+    cost = (sizes * (sizes - 1)).double()
+    sc = torch.tensor([float(cost[p_].sum()) for p_ in parts])
+    finite = bool(torch.isfinite(L.state['x_t']).all().item())
+    del L
+    return {'value_geom_size_dist': B * world / (evals * ms / 1e3), 'ms_per_step_geom_size_dist': ms,
+            'workload_size_dist': f'flowmol3 model, {B * world} molecules with sizes ~ the shipped GEOM-drugs histogram (seed 1000: mean {float(sizes.double().mean()):.1f}, max {int(sizes.max())} atoms), '
+                                  f'n_timesteps={T}, dealt to {world} rank(s) by shard.partition_lpt; {steps} timed steps after {warm} warm-up steps, max over ranks',
+            'size_dist_shard_cost_max_over_mean': float(sc.max() / sc.mean()), 'size_dist_finite': finite}
 
 
 PARITY_MOLS_PER_RANK, PARITY_T, PARITY_SEED = 8, 12, 1234
@@ -585,8 +622,12 @@ def multi_gpu_parity(cfg, sd, eng, world, rank, dev, backend, n_atoms=None, T=No
         for mode in ('replicated', 'philox'):
             tok[mode] = int(sum((res[mode][k] != single[mode][k]).sum() for k in 'ace'))
             out[f'{mode}_x_rel'] = float((res[mode]['x'] - single[mode]['x']).abs().max() / single[mode]['x'].abs().max())
+            out[f'{mode}_x_bit_identical'] = bool(torch.equal(res[mode]['x'], single[mode]['x']))
         out['token_diffs'] = tok['replicated']
         out['x_rel'] = out.pop('replicated_x_rel')
+        out['x_bit_identical'] = out.pop('replicated_x_bit_identical')
+        canonical = eng.tuning.get('canonical', 0) >= 0       # canonical arithmetic (the default): a molecule's bits do not depend on its batch or shard
+        out['canonical'] = bool(canonical)
         out['philox_token_diffs'] = tok['philox']
         out['tokens_compared'] = int(sum(single['replicated'][k].numel() for k in 'ace'))
         out['ranks_hold_the_same_batch'] = all(i['digests'] == infos[0]['digests'] for i in infos)
@@ -599,9 +640,11 @@ def multi_gpu_parity(cfg, sd, eng, world, rank, dev, backend, n_atoms=None, T=No
         out['all_gather_bytes'] = slot * world
         out['all_gather_slot_bytes'] = slot
         out['payload_bytes_per_rank'] = [i['payload_bytes'] for i in infos]
-        out['ok'] = bool(out['token_diffs'] == 0 and out['philox_token_diffs'] == 0 and out['x_rel'] < 1e-4 and out['philox_x_rel'] < 1e-4 and out['ranks_hold_the_same_batch'])
+        out['ok'] = bool(out['token_diffs'] == 0 and out['philox_token_diffs'] == 0 and out['x_rel'] < 1e-4 and out['philox_x_rel'] < 1e-4 and out['ranks_hold_the_same_batch']
+                         and (not canonical or (out['x_bit_identical'] and out['philox_x_bit_identical'])))
         out['note'] = ("sample_distributed(noise='replicated' | 'philox') on all ranks vs the single-process sample() of the same seed on rank 0, before the timed region; "
-                       'token_diffs / x_rel = replicated mode (north star: indices bit-exact, coordinates within 1e-4 relative); a run with ok = false exits non-zero without timing anything')
+                       'token_diffs / x_rel = replicated mode (north star: indices bit-exact, coordinates within 1e-4 relative); with canonical arithmetic (the default) the coordinates '
+                       'must be BIT-IDENTICAL in both modes (x_bit_identical, philox_x_bit_identical); a run with ok = false exits non-zero without timing anything')
         verdict[0] = out
     dist.broadcast_object_list(verdict, src=0)
     return verdict[0]
@@ -874,9 +917,20 @@ def main():
     }
     if roofline:
         out['roofline'] = roofline
+    out['config']['canonical_arithmetic'] = eng.tuning.get('canonical', 0) >= 0
     if rank == 0 and world == 1 and args.workload == 'c3' and args.precision == 'f32' and args.size_dist is None and not args.no_secondary:
         del leg
         out['secondary'] = secondary_legs({args.preset: (cfg, eng)}, dev, lib_digest, args.secondary_steps)
+        # BASELINE.json's metric reads "(GEOM-drugs size dist)": that figure next to `value` (which north_star asks on fixed-size graphs), at the top level
+        g = out['secondary']['geom_size_dist']
+        out['value_geom_size_dist'], out['ms_per_step_geom_size_dist'] = g['value'], g['ms_per_step']
+        out['config']['workload_size_dist'] = g['workload'] + f"; {g['steps']} timed steps after {g['warmup']} warm-up steps"
+    elif world > 1 and args.workload == 'c3' and args.precision == 'f32' and args.size_dist is None and not args.no_secondary:
+        del leg        # every rank takes part (barriers); LPT-balanced GEOM sizes, max over ranks
+        sdl = size_dist_leg(eng, cfg, world, rank, dev, B, T, args.secondary_steps)
+        out['value_geom_size_dist'], out['ms_per_step_geom_size_dist'] = sdl['value_geom_size_dist'], sdl['ms_per_step_geom_size_dist']
+        out['config']['workload_size_dist'] = sdl['workload_size_dist']
+        out['config']['size_dist_shard_cost_max_over_mean'] = sdl['size_dist_shard_cost_max_over_mean']
     if rank == 0 and world == 1 and not args.no_api_e2e:
         out['api_end_to_end'] = api_end_to_end(args, all_sizes, T, dev, wl['traj'])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

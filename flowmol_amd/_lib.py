@@ -11,7 +11,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-FM_ABI_VERSION = 6
+FM_ABI_VERSION = 7
 FM_DFM_CAMPBELL, FM_DFM_GAT = 0, 1
 FM_NOISE_TENSORS, FM_NOISE_PHILOX = 0, 1
 FM_PREC_F32, FM_PREC_BF16X3, FM_PREC_BF16X6, FM_PREC_F16X3 = 0, 1, 2, 3
@@ -34,10 +34,12 @@ class fm_config(C.Structure):
         # ABI 5: launch-tuning overrides, 0 = automatic (see include/flowmol_hip.h)
         ('tile_edge', C.c_int32), ('tile_node', C.c_int32), ('tile_edge_update', C.c_int32), ('xcd_swizzle', C.c_int32),
         ('fuse_node', C.c_int32), ('pair_mlps', C.c_int32), ('mlp_small_tiles', C.c_int32), ('pair_slab', C.c_int32),
+        # ABI 7: 0 / 1 = canonical arithmetic (a molecule's bits do not depend on its batch), -1 = latency mode
+        ('canonical', C.c_int32),
     ]
 
 
-TUNING_FIELDS = ('tile_edge', 'tile_node', 'tile_edge_update', 'xcd_swizzle', 'fuse_node', 'pair_mlps', 'mlp_small_tiles', 'pair_slab')
+TUNING_FIELDS = ('tile_edge', 'tile_node', 'tile_edge_update', 'xcd_swizzle', 'fuse_node', 'pair_mlps', 'mlp_small_tiles', 'pair_slab', 'canonical')
 
 
 class fm_tensor_desc(C.Structure):

@@ -124,8 +124,6 @@ def _dist_setup(args):
 
 def run(args, engine_lib=None):
     world, rank = _dist_setup(args)
-    if world > 1 and (args.xt_traj or args.ep_traj):
-        raise NotImplementedError('trajectory output is single-GPU (sample_distributed gathers final states only)')
     if args.seed is not None:
         torch.manual_seed(args.seed)        # the reference uses lightning's seed_everything (test.py:70-71)
     model = load_model(args, engine_lib).to(args.device).eval()
@@ -136,7 +134,7 @@ def run(args, engine_lib=None):
         bs = min(args.n_mols - len(molecules), args.max_batch_size)
         common = dict(n_timesteps=args.n_timesteps, stochasticity=args.stochasticity, high_confidence_threshold=args.hc_thresh)
         n_atoms = model.sample_n_atoms(bs) if args.n_atoms_per_mol is None else torch.full((bs,), args.n_atoms_per_mol, dtype=torch.long)
-        if world == 0 or args.xt_traj or args.ep_traj:
+        if world == 0:
             molecules.extend(model.sample(n_atoms, device=args.device, xt_traj=args.xt_traj, ep_traj=args.ep_traj, **common))
         else:
             # every rank must shard the SAME size list: rank 0's draw is broadcast; noise streams differ per rank
@@ -145,7 +143,7 @@ def run(args, engine_lib=None):
             dist.broadcast(nb, src=0)
             if args.seed is not None:
                 torch.manual_seed(args.seed + 7919 * (b + 1) + rank)
-            molecules.extend(model.sample_distributed(nb.cpu(), **common))
+            molecules.extend(model.sample_distributed(nb.cpu(), xt_traj=args.xt_traj, ep_traj=args.ep_traj, **common))      # trajectories: a second gather of the frames
     sampling_time = time.time() - start
     if rank != 0:            # every rank holds the gathered batch; rank 0 writes
         return molecules, sampling_time

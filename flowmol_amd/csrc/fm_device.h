@@ -487,7 +487,8 @@ __device__ __forceinline__ f32x4 fm_mfma_16(fm_h8 a, fm_h8 b, f32x4 c) {
 template <int FMT = 0>
 __device__ __forceinline__ void fm_split(float v, unsigned short& hi, unsigned short& lo) {
     if constexpr (FMT == 1) {
-        v = fminf(fmaxf(v, -65504.f), 65504.f);        // one v_med3_f32
+        const float cl = fminf(fmaxf(v, -65504.f), 65504.f);        // one v_med3_f32
+        v = (v != v) ? v : cl;                          // NaN stays NaN (fmaxf(NaN, x) = x would turn a blown-up network into finite +-65504: ADVICE r5)
         const _Float16 h = (_Float16)v;                // round-to-nearest-even
         const _Float16 l = (_Float16)(v - (float)h);   // v - hi is exact in f32
         hi = __builtin_bit_cast(unsigned short, h);
@@ -893,13 +894,14 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     }
     FM_MARKB(5);
     // gates = Linear(256 -> VOUT)(scalar out)   (gvp.py:122-128): NJ = (TM/16) x (VOP/16) single-tile jobs, K = 256.
-    // With fewer jobs than half the waves, K is split in two: waves [0,NJ) take k < 128 and write G, waves [NJ,2NJ)
-    // take k >= 128 and write a partial tile in Vh (dead since the scalar GEMM); the gating loop adds the parts and the bias.  16-row tiles: four
-    // K quarters (profiles/r04i: the gate GEMM of a small batch is a latency chain of 16 k-steps on 2-4 waves).
+    // K is split in two: jobs [0,NJ) take k < 128 and write G, jobs [NJ,2NJ) take k >= 128 and write a partial tile in Vh (dead since the
+    // scalar GEMM); the gating loop adds the parts and the bias.
     // (The 64-MFMA dependent chain of an unsplit job was the critical path of this phase: profiles/r01c.)
     constexpr int NJ = (TM / 16) * (VOP / 16);
-    constexpr bool FIT4 = (3 + (SP ? 1 : 0)) * TM * FM_LDG <= T::VH_FLOATS;      // room for three more partial gate tiles in Vh (not for V = 16 split precision)
-    constexpr int KS = (NW >= 4 * NJ && FIT4) ? 4 : (NW >= 2 * NJ) ? 2 : 1;       // 16-row tiles: four K quarters, all eight waves busy
+    // CANONICAL ORDER (round 6): two K halves for EVERY tile height, so that a row's gates -- like every other sum of this file -- do not depend on whether
+    // its batch ran 16-, 32- or 64-row tiles (a molecule alone and the same molecule inside a 1024-batch give the same bits).  Round 4's four K quarters
+    // for 16-row tiles were worth 1.4 of 68 us per node tile (profiles/r04j); 64-row tiles (A/B only) take two rounds of eight jobs.
+    constexpr int KS = 2;
     // partial q >= 1 lives in slot (q - 1) of Vh (dead since the scalar GEMM), in units of a gate tile; split-precision instances keep G itself in
     // slot 1 of Vh, so their partials 2, 3 move up one slot
     auto gpart = [&](int q) { return Vh + (SP && q >= 2 ? q : q - 1) * TM * FM_LDG; };
@@ -989,16 +991,23 @@ __device__ __forceinline__ float fm_group_sum(float s) {
 
 // LayerNorm statistics of one LDS row handled by a group of LPR consecutive lanes (LPR = 8 or 16):
 // two-pass mean / biased variance like torch.nn.functional.layer_norm.  All lanes must call it.
+// CANONICAL ORDER (round 6): a row owned by 32 lanes (16-row tiles) is summed in the 16-lane order of the 32-row tiles -- lanes sub and sub ^ 16 form the
+// same strided partial sums and each aligned group of 16 runs the same butterfly, so both halves hold identical statistics -- which makes every LayerNorm
+// independent of the tile height its batch happened to run (FM_LN_LANES<LPR> / fm_ln_sub).  8-lane rows (64-row tiles: A/B configurations only) keep their own order.
+template <int LPR> struct FmLnLanes { static constexpr int value = LPR > 16 ? 16 : LPR; };
+template <int LPR> __device__ __forceinline__ int fm_ln_sub(int sub) { return LPR > 16 ? (sub & 15) : sub; }
 template <int LPR>
 __device__ __forceinline__ void fm_row_stats(const float* row, int n, int sub, float& mean, float& rstd) {
+    constexpr int L = FmLnLanes<LPR>::value;
+    const int s0 = fm_ln_sub<LPR>(sub);
     float s = 0.f;
-    for (int c = sub; c < n; c += LPR) s += row[c];
-    s = fm_group_sum<LPR>(s);
+    for (int c = s0; c < n; c += L) s += row[c];
+    s = fm_group_sum<L>(s);
     const float inv_n = 1.0f / (float)n;          // n is a power of two in every use: s * inv_n == s / n bit for bit
     mean = s * inv_n;
     float q = 0.f;
-    for (int c = sub; c < n; c += LPR) { const float d = row[c] - mean; q = fm_fma(d, d, q); }
-    q = fm_group_sum<LPR>(q);
+    for (int c = s0; c < n; c += L) { const float d = row[c] - mean; q = fm_fma(d, d, q); }
+    q = fm_group_sum<L>(q);
     rstd = __builtin_amdgcn_rsqf(fm_fma(q, inv_n, 1e-5f));     // v_rsq_f32 (~1 ulp) instead of IEEE 1/sqrt (about 25 VALU less per row lane)
 }
 __device__ __forceinline__ void fm_row_stats8(const float* row, int n, int sub, float& mean, float& rstd) {

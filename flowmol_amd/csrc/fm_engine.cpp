@@ -72,6 +72,10 @@ struct fm_ctx {
     int node_rg = 0;          // this batch runs the node kernel on tiles of 4 * node_rg nodes (RG instances; 1, 2, 3 in the 16-row frame, 5 in the 32-row
                               // frame): chosen per bound batch, fm_config.tile_node = 4 / 8 / 12 / 20 forces it
     int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
+    // fm_config.canonical >= 0 (default): every launch choice that selects another f32 summation order is FIXED -- regular node tiles (no 4 RG-node instances),
+    // no 4-row node MLPs, the pair slab in every evaluation that can use it -- so that a molecule's result does not depend on the size or composition of
+    // its batch (see FM_CHUNK_E in fm_kernels.h for the aggregation order); -1: those three follow the batch size (lowest latency for batches of a few molecules)
+    bool canonical = true;
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
@@ -89,6 +93,7 @@ struct fm_ctx {
     int nmax = 0;             // atoms of the largest molecule of the bound batch
     FmBatch b{};
     int n_tiles_e = 0, n_tiles_n = 0, n_tiles_u = 0;
+    int n_tiles_msg = 0;      // molecule-aligned edge-message tiles of the bound batch (FmBatch::n_tiles)
     float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
     float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *Psd = nullptr, *PVd = nullptr;
     float* s_tab_base = nullptr; size_t tab_slot_floats = 0;      // FM_TAB_SLOTS embedding tables (one per step of a chunk); s_tab = the current step's
@@ -225,6 +230,7 @@ struct Fix { const void** slot; size_t off; };
 
 struct Builder {
     Arena A; std::vector<Fix> fix;
+    int sp_fmt = 0;          // plane format of the split-precision copies this builder packs: 0 = bf16, 1 = IEEE half (weights times 2^6); set once by fm_create
     template <class T> void put(const T*& slot, const std::vector<float>& v) { fix.push_back({(const void**)&slot, A.add(v)}); }
     void putv(const void*& slot, const std::vector<float>& v) { fix.push_back({&slot, A.add(v)}); }
 };
@@ -239,14 +245,13 @@ void pack_linear(Builder& B, const float2*& slot, const float* W, int out, int i
     }));
 }
 // the same logical matrix as pack_linear, K padded to a multiple of 32, as split-precision planes
-thread_local int g_sp_fmt = 0;          // plane format of the split-precision copies being packed (set by fm_create for the duration of its packing: single-threaded per call)
 void pack_linear_sp(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, int Np, const std::function<int(int)>& kmap, int npl = 2) {
     const int K32 = (Kp + 31) / 32 * 32;
     B.putv(slot, pack_sp(K32, Np, [&](int k, int n) -> float {
         if (n >= out || k >= Kp) return 0.f;
         const int kk = kmap(k);
         return (kk >= 0 && kk < in) ? W[(size_t)n * in + kk] : 0.f;
-    }, npl, g_sp_fmt));
+    }, npl, B.sp_fmt));
 }
 void pack_linear4(Builder& B, const void*& slot, const float* W, int out, int in, int Kp, const std::function<int(int)>& kmap, int G = 4) {
     B.putv(slot, pack4(Kp, [&](int k, int n) -> float {
@@ -386,7 +391,7 @@ void launch_mlp_pair(Launch& L, const char* name, FmMlpArgs a, const MlpW& wa, i
 // forces it.  ONE predicate for the workspace layout (the Q tables, U KB each, exist only when it holds) and for every evaluation.
 inline int pq_convs(const fm_ctx* c, long long U) {
     if (c->n_pq == 0 || U <= 0 || ld_for(c->sc_edge.H) > 164) return 0;      // the slab GEMM reads [rbf | ef] rows at the pitch 164 of a 128-wide hidden tile
-    return (c->pq_forced || (U + 31) / 32 >= 16LL * c->n_cus) ? c->n_pq : 0;
+    return (c->pq_forced || c->canonical || (U + 31) / 32 >= 16LL * c->n_cus) ? c->n_pq : 0;      // canonical: a rule that does not read the batch size
 }
 
 // ---------------------------------------------------------------------------------------- one network evaluation
@@ -413,7 +418,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
     // node-side MLPs on 4-row tiles (fm_k_mlp4) while such tiles fit one per CU: a 16-row tile's two 256-wide layers are ~7 us of matrix time on one CU
     // whatever the batch, four rows on v_mfma_f32_4x4x1 are the layers' weight stream; fm_config.mlp_small_tiles = 2 forces it (1 / -1: never)
-    const bool mlp4 = c->node_head_W1q && !dense && (c->mlp4_forced >= 0 ? c->mlp4_forced != 0 : (N + 3) / 4 <= c->n_cus);
+    const bool mlp4 = c->node_head_W1q && !dense && (c->mlp4_forced >= 0 ? c->mlp4_forced != 0 : (!c->canonical && (N + 3) / 4 <= c->n_cus));      // K slices: another summation order -> never in canonical mode
     const int tiles4 = (N + 3) / 4;
     // pair-slab convolutions of this evaluation (first pass only; FmMlpArgs::slabQ0): self-conditioned evaluations with at least four rounds of
     // 32-row pair tiles (measured neutral on small batches: the table costs a kernel phase, the saving is matrix-pipe time they are not bound by)
@@ -480,7 +485,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
 
     const dim3 blk(FM_THREADS);
     const dim3 gn((N + FM_TM - 1) / FM_TM), ge((E + FM_TM - 1) / FM_TM);     // 64-row kernels
-    const dim3 gnt((N + TN - 1) / TN), get((E + TE - 1) / TE);              // GVP kernels
+    const dim3 gnt((N + TN - 1) / TN), get(c->n_tiles_msg);                 // GVP kernels (edge tiles: molecule-aligned, FmBatch::tile_desc)
     // fm_config.fuse_node = -1 keeps round 1's launch sequence: node_proj / pos_update / node_proj_asd as kernels of their own (0 / 1 = fused)
     const bool fuse = c->fuse_node != 0 && HX == 0;      // destination-feature models keep the unfused node sequence (their projection GVP reuses the tile)
     const int n_pass = cf.n_convs * (cf.n_recycles > 1 ? cf.n_recycles : 1);       // vector_field.py:307: the whole stack again, same weights
@@ -541,7 +546,6 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         // aggregated-message taps go through scratch of their own (Ps / PV, which served in round 1, are outputs of the fused kernel)
         nu.agg_s = tagg ? c->tap_s : nullptr;
         nu.agg_v = tagg ? c->tap_v : nullptr;
-        nu.tile_e = TE;
         if (fuse) {
             if (it + 1 < n_pass) { const ConvW& nx = c->conv[(i + 1) % cf.n_convs]; nu.Wps = nx.Wps; nu.Wps4 = nx.Wps4; nu.Ps = c->Ps; nu.Wpv = nx.Wpv; nu.PV = c->PV; }
             if (u >= 0) {
@@ -600,7 +604,8 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
                 FmEdgeUpdSpW sw{uw.W1_sp, uw.W2_sp};
                 if (cf.precision == FM_PREC_F16X3) L("edge_update", fm_k_edge_update_sp<32, 1>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
                 else L("edge_update", fm_k_edge_update_sp<32>, dim3((E + 31) / 32), blk, lds_edge_upd_sp(32), eu, sw);
-            } else if (it == n_pass - 1 && c->fuse_head && c->F == 128 && c->tm_eupd == 32 && !(taps_on && c->taps.count("upd" + std::to_string(i) + ".ef"))) {
+            } else if (it == n_pass - 1 && c->fuse_head && c->F == 128 && c->tm_eupd == 32 && (long long)c->nmax * (c->nmax - 1) * 512 < 0x7ffffe00LL      // the tile's pair rows are
+                       && !(taps_on && c->taps.count("upd" + std::to_string(i) + ".ef"))) {      // gathered with 31-bit offsets inside ONE molecule's edge rows (n < 2048 atoms); larger: separate head
                 // the evaluation's last EdgeUpdate: its rows feed the edge head and nothing else -- tiles of 16 pairs, the head as the epilogue, no ef store
                 eu.hW1 = c->edge_head.W1; eu.hb1 = c->edge_head.b1; eu.hW2 = c->edge_head.W2; eu.hb2 = c->edge_head.b2; eu.out_e = out->e; eu.ne = c->ne;
                 L("edge_update_head", fm_k_edge_update<32, false, true>, dim3((U + 15) / 16), blk, lds_edge_upd(32), eu);
@@ -787,12 +792,12 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     const int H0 = V + 1 + HX, KU0 = pad8(H0 + 4), PVW = c->PVW = pvw_of(V, HX);
     if (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_BF16X3 && cfg->precision != FM_PREC_BF16X6 && cfg->precision != FM_PREC_F16X3) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: unknown precision %d", cfg->precision); }
     if (cfg->precision != FM_PREC_F32 && HX > 0) { delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: split precision is built for models without destination features"); }
-    g_sp_fmt = cfg->precision == FM_PREC_F16X3 ? 1 : 0;
     const int na = c->na = cfg->n_atom_types, nc = c->nc = cfg->n_charges, ne = c->ne = cfg->n_bond_types;
     c->rbf_mu_step = cfg->rbf_dmax / (float)(cfg->rbf_dim - 1);
     c->rbf_inv_sigma = 1.0f / (cfg->rbf_dmax / (float)cfg->rbf_dim);
     Blob bl{host_blob, tensors, n_tensors, {}};
     Builder B;
+    B.sp_fmt = cfg->precision == FM_PREC_F16X3 ? 1 : 0;
     auto bail = [&](const std::string& m) { std::string mm = m; delete c; return fail(nullptr, FM_ERR_WEIGHTS, "fm_create: %s", mm.c_str()); };
     auto ident = [](int k) { return k; };
 
@@ -998,7 +1003,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
             B.putv(uw.Wasd_sp, pack_sp(256, 256, [&](int k, int n) -> float {
                 const int o = n < 128 ? n : n - 128;
                 if (k >= S || o >= F) return 0.f;
-                return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }, 2, g_sp_fmt));
+                return W1[(size_t)o * kin + (n < 128 ? 0 : S) + k]; }, 2, B.sp_fmt));
             pack_linear_sp(B, uw.W1_sp, W1, F, kin, 160, 128, [&](int k) { return k < 128 ? (k < F ? 2 * S + k : -1) : (with_d ? 2 * S + F + (k - 128) : -1); });
             pack_linear_sp(B, uw.W2_sp, W2, F, F, 128, 128, ident);
         }
@@ -1040,6 +1045,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     // pair-slab hoist: the convolutions that run before any molecule update see pair-symmetric edge features and distances
     c->n_pq = 0;
     c->pq_forced = cfg->pair_slab > 0;
+    c->canonical = cfg->canonical >= 0;
     if (cfg->pair_slab >= 0 && HX == 0 && cfg->precision == FM_PREC_F32 && cfg->self_conditioning)
         for (int i = 0; i < cfg->n_convs && i < 2; ++i) {
             bool clean = true;
@@ -1113,8 +1119,8 @@ int fm_destroy(fm_ctx* c) {
 
 // ---------------------------------------------------------------------------------------- workspace
 struct WsLayout {
-    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node, node_rg;
-    size_t off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
+    int B, N, E, U, P, nmax, tab_rows, tab_kp, tm_edge, tm_node, node_rg, n_tiles_msg;
+    size_t off_mol_tile, off_tile_desc, off_mol_node, off_mol_edge, off_mol_pair, off_node_mol, off_first_edge, off_esrc, off_edst, off_epair, off_pe0, off_pe1,
         off_pair_mol, off_s, off_v, off_xw, off_ef, off_Ps, off_Asd, off_PV, off_part_s, off_part_v, off_Psd, off_PVd, off_stab, off_bx, off_ba,
         off_bc, off_be, off_tap_s, off_tap_v, off_gid, off_sa1, off_sc1, off_se1, off_Q0, off_Q1, total;
 };
@@ -1144,7 +1150,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     int tn = c->tm_node_forced;
     if (!tn) {
         tn = (N + 31) / 32 <= c->n_cus ? 16 : 32;
-        if (rg_ok) {
+        if (rg_ok && !c->canonical) {      // the RG instances split K over two wave groups: another summation order -> latency mode only (or forced)
             static const int cand[] = {4, 8, 12, 16, 20};
             for (int r : cand) if ((N + r - 1) / r <= c->n_cus) { tn = r; break; }
         }
@@ -1156,10 +1162,14 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     }
     w.tm_node = tn;
     if ((c->HX || !c->cfg.has_mask) && (w.tm_node > 32)) w.tm_node = 32;
-    w.P = (nmax - 2) / w.tm_edge + 2; w.nmax = nmax;
+    w.P = nmax > 1 ? (nmax - 2) / FM_CHUNK_E + 2 : 1; w.nmax = nmax;      // chunks of FM_CHUNK_E rows a destination's n - 1 in-edges can touch
+    long long nt = 0;
+    for (int i = 0; i < B; ++i) nt += ((long long)n_atoms[i] * (n_atoms[i] - 1) + w.tm_edge - 1) / w.tm_edge;      // every molecule starts a tile
+    w.n_tiles_msg = (int)nt;
     w.tab_rows = c->tab_rows; w.tab_kp = c->tab_kp;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    w.off_mol_tile = take((size_t)(B + 1) * 4); w.off_tile_desc = take((size_t)w.n_tiles_msg * 16);
     w.off_mol_node = take((size_t)(B + 1) * 4); w.off_mol_edge = take((size_t)(B + 1) * 4); w.off_mol_pair = take((size_t)(B + 1) * 4);
     w.off_node_mol = take((size_t)N * 4); w.off_first_edge = take((size_t)N * 4);
     w.off_esrc = take((size_t)E * 4); w.off_edst = take((size_t)E * 4); w.off_epair = take((size_t)E * 4);
@@ -1223,15 +1233,20 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     if ((uintptr_t)workspace % 256) return fail(c, FM_ERR_INVALID, "fm_batch_bind: workspace must be 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
-    rc = stage_acquire(c, st, 3 * (size_t)(B + 1) + (size_t)B);
+    rc = stage_acquire(c, st, 4 * (size_t)(B + 1) + (size_t)B);
     if (rc) return rc;
-    int32_t* no = c->stage; int32_t* eo = no + (B + 1); int32_t* po = eo + (B + 1); int32_t* ids = po + (B + 1);
-    no[0] = eo[0] = po[0] = 0;
-    for (int i = 0; i < B; ++i) { const int n = n_atoms[i]; no[i + 1] = no[i] + n; eo[i + 1] = eo[i] + n * (n - 1); po[i + 1] = po[i] + n * (n - 1) / 2; ids[i] = i; }
+    int32_t* no = c->stage; int32_t* eo = no + (B + 1); int32_t* po = eo + (B + 1); int32_t* to = po + (B + 1); int32_t* ids = to + (B + 1);
+    no[0] = eo[0] = po[0] = to[0] = 0;
+    for (int i = 0; i < B; ++i) {
+        const int n = n_atoms[i];
+        no[i + 1] = no[i] + n; eo[i + 1] = eo[i] + n * (n - 1); po[i + 1] = po[i] + n * (n - 1) / 2; ids[i] = i;
+        to[i + 1] = to[i] + (n * (n - 1) + w.tm_edge - 1) / w.tm_edge;
+    }
     {   // a copy that fails after earlier ones were enqueued must not leave the staging buffer unguarded: the event is recorded either way
         hipError_t e_ = hipMemcpyAsync(base + w.off_mol_node, no, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
         if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_mol_edge, eo, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
         if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_mol_pair, po, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
+        if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_mol_tile, to, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st);
         if (e_ == hipSuccess) e_ = hipMemcpyAsync(base + w.off_gid, ids, (size_t)B * 4, hipMemcpyHostToDevice, st);
         rc = stage_release(c, st);
         if (e_ != hipSuccess) return fail(c, FM_ERR_HIP, "fm_batch_bind: descriptor copy failed: %s", hipGetErrorString(e_));
@@ -1239,6 +1254,8 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     }
     FmBatch& b = c->b;
     b.B = B; b.N = w.N; b.E = w.E; b.U = w.U; b.P = w.P;
+    b.n_tiles = w.n_tiles_msg; b.tile_rows = w.tm_edge;
+    b.mol_tile_off = (const int*)(base + w.off_mol_tile); b.tile_desc = (int4*)(base + w.off_tile_desc);
     b.mol_node_off = (const int*)(base + w.off_mol_node); b.mol_edge_off = (const int*)(base + w.off_mol_edge); b.mol_pair_off = (const int*)(base + w.off_mol_pair);
     b.node_mol = (int*)(base + w.off_node_mol); b.node_first_edge = (int*)(base + w.off_first_edge);
     b.e_src = (int*)(base + w.off_esrc); b.e_dst = (int*)(base + w.off_edst); b.e_pair = (int*)(base + w.off_epair);
@@ -1259,7 +1276,7 @@ int fm_batch_bind(fm_ctx* c, void* stream, const int32_t* n_atoms, int B, void* 
     const int work = w.E > w.N ? w.E : w.N;
     L("batch_setup", fm_k_batch_setup, dim3((work + 255) / 256), dim3(256), 0, b);
     if (L.rc) return L.rc;
-    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node; c->node_rg = w.node_rg;
+    c->bound = true; c->nmax = w.nmax; c->tm_edge = w.tm_edge; c->tm_node = w.tm_node; c->node_rg = w.node_rg; c->n_tiles_msg = w.n_tiles_msg;
     return FM_OK;
 }
 

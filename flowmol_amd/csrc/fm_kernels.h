@@ -13,7 +13,8 @@
 // ------------------------------------------------------------------------------------------------
 struct FmBatch {
     int B, N, E, U;          // molecules, nodes, directed edges, unordered pairs (E = 2U)
-    int P;                   // max number of 64-edge tiles one destination's in-edges can span
+    int P;                   // max number of FM_CHUNK_E-row chunks one destination's in-edges can span
+    int n_tiles, tile_rows;  // edge-message tiles of the bound batch: tile_rows (16 | 32 | 64) rows each, every molecule's first edge row starts a tile
     const int* mol_node_off; // [B+1]
     const int* mol_edge_off; // [B+1]  (internal, dst-major directed edges)
     const int* mol_pair_off; // [B+1]  (reference upper-triangle order)
@@ -25,7 +26,18 @@ struct FmBatch {
     int* p_e0;               // [U]  internal edge id of (src=a -> dst=b), a<b   ("upper" edge)
     int* p_e1;               // [U]  internal edge id of (src=b -> dst=a)        ("lower" edge)
     int* pair_mol;           // [U]
+    const int* mol_tile_off; // [B+1] first edge-message tile of every molecule (host-computed: sum of ceil(n (n - 1) / tile_rows))
+    int4* tile_desc;         // [n_tiles] {first edge row, rows that exist (1 .. tile_rows), the molecule's first edge row, molecule}
 };
+
+// CANONICAL AGGREGATION ORDER (round 6).  In the reference a molecule's result is a function of the molecule and its noise rows only: every reduction is per
+// molecule (gvp.py:491-492 message sum, ctmc_utils.py:11-20 purity counts, vector_field.py:347-350 centring).  Up to round 5 the f32 ORDER of the message sum
+// depended on where the molecule sat in the batch: tiles were cut from the batch-global edge list, so a destination's in-edges met tile boundaries at
+// offset-dependent places.  Now every molecule's directed-edge rows start at a tile boundary (the last tile of a molecule is ragged; the edge arrays stay
+// compact -- only the tile -> row map changes) and a destination's rows are summed in chunks of FM_CHUNK_E rows counted from the MOLECULE's first row:
+// rows of a chunk in order, chunks in order.  16 divides every tile height, so 16-, 32- and 64-row tiles produce the same partial sums, and a molecule
+// alone, in a 1024-batch or in any shard of it gives bit-identical messages.  Cost at 1024 x 47 atoms: 68 tiles of 32 rows for 2162 rows = 0.65 % padding.
+#define FM_CHUNK_E 16
 
 // Internal edge order: per molecule, destination-major: edge (dst=i, src=j), j != i, sits at
 // off + i*(n-1) + (j - (j>i)).  The reference's order (upper triangle row-major, then the same pairs
@@ -55,6 +67,14 @@ __global__ void __launch_bounds__(256) fm_k_batch_setup(FmBatch b) {
         b.e_pair[gid] = pair;
         if (j < i) { b.p_e0[pair] = gid; b.pair_mol[pair] = lo; }   // src=a<b=dst : the reference's upper edge
         else b.p_e1[pair] = gid;
+    }
+    if (gid < b.n_tiles) {              // n_tiles <= E: every tile holds at least one row
+        int lo = 0, hi = b.B;           // largest m with mol_tile_off[m] <= gid (molecules without edges own no tile: equal offsets, the search lands on the owner)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.mol_tile_off[mid] <= gid) lo = mid; else hi = mid; }
+        const int moff = b.mol_edge_off[lo];
+        const int e0 = moff + (gid - b.mol_tile_off[lo]) * b.tile_rows;
+        const int left = b.mol_edge_off[lo + 1] - e0;
+        b.tile_desc[gid] = make_int4(e0, left < b.tile_rows ? left : b.tile_rows, moff, lo);
     }
 }
 
@@ -692,15 +712,15 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // one contiguous range of tiles, so a molecule's Ps / PV rows (shared by its ~n^2/TM consecutive tiles) are filled
     // into one L2 instead of all eight.
     const int tile = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int e0 = tile * TM;
-    if (e0 >= a.b.E) return;          // padding workgroups of the chunked grid (uniform exit, before any barrier)
+    if (tile >= a.b.n_tiles) return;  // padding workgroups of the chunked grid (uniform exit, before any barrier)
+    const int4 td = a.b.tile_desc[tile];      // wave-uniform: one scalar load
+    const int e0 = td.x, left = td.y, moff = td.z;      // first row, rows that exist, the molecule's first row (e0 - moff is a multiple of TM)
     FM_MARK_DECL
     // (A) the edge-feature rows depend only on the tile index: request them before anything else (HBM latency)
     constexpr int NEF = PQ ? 1 : TM * 32 / NTH;
     float4 efv[NEF];
     if constexpr (!PQ) {
-        const int left = a.b.E - e0;                         // rows of this tile that exist (ragged last tile: the range check zero-fills)
-        const auto rs = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)(left < TM ? left : TM) * 512u);
+        const auto rs = fm_buf(a.ef + (size_t)e0 * 128, (unsigned)left * 512u);      // ragged last tile of a molecule: the range check zero-fills
 #pragma unroll
         for (int k = 0; k < NEF; ++k) efv[k] = (FM_ABLATE & 16) ? make_float4(0.1f, 0.2f, 0.3f, 0.4f) : fm_buf_f32x4(rs, tid * 16 + k * NTH * 16, 0);
     }
@@ -709,7 +729,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         // PQ: byte offsets of the rows' pairs in Q, relative to the tile's smallest pair id (a wave-wide min: the tile's pairs lie within a few
         // molecules, so the relative offsets stay far below the 31-bit limit of a buffer offset however large the batch's Q table is)
         const int e = e0 + tid;
-        const int pr = (tid < TM && e < a.b.E) ? a.b.e_pair[e] : 0x7fffffff;
+        const int pr = tid < left ? a.b.e_pair[e] : 0x7fffffff;
         int mn = pr;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
@@ -720,9 +740,9 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         const int e = e0 + tid;
         int s = -1, d = -1, piece = 0;
         float gx = 0.f, gy = 0.f, gz = 0.f, dist = 0.f;
-        if (e < a.b.E) {
+        if (tid < left) {
             s = a.b.e_src[e]; d = a.b.e_dst[e];
-            piece = tile - a.b.node_first_edge[d] / TM;
+            piece = (e - moff) / FM_CHUNK_E - (a.b.node_first_edge[d] - moff) / FM_CHUNK_E;      // chunk of the row minus the first chunk of its destination, both counted from the molecule's first row
             // x_diff = x[src] - x[dst]; d = sqrt(max(|.|^2,1e-8)) + 1e-8; xhat = x_diff / d  (vector_field.py:381-383)
             const float dx = a.x[s * 3] - a.x[d * 3], dy = a.x[s * 3 + 1] - a.x[d * 3 + 1], dz = a.x[s * 3 + 2] - a.x[d * 3 + 2];
             dist = fm_norm3(dx, dy, dz) + 1e-8f;
@@ -849,11 +869,12 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         }
     }
     FM_MARK(40);
-    // segmented sum over the rows of each destination (rows are dst-sorted).  One thread per output column; the column's TM
+    // segmented sum over the rows of each destination (rows are dst-sorted), cut at the molecule-relative chunk boundaries (FM_CHUNK_E: tile rows 15, 31, 47 --
+    // tiles start at multiples of TM from the molecule's first row).  One thread per output column; the column's TM
     // values are pulled into registers with independent LDS reads and summed there (the first version walked the rows with
     // dependent LDS reads: 15k cycles).  Where a destination's rows end inside the tile is ONE wave-uniform bit mask (a ballot of
     // dst[r] != dst[r+1]), so the segment logic is a scalar bit test per row; destination id and piece are fetched (LDS
-    // broadcast + v_readfirstlane) only at the 1-2 segment ends of a tile.  Round 1 made all 2*TM ids wave-uniform with
+    // broadcast + v_readfirstlane) only at the 2-5 segment ends of a tile.  Round 1 made all 2*TM ids wave-uniform with
     // v_readlane: 64 VALU per wave and tile, each of which costs matrix-pipe time (profiles/r02a ablation).  Rows past the end
     // of the edge list (ragged last tile) come after the last set bit, so whatever they add to `run` is never stored.
     static_assert(NTH == 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
@@ -862,7 +883,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
         const int lr = lane < TM ? lane : TM - 1;
         const int myd = m_dst[lr];
         const int nxd = m_dst[lr + 1 < TM ? lr + 1 : TM - 1];
-        const unsigned long long ends = __ballot(lane < TM && myd >= 0 && (lr + 1 == TM || nxd != myd));
+        const unsigned long long ends = __ballot(lane < TM && myd >= 0 && (lr + 1 == TM || nxd != myd || (lr & (FM_CHUNK_E - 1)) == FM_CHUNK_E - 1));      // a destination's rows end, or a chunk does
         const bool is_s = wave < 4;                                       // columns 0..255: scalars
         const int cv = tid - 256;                                         // vector column = xyz*V + channel
         // one instance per tile kind, so that the row stride is a compile-time constant and the TM LDS reads of a column are
@@ -899,7 +920,6 @@ struct FmNodeUpdArgs {
     float* s; float* v;              // (N,256), (N,3,V) updated in place
     const float* part_s; const float* part_v;
     float inv_z;                     // 1 / z; < 0: divide by the node's in-degree (message_norm 'mean')
-    int tile_e;                      // rows per tile of the edge-message kernel (defines the pieces)
     FmGvpW g0, g1, g2;
     const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
     float* agg_s; float* agg_v;      // optional debug taps of the aggregated messages, else null
@@ -929,11 +949,11 @@ __device__ __forceinline__ void fm_gvp_layernorm_tile(float* X, float* Vin, cons
     fm_row_stats<LPR>(X + r * FM_LDX, s_width, sub, mean, rstd);      // zero-padded columns beyond s_width stay 0: gain and bias are padded with 0
     // vector norm: vn = sqrt(mean_c max(|v_c|^2, 1e-8) + eps) + eps
     float q = 0.f;
-    for (int u = sub; u < V; u += LPR) {
+    for (int u = fm_ln_sub<LPR>(sub); u < V; u += FmLnLanes<LPR>::value) {      // canonical order (fm_row_stats): 16 lanes per row whatever the tile height
         const float vx = Vin[(0 * TM + r) * T::LDVI + u], vy = Vin[(1 * TM + r) * T::LDVI + u], vz = Vin[(2 * TM + r) * T::LDVI + u];
         q += fmaxf(fm_fma(vz, vz, fm_fma(vy, vy, vx * vx)), 1e-8f);
     }
-    q = fm_group_sum<LPR>(q);
+    q = fm_group_sum<FmLnLanes<LPR>::value>(q);
     const float vn = __builtin_amdgcn_sqrtf(fm_fma(q, 1.0f / (float)V, 1e-5f)) + 1e-5f;
     const float inv_vn = __builtin_amdgcn_rcpf(vn);          // hardware sqrt / rcp (~1 ulp each)
     const bool valid = r < rows_valid && row0 + r < nrows;       // rows_valid < TM: the RG instances' tiles hold 4 RG nodes in a TM-row frame
@@ -1003,8 +1023,8 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
             const int m = a.b.node_mol[n];
             const int deg = a.b.mol_node_off[m + 1] - a.b.mol_node_off[m] - 1;
             if (deg > 0) {
-                const int fe = a.b.node_first_edge[n];
-                np = (fe + deg - 1) / a.tile_e - fe / a.tile_e + 1;
+                const int fe = a.b.node_first_edge[n] - a.b.mol_edge_off[m];       // counted from the molecule's first row, like the chunks
+                np = (fe + deg - 1) / FM_CHUNK_E - fe / FM_CHUNK_E + 1;
             }
             if (iz < 0.f) iz = deg > 0 ? 1.0f / (float)deg : 0.f;
         }
@@ -1324,17 +1344,6 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
             }
         }
     }
-#ifdef FM_ALT_FILL
-    // dev-only (-DFM_ALT_FILL): round 4's EARLIER arrangement of this fill (index arithmetic per pass, profiles/r04x).  Same arithmetic per element; under
-    // -ffp-contract=fast the two arrangements produced different output bits (the compiler fused fm_rbf's d - k mu in one and not in the other), with
-    // contraction off they must not -- tools/fingerprint_matrix.py compares the two builds: identical under every tuning (profiles/r05c_fingerprint_matrix_fill_arrangements.jsonl)
-#pragma unroll
-    for (int k = 0; k < NEF; ++k) {
-        const int idx = tid + k * FM_THREADS, r = idx >> 5, c4 = idx & 31;
-        *reinterpret_cast<float4*>(X + r * LDX + 4 * c4) = efv[k];
-        X[r * LDX + 128 + c4] = fm_rbf(m_d[r], c4, a.rbf_mu_step, a.rbf_inv_sigma);
-    }
-#else
     {   // thread -> (row fr + 16 k, float4 column c4): one address per thread, the passes are immediate offsets
         constexpr int RP = FM_THREADS / 32;
         const int fr = tid >> 5, c4 = tid & 31;
@@ -1346,7 +1355,6 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update(FmEdgeUpdArgs a) 
             xr[k * RP * LDX] = fm_rbf(m_d[fr + k * RP], c4, a.rbf_mu_step, a.rbf_inv_sigma);      // rows past the edge list (d = 0): finite junk, dropped by the final store's range check
         }
     }
-#endif
     __syncthreads();
     float* ho = Hb + (4 * (lane >> 4)) * LDH + col;
     float* xo = X + (4 * (lane >> 4)) * LDX + col;

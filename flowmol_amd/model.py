@@ -127,8 +127,12 @@ class FlowMol:
     canonical_feat_order = ['x', 'a', 'c', 'e']
 
     def __init__(self, cfg: VFConfig, state_dict: Dict[str, torch.Tensor], prefix: str = 'vector_field.',
-                 n_atoms_hist: Optional[str] = None, _engine_lib=None, precision: Optional[str] = None):
+                 n_atoms_hist: Optional[str] = None, _engine_lib=None, precision: Optional[str] = None, canonical: bool = True):
         self.cfg = cfg.validate()
+        # canonical arithmetic (fm_config.canonical, default on): a molecule's coordinates and tokens are bit-for-bit independent of the batch it is sampled in
+        # (size, position, sharding over GPUs) -- the reference's semantics, where every reduction is per molecule.  canonical=False = latency mode: launch
+        # choices follow the batch size (one molecule ~0.54 instead of ~0.65 ms per step); differently composed batches then agree to f32 summation order only.
+        self.canonical = bool(canonical)
         self.precision = precision or 'f32'  # 'f16x3' / 'bf16x3' / 'bf16x6' = opt-in split precision (Engine); explicit argument only, recorded in last_timing
         self._sd = state_dict
         self._prefix = prefix
@@ -183,7 +187,8 @@ class FlowMol:
             if self.device.type != 'cuda' and self._lib is None:
                 raise RuntimeError('flowmol_amd runs on MI355X only: move the model to a GPU with .cuda() '
                                    '(there is no CPU implementation of the sampling path)')
-            self._engine = Engine(self.cfg, self._sd, device=self.device, prefix=self._prefix, lib=self._lib, precision=self.precision)
+            self._engine = Engine(self.cfg, self._sd, device=self.device, prefix=self._prefix, lib=self._lib, precision=self.precision,
+                                  tuning=None if self.canonical else {'canonical': -1})
         return self._engine
 
     # ------------------------------------------------------------------ sizes
@@ -221,18 +226,24 @@ class FlowMol:
         ``sample(n_atoms)`` with that seed (to float summation order), at world_size times the (cheap) RNG work.
         ``noise='philox'`` (performance mode): prior and CTMC noise are drawn INSIDE the kernels from per-molecule Philox4x32-10
         streams keyed by (seed, original molecule index, step, modality): no noise tensors at all, and every molecule's
-        trajectory is the same for any world size or batch composition (tokens identical; coordinates to float summation order).
-        Trajectories are not gathered."""
+        trajectory is the same for any world size or batch composition -- bit for bit with canonical arithmetic (the default).
+
+        Everything one ``sample()`` call of the reference takes (flowmol.py:489-493) shards too: ``prior`` (a reference-format prior dict of the WHOLE
+        batch: every rank keeps its molecules' rows, flowmol.py:534-545) and ``xt_traj`` / ``ep_traj`` (flowmol.py:564-589, test.py:212-257): each rank
+        records its shard's frames in HBM in the compact token format and a SECOND all-gather (``shard.gather_frames``; only when trajectories
+        are asked for) gives every rank the full batch's frames in the caller's order."""
         import torch.distributed as dist
         from . import shard
-        if kwargs.get('xt_traj') or kwargs.get('ep_traj') or kwargs.get('prior') is not None:
-            raise NotImplementedError('sample_distributed gathers final states only (no trajectories / caller-supplied priors)')
         if noise not in ('per_rank', 'replicated', 'philox'):
             raise ValueError(f"noise must be 'per_rank', 'replicated' or 'philox', got {noise!r}")
         n_atoms = torch.as_tensor(n_atoms).detach().to('cpu', torch.int64)
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         parts = shard.partition_lpt(n_atoms, world)
         dev = self.engine.device
+        xt_traj, ep_traj = bool(kwargs.pop('xt_traj', False)), bool(kwargs.pop('ep_traj', False))
+        visualize = xt_traj or ep_traj
+        if kwargs.get('prior') is not None:
+            kwargs['prior'] = shard.slice_prior(kwargs['prior'], n_atoms, parts[rank])
         if noise == 'replicated':
             pairs = n_atoms * (n_atoms - 1) // 2
             mine = parts[rank]
@@ -246,18 +257,26 @@ class FlowMol:
             sd = seed.to(dev if dist.get_backend(group) == 'nccl' else 'cpu')
             dist.broadcast(sd, src=0, group=group)
             kwargs.update(rng='philox', _philox=int(sd.item()), _mol_ids=parts[rank])
+        local_frames = None
         if len(parts[rank]):
-            local, _ = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors='device', **kwargs)   # stays in HBM
+            got = self.sample(n_atoms[parts[rank]], n_timesteps=n_timesteps, return_tensors='device', xt_traj=visualize, _frames=visualize, **kwargs)   # stays in HBM
+            local, local_frames = got[0], (got[2] if visualize else None)
         else:
             i32 = dict(dtype=torch.int32, device=dev)
             local = {'x': torch.zeros(0, 3, device=dev), 'a': torch.zeros(0, **i32), 'c': torch.zeros(0, **i32), 'e': torch.zeros(0, **i32)}
         full_dev = shard.gather_results(local, n_atoms, parts, group=group)
+        frames_dev = None
+        if visualize:
+            ts = kwargs.get('tspan')
+            n_frames = (self.default_n_timesteps if n_timesteps is None else n_timesteps) if ts is None else int(ts.shape[0])
+            frames_dev = shard.gather_frames(local_frames, n_atoms, parts, n_frames, dev, group=group)
         if return_tensors == 'device':
-            return full_dev, n_atoms
+            return (full_dev, n_atoms, frames_dev) if visualize else (full_dev, n_atoms)
         full = _to_host(full_dev)            # one packed device->host copy of the whole gathered batch (1.7 KB/molecule)
+        frames = {k: v.cpu() for k, v in frames_dev.items()} if visualize else None
         if return_tensors:
-            return full, n_atoms
-        return self._package(full, n_atoms, None, False, False)
+            return (full, n_atoms, frames) if visualize else (full, n_atoms)
+        return self._package(full, n_atoms, frames, xt_traj, ep_traj)
 
     @torch.no_grad()
     def sample(self, n_atoms: torch.Tensor, n_timesteps: int = None, device=None, stochasticity=None,
@@ -279,7 +298,7 @@ class FlowMol:
         dfm_type = kwargs.get('dfm_type') or self.cfg.dfm_type
         if dfm_type not in ('campbell', 'gat'):
             raise ValueError(f"Invalid dfm_type: {dfm_type}")
-        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows', '_noise_for_step', 'rng', '_philox', '_mol_ids'}
+        unknown = set(kwargs) - {'dfm_type', 'tspan', 'cat_temp_func', 'forward_weight_func', 'inv_temp_func', '_rows', '_noise_for_step', 'rng', '_philox', '_mol_ids', '_frames'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         visualize = bool(xt_traj or ep_traj)
@@ -342,16 +361,15 @@ class FlowMol:
         out_dev = {k: state[f'{k}_t'] for k in 'xace'}
         if return_tensors == 'device':
             self.last_timing = {'integrate': t1 - t0, 'precision': eng.precision}
+            if kwargs.get('_frames'):          # sample_distributed: this shard's frames stay in HBM for the second gather
+                return out_dev, n_atoms, (_frames_of(init, traj) if visualize else None)
             return out_dev, n_atoms
         out = _to_host(out_dev)
         t2 = time.perf_counter()
         self.last_timing = {'integrate': t1 - t0, 'to_host': t2 - t1, 'precision': eng.precision}
         if return_tensors:
             return out, n_atoms
-        frames = None
-        if visualize:
-            frames = {k: torch.cat([init[k].unsqueeze(0), traj[k]]).cpu() for k in 'xace'}
-            frames.update({f'{k}_1_pred': traj[f'{k}1'].cpu() for k in 'xace'})
+        frames = {k: v.cpu() for k, v in _frames_of(init, traj).items()} if visualize else None
         mols = self._package(out, n_atoms, frames, xt_traj, ep_traj)
         self.last_timing['package'] = time.perf_counter() - t2
         return mols
@@ -416,7 +434,7 @@ class FlowMol:
         molecule takes their argmax.  RNG order = the reference's: randn(N,3) on the device, then a, c, e priors on the CPU generator."""
         if kwargs.get('rng', 'torch') != 'torch' or '_philox' in kwargs:
             raise NotImplementedError("per-molecule Philox noise covers CTMC models; endpoint models draw their priors with torch (noise='per_rank' / 'replicated')")
-        unknown = set(kwargs) - {'inv_temp_func', 'tspan', '_rows', 'rng'}
+        unknown = set(kwargs) - {'inv_temp_func', 'tspan', '_rows', 'rng', '_frames'}
         if unknown:
             raise TypeError(f'sample() got unexpected keyword arguments {sorted(unknown)}')
         eng, cfg = self.engine, self.cfg
@@ -476,14 +494,13 @@ class FlowMol:
             return {k: state[f'{k}_t'] for k in 'xace'}, n_atoms
         out_dev = {'x': state['x_t'], 'a': state['a_t'].argmax(-1).int(), 'c': state['c_t'].argmax(-1).int(), 'e': state['e_t'].argmax(-1).int()}
         if return_tensors == 'device':
+            if kwargs.get('_frames'):
+                return out_dev, n_atoms, (_frames_of(init, traj) if visualize else None)
             return out_dev, n_atoms
         out = _to_host(out_dev)
         if return_tensors:
             return out, n_atoms
-        frames = None
-        if visualize:
-            frames = {k: torch.cat([init[k].unsqueeze(0), traj[k]]).cpu() for k in 'xace'}
-            frames.update({f'{k}_1_pred': traj[f'{k}1'].cpu() for k in 'xace'})
+        frames = {k: v.cpu() for k, v in _frames_of(init, traj).items()} if visualize else None
         return self._package(out, n_atoms, frames, xt_traj, ep_traj)
 
     # ------------------------------------------------------------------ helpers
@@ -522,6 +539,14 @@ class FlowMol:
                                         ctmc_mol=self.cfg.has_mask, explicit_aromaticity=self.explicit_aromaticity, traj_frames=tf,
                                         build_xt_traj=xt_traj, build_ep_traj=ep_traj, n_charges=self.n_atom_charges))
         return mols
+
+
+def _frames_of(init: Dict[str, torch.Tensor], traj: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Compact frames of a visualised run on the device: 'x', 'a', 'c', 'e' = the prior + the state after every step (T frames), '*_1_pred' = every step's
+    endpoint prediction (T - 1 frames) -- the frame set of the reference (ctmc_vector_field.py:188-202,235-283), tokens instead of one-hots."""
+    frames = {k: torch.cat([init[k].unsqueeze(0), traj[k]]) for k in 'xace'}
+    frames.update({f'{k}_1_pred': traj[f'{k}1'] for k in 'xace'})
+    return frames
 
 
 def _to_host(dev_out: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 6
+#define FM_ABI_VERSION 7
 #define FM_MAX_CONVS 16
 
 typedef enum fm_status {
@@ -116,7 +116,18 @@ typedef struct fm_config {
     /* --- ABI 6 */
     int32_t pair_slab;            /* [rbf | ef] slab of the first edge GVP once per unordered pair for the convolutions before the first molecule
                                    * update (pair-symmetric inputs; self-conditioned f32 models without destination features): 0 = in evaluations
-                                   * whose pair tiles fill the chip | 1 = in every self-conditioned evaluation | -1 = off */
+                                   * whose pair tiles fill the chip (canonical mode: in every one) | 1 = in every self-conditioned evaluation | -1 = off */
+    /* --- ABI 7: canonical arithmetic.  In the reference a molecule's result is a function of the molecule and its noise rows only -- every reduction is per
+     * molecule (flowmol/models/gvp.py:491-492, flowmol/utils/ctmc_utils.py:11-20, flowmol/models/vector_field.py:347-350).  0 / 1 (default): the library gives the
+     * same guarantee BIT FOR BIT: the f32 summation order of everything computed for a molecule depends on the molecule alone -- edge-message tiles start at the
+     * molecule's first edge row and in-edges are summed in 16-row chunks counted from it, LayerNorm statistics and gate sums have one order for every tile
+     * height, and the launch choices that would select another order (4-row node tiles, K-sliced 4-row node MLPs, pair slab on / off) are fixed instead of
+     * following the batch size.  A molecule alone, inside a 1024-batch, in any shard of it and on 1 or 8 GPUs gives identical coordinates and tokens for
+     * identical noise.  Holds for the automatic tile heights (16 / 32 rows) and across explicit tile_edge / tile_node 16 | 32; 64-row tiles and forced
+     * tile_node 4..20 / mlp_small_tiles 2 / pair_slab -1 are other (self-consistent) orders.
+     * -1: latency mode -- those three choices follow the batch size (round 5's behaviour: one molecule 0.54 instead of ~0.65 ms per step); results then agree
+     * between differently composed batches to f32 summation order only. */
+    int32_t canonical;
 } fm_config;
 
 enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1, FM_PREC_BF16X6 = 2, FM_PREC_F16X3 = 3 };

@@ -551,6 +551,11 @@ LONG_CASES = {       # tag: (preset, sizes, T, weight scale, prior seed, noise s
     # NodePositionUpdate x 128): the endpoint prediction moves every atom by ~4.6 % of the coordinate scale per evaluation, so x_rel over 250 steps is a
     # strong statistic for 16 molecules (the unit-weight fixtures move 0.04 %: VERDICT r4 weak #3), on a well-conditioned trajectory (1-ulp test: 2e-7)
     'flowmol3_geom16_T250_pos128': ('flowmol3', [41, 45, 57, 43, 54, 58, 46, 42, 29, 38, 44, 53, 66, 46, 48, 32], 250, 1.0, 39, 40, 128.0),
+    # the same 16 sizes with the categorical output heads' last Linear x 256 (weights.scaled_weights: cat_head_scale): head logit gaps of tens instead of
+    # < 1, i.e. the regime of a TRAINED model -- most classes of the tempered distribution exactly 0, rows with p == 1.0, exact zeros (log 0 = -inf) and
+    # denormals in p, near-one-hot self-conditioning inputs -- over a free-running 250-step trajectory (measured with
+    # the oracle on two GEOM-sized molecules: p == 1 in 16-100 % of the rows, exact zeros in up to 50 % of the edge probabilities, denormals in up to 29 %)
+    'flowmol3_geom16_T250_heads256': ('flowmol3', [41, 45, 57, 43, 54, 58, 46, 42, 29, 38, 44, 53, 66, 46, 48, 32], 250, 1.0, 43, 44, 1.0, 256.0),
 }
 LONG_X_STRIDE = 10
 
@@ -559,8 +564,9 @@ def gen_integrate_long(ns, tag):
     from flowmol_amd.engine import StepNoise
     name, sizes, T, scale, seed_prior, seed_noise = LONG_CASES[tag][:6]
     pos_scale = LONG_CASES[tag][6] if len(LONG_CASES[tag]) > 6 else 1.0
+    head_scale = LONG_CASES[tag][7] if len(LONG_CASES[tag]) > 7 else 1.0
     cfg = presets.PRESETS[name]()
-    sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale, pos_scale)
+    sd = weights.scaled_weights(weights.synth_state_dict(cfg, 0), scale, pos_scale, head_scale)
     vf = ref_standin.build_reference_vf(ns, cfg, sd)
     n_atoms = torch.tensor(sizes)
     g, upper, nb, eb = ref_standin.build_reference_graph(ns, n_atoms)
@@ -591,7 +597,7 @@ def gen_integrate_long(ns, tag):
     B = len(sizes)
     u8 = lambda t_: t_.to(torch.uint8)
     cat = lambda key, half=False: torch.cat([(f[key][:, :f[key].shape[1] // 2] if half else f[key]).argmax(-1) for f in frames], dim=1)
-    out = {'n_atoms': n_atoms, 'T': T, 'weight_scale': scale, **({'pos_head_scale': pos_scale} if pos_scale != 1 else {}), 'seed_prior': seed_prior, 'seed_noise': seed_noise, 'x_0': x0,
+    out = {'n_atoms': n_atoms, 'T': T, 'weight_scale': scale, **({'pos_head_scale': pos_scale} if pos_scale != 1 else {}), **({'cat_head_scale': head_scale} if head_scale != 1 else {}), 'seed_prior': seed_prior, 'seed_noise': seed_noise, 'x_0': x0,
            'x_1': gout.ndata['x_1'], 'a_1': gout.ndata['a_1'].argmax(-1), 'c_1': gout.ndata['c_1'].argmax(-1),
            'e_1_upper': gout.edata['e_1'][upper].argmax(-1),
            'e_1_sym': torch.equal(gout.edata['e_1'][upper], gout.edata['e_1'][~upper]),
@@ -672,10 +678,20 @@ def gen_priors(ns):
 def main():
     """no arguments: every fixture (the three long-horizon runs take ~20 min of the reference on 8 threads);
     ``long`` / ``long:<tag>``: only those; ``--skip-long``: everything else."""
+    import argparse
+    ap = argparse.ArgumentParser(prog='python -m oracle.make_golden', description='(Re)generate tests/golden/*.npz from the reference under /root/reference. '
+                                 'Without arguments EVERY fixture is rewritten (about an hour on 8 threads; they regenerate bit for bit).')
+    ap.add_argument('what', nargs='*', metavar='WHAT', help="'long' = every long-horizon fixture, 'long:<tag>' = that one "
+                    f"(tags: {', '.join(LONG_CASES)}), 'traj_frames' = only the reference-format frame fixture; nothing = everything")
+    ap.add_argument('--skip-long', action='store_true', help='everything except the long-horizon fixtures')
+    ns_args = ap.parse_args()
+    bad = [a for a in ns_args.what if not (a == 'traj_frames' or a == 'long' or (a.startswith('long:') and a.split(':', 1)[1] in LONG_CASES))]
+    if bad:
+        ap.error(f'unknown fixture selector(s) {bad}')
+    args = list(ns_args.what) + (['--skip-long'] if ns_args.skip_long else [])
     torch.set_num_threads(8)
     OUT.mkdir(parents=True, exist_ok=True)
     ns = ref_standin.import_reference()
-    args = sys.argv[1:]
     if 'traj_frames' in args:          # only that fixture
         gen_traj_frames(ns)
         return

@@ -174,7 +174,7 @@ def test_sample_distributed_replicated_noise_equals_single_process(emu_lib_path,
     for r in range(world):
         for k in 'ace':
             assert torch.equal(res[r][k], single[k].to(res[r][k].dtype))
-        torch.testing.assert_close(res[r]['x'], single['x'], rtol=1e-5, atol=1e-5)    # tile alignment changes the summation order
+        assert torch.equal(res[r]['x'], single['x'])      # canonical arithmetic: a molecule's bits do not depend on the shard it was computed in
 
 
 def _philox_worker(rank, world, port, sizes, q):
@@ -215,7 +215,80 @@ def test_sample_distributed_philox_is_independent_of_the_world_size(emu_lib_path
     single, _ = model.sample(torch.tensor(sizes), n_timesteps=3, return_tensors=True, rng='philox', _philox=seed)
     for k in 'ace':
         assert torch.equal(res[0][k], single[k].to(res[0][k].dtype))
-    torch.testing.assert_close(res[0]['x'], single['x'], rtol=1e-5, atol=1e-5)
+    assert torch.equal(res[0]['x'], single['x'])          # canonical arithmetic: bit for bit on 1 or 2 ranks
+
+
+def _traj_worker(rank, world, port, sizes, q, preset, with_prior):
+    """sample_distributed with everything one sample() call can do: trajectory frames (second gather) and a caller-supplied prior (sliced per rank)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pathlib import Path
+        import flowmol_amd as flowmol
+        from flowmol_amd import _lib
+        emu = _lib.load(Path(__file__).resolve().parent / 'emu' / 'libflowmol_emu.so')
+        model = flowmol.FlowMol.from_preset(preset, _engine_lib=emu).to('cpu')
+        n_atoms = torch.tensor(sizes)
+        prior = _reference_prior(model.cfg, n_atoms) if with_prior else None
+        torch.manual_seed(100)
+        full, n, frames = model.sample_distributed(n_atoms, n_timesteps=4, return_tensors=True, noise='replicated', xt_traj=True, ep_traj=True, prior=prior)
+        torch.manual_seed(100)
+        mols = model.sample_distributed(n_atoms, n_timesteps=4, noise='replicated', xt_traj=True, ep_traj=True, prior=prior)
+        blocks = [len(m.traj_mol_blocks(ep_traj=False)) for m in mols] + [len(m.traj_mol_blocks(ep_traj=True)) for m in mols]
+        q.put((rank, {k: v.numpy().copy() for k, v in full.items()}, {k: v.numpy().copy() for k, v in frames.items()}, blocks))
+    except Exception as e:
+        q.put((rank, repr(e), None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference_prior(cfg, n_atoms):
+    """A prior dict in the reference's format (flowmol.py:534-545) for a CTMC model: centred positions, mask one-hots, e_0 per directed edge."""
+    from oracle import cpu_ref
+    batch = cpu_ref.build_batch(n_atoms)
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(batch.N, 3, generator=g)
+    x0 = x0 - cpu_ref.segment_mean(x0, batch.node_batch_idx, batch.B)[batch.node_batch_idx]
+    return {'x_0': x0, 'a_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_atom_types), 'c_0': cpu_ref.ctmc_masked_prior(batch.N, cfg.n_charges),
+            'e_0': cpu_ref.edge_prior(batch.upper_edge_mask, cfg.n_bond_types), 'fake_atoms': True}
+
+
+@pytest.mark.parametrize('preset,world,with_prior', [('qm9', 2, False), ('qm9', 3, True), ('endpoint_small', 2, False)])
+def test_sample_distributed_trajectories_and_priors_equal_single_process(emu_lib_path, preset, world, with_prior):
+    """the sharded path does everything one sample() call of the reference does (flowmol.py:489-493,534-545,564-589): xt_traj / ep_traj
+    (every frame of every molecule, gathered with a second all-gather) and a caller-supplied prior (sliced per rank) -- frames, final state and
+    the packaged molecules' trajectory lengths equal the single-process sample() of the same seed BIT FOR BIT; three ranks for four molecules
+    incl. unequal parts."""
+    import flowmol_amd as flowmol
+    from flowmol_amd import _lib
+    sizes = [4, 6, 3, 5]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_traj_worker, args=(r, world, port, sizes, q, preset, with_prior)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert not [g_ for g_ in got if isinstance(g_[1], str)], got
+    model = flowmol.FlowMol.from_preset(preset, _engine_lib=_lib.load(emu_lib_path)).to('cpu')
+    n_atoms = torch.tensor(sizes)
+    prior = _reference_prior(model.cfg, n_atoms) if with_prior else None
+    torch.manual_seed(100)
+    mols = model.sample(n_atoms, n_timesteps=4, xt_traj=True, ep_traj=True, prior=prior)
+    pairs = [n * (n - 1) // 2 for n in sizes]
+    for rank, full, frames, blocks in got:
+        assert blocks == [4] * len(sizes) + [3] * len(sizes)                      # T frames / T - 1 endpoint frames per molecule
+        no = po = 0
+        for i, m in enumerate(mols):
+            n, u = sizes[i], pairs[i]
+            assert torch.equal(torch.from_numpy(full['x'][no:no + n]), m.x_1) and torch.equal(torch.from_numpy(full['a'][no:no + n]).long(), m.a_1.long())
+            for k, v in m.traj_frames.items():
+                lo, w = (po, u) if k.startswith('e') else (no, n)
+                assert torch.equal(torch.from_numpy(frames[k][:, lo:lo + w]).to(v.dtype), v), (rank, i, k)
+            no += n; po += u
 
 
 def _bench_parity_worker(rank, world, port, sizes, q):

@@ -152,7 +152,12 @@ def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
     big = res['categorical_decisions'] > 10_000_000
     assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0, res
     if big:
-        assert len(res['molecules_with_state_diffs']) <= 2, res
+        # numeric ceilings next to the molecule count, and the diverging molecules must be the AUDITED near-tie molecules -- 31 (step 113: a charge
+        # row's purity 1.8e-7 above the 0.9 threshold) and 58 (step 79: two sampled charge candidates 2.7e-6 apart), the two events of the teacher-forced
+        # audit below -- so that a regression in any other molecule cannot hide behind the allowance.  Measured on this library (profiles/r06b_*):
+        # molecule 31 only, 350 state tokens over all steps, 106 sampled tokens.
+        assert set(res['molecules_with_state_diffs']) <= {31, 58}, res
+        assert res['state_token_diffs_all_steps'] <= 1000 and sample_diffs <= 300, res
     else:
         assert res['state_token_diffs_all_steps'] == 0 and sample_diffs == 0, res
     assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4 and res['x_norm_rel'] < 1e-4 and res['x1_norm_rel'] < 1e-4, res
@@ -160,25 +165,26 @@ def test_long_horizon_matches_reference_trajectory(golden_dir, tag, name):
         assert res['mean_rel_move'] > 0.02, res          # all weights x2 / the position heads x128: the coordinates really depend on the network's arithmetic
 
 
-def test_long_horizon_64_molecules_with_the_pair_slab_forced(golden_dir):
-    """The 20-M-decision reference trajectory with the pair-slab hoist forced on (fm_config.pair_slab = 1; a 64-molecule batch is below the
-    size at which it switches on by itself): same gate as the automatic path -- every state token of every step, the final tokens and
-    coordinates; differing sampled endpoint tokens counted and bounded -- so the other summation order of the hoisted slab is covered over
+def test_long_horizon_64_molecules_without_the_pair_slab(golden_dir):
+    """The 20-M-decision reference trajectory with the pair-slab hoist switched OFF (fm_config.pair_slab = -1; canonical arithmetic computes the slab in
+    every self-conditioned evaluation, whatever the batch size): same gate as the default path -- the final tokens and coordinates, the diverging
+    molecules confined to the audited near-ties -- so the other summation order (one K = 200 chain instead of slab + K = 40) is covered over
     the full horizon, not only per evaluation."""
     from flowmol_amd.engine import Engine
     from parity_util import integrate_long_golden
     g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(golden_dir / 'long_flowmol3_geom64_T250.npz').items()}
     cfg = presets.flowmol3()
-    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', precision='f32', tuning={'pair_slab': 1})
+    eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', precision='f32', tuning={'pair_slab': -1})
     res = integrate_long_golden(eng, cfg, g)
     res['categorical_decisions'] = (int(g['T']) - 1) * int(2 * g['a_1'].numel() + g['e_1_upper'].numel())
-    _report('long[flowmol3_geom64_T250, pair_slab=1]', res)
-    assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and len(res['molecules_with_state_diffs']) <= 2, res
+    _report('long[flowmol3_geom64_T250, pair_slab=-1]', res)
+    assert res['a_flips'] == res['c_flips'] == res['e_flips'] == 0 and set(res['molecules_with_state_diffs']) <= {31, 58}, res
+    assert res['state_token_diffs_all_steps'] <= 1000 and res['a1_sample_diffs'] + res['c1_sample_diffs'] + res['e1_sample_diffs'] <= 300, res
     assert res['x_rel'] < 1e-4 and res['x_frames_rel'] < 1e-4 and res['x_norm_rel'] < 1e-4, res
     eng.close()
 
 
-@pytest.mark.parametrize('tag,tuning', [('flowmol3_geom64_T250', {}), ('flowmol3_geom64_T250', {'pair_slab': 1}), ('flowmol3_geom16_T250_pos128', {})])
+@pytest.mark.parametrize('tag,tuning', [('flowmol3_geom64_T250', {}), ('flowmol3_geom64_T250', {'pair_slab': -1}), ('flowmol3_geom16_T250_pos128', {})])
 def test_teacher_forced_decisions_differ_from_the_reference_only_at_near_ties(golden_dir, tag, tuning):
     """"Bit-exact categorical indices" made checkable over 20.2 M decisions: every step is started from the REFERENCE's token
     state (coordinates and self-conditioning input run free), so each of the fixture's decisions -- sampled endpoint token and new state token of
@@ -196,11 +202,13 @@ def test_teacher_forced_decisions_differ_from_the_reference_only_at_near_ties(go
     res = audit_long_decisions(cfg, g, traj, probs)
     _report(f'teacher_forced_audit[{tag},{tuning}]', {k: v for k, v in res.items()})
     assert not res['unexplained'], res['unexplained'][:5]
-    # the measured constants of this library (profiles/r05b_gpu_parity_report.jsonl): of the 20,185,683 decisions of the 64-molecule fixture ONE differs --
-    # step 113, a charge row of molecule 31 whose purity sits 1.8e-7 (3 ulp) above the 0.9 threshold -- plus, with the pair slab forced on, one sampled
-    # charge token at step 79 (margin 2.7e-6); none of the 4,733,490 decisions of the position-heads fixture.  The arithmetic is
-    # deterministic, so the bound is the measured count.
-    assert len(res['events']) <= (0 if 'pos128' in tag else 2 if tuning else 1), res['events']
+    # the measured constants of this library (profiles/r06b_gpu_parity_report.jsonl; the same two events as round 5's pair-slab path): of the 20,185,683 decisions
+    # of the 64-molecule fixture TWO differ on the default (canonical: pair slab in every evaluation) path -- step 113, a charge row of molecule 31 whose purity
+    # sits 1.8e-7 (3 ulp) above the 0.9 threshold, and one sampled charge token of molecule 58 at step 79 (margin 2.7e-6) -- at most those two without the slab;
+    # none of the 4,733,490 decisions of the position-heads fixture.  The arithmetic is deterministic and, since round 6, independent of the batch a
+    # molecule sits in, so these are constants of the LIBRARY, not of (library, batch).
+    assert len(res['events']) <= (0 if 'pos128' in tag else 2), res['events']
+    assert {ev['molecule'] for ev in res['events']} <= {31, 58}, res['events']
     x = traj['x'][-1].cpu()
     assert float((x - g['x_1']).abs().max() / g['x_1'].abs().max()) < 1e-4
     eng.close()
@@ -424,9 +432,10 @@ def test_c3_full_size_geom_properties():
 @pytest.mark.gpu
 def test_shards_with_replicated_noise_equal_the_full_batch():
     """SURVEY.md §8e on one GPU: the three shards of an LPT partition, each integrated alone with the full batch's
-    noise rows (what sample_distributed(noise='replicated') does per rank), reproduce the unsharded run: identical
-    tokens, coordinates to float summation order (where a destination's in-edges are cut into tiles depends on the
-    molecule's offset in the batch, so the order of its partial sums does)."""
+    noise rows (what sample_distributed(noise='replicated') does per rank), reproduce the unsharded run BIT FOR BIT --
+    tokens and coordinates (canonical arithmetic, fm_config.canonical: the f32 summation order of a molecule is a function
+    of the molecule alone, as every reduction of the reference is per molecule: gvp.py:491-492, ctmc_utils.py:11-20,
+    vector_field.py:347-350)."""
     import flowmol_amd as flowmol
     from flowmol_amd import shard
     model = flowmol.FlowMol.from_preset('flowmol3').cuda()
@@ -442,7 +451,7 @@ def test_shards_with_replicated_noise_equal_the_full_batch():
         nidx, pidx = rows[2].cpu(), rows[3].cpu()
         assert torch.equal(part['a'], full['a'][nidx]) and torch.equal(part['c'], full['c'][nidx])
         assert torch.equal(part['e'], full['e'][pidx])
-        torch.testing.assert_close(part['x'], full['x'][nidx], rtol=1e-5, atol=1e-5)
+        assert torch.equal(part['x'], full['x'][nidx])
 
 
 def _gloo_rank_on_shared_gpu(rank, world, port, sizes, T, seed, q):
@@ -474,8 +483,8 @@ def test_eight_rank_process_group_on_one_gpu_equals_single_process_sample():
     """BASELINE configs[3]'s process layout as far as one GPU allows (VERDICT r3 #1b): EIGHT ranks (one process each, gloo process group,
     all on this box's one MI355X) run FlowMol.sample_distributed on a 512-molecule job with sizes drawn from the shipped GEOM-drugs
     histogram: LPT parts of unequal length, packed payloads of odd sizes, one all-gather.  noise='replicated' must reproduce the
-    single-process sample() of the same seed (tokens identical, coordinates to float summation order); noise='philox' -- what a
-    throughput run uses -- must reproduce the single-process Philox sample token for token (per-molecule streams keyed by the original
+    single-process sample() of the same seed BIT FOR BIT (tokens and coordinates: canonical arithmetic); noise='philox' -- what a
+    throughput run uses -- must reproduce the single-process Philox sample bit for bit too (per-molecule streams keyed by the original
     molecule index).  What stays untested after this is only the RCCL/xGMI transport between eight devices."""
     import socket
     import torch.multiprocessing as mp
@@ -521,7 +530,7 @@ def test_eight_rank_process_group_on_one_gpu_equals_single_process_sample():
         for k in 'ace':
             assert torch.equal(full[k], single[mode][k]), (mode, k, int((full[k] != single[mode][k]).sum()))
         rep[f'{mode}_x_max_abs_diff'] = float((full['x'] - single[mode]['x']).abs().max())
-        torch.testing.assert_close(full['x'], single[mode]['x'], rtol=1e-5, atol=1e-5)
+        assert torch.equal(full['x'], single[mode]['x']), (mode, rep[f'{mode}_x_max_abs_diff'])      # canonical arithmetic: bit for bit, whatever the sharding
     _report('eight_ranks_one_gpu', rep)
 
 
@@ -550,6 +559,7 @@ def _check_multi_gpu_line(d, world, backend):
     for k in ('token_diffs', 'x_rel', 'philox_token_diffs', 'world_size', 'distinct_pci_devices', 'rccl_version', 'all_gather_bytes', 'ranks_hold_the_same_batch', 'ok'):
         assert k in p, k
     assert p['ok'] and p['token_diffs'] == 0 and p['philox_token_diffs'] == 0 and p['x_rel'] < 1e-4 and p['philox_x_rel'] < 1e-4, p
+    assert p['canonical'] and p['x_bit_identical'] and p['philox_x_bit_identical'] and p['x_rel'] == 0.0, p      # canonical arithmetic: sharding changes no bit
     assert p['world_size'] == world and p['molecules'] == 8 * world and p['n_timesteps'] == 12 and p['ranks_hold_the_same_batch']
     assert p['all_gather_bytes'] == world * p['all_gather_slot_bytes'] and p['backend'] == backend
     assert d['n_gpus'] == world and d['config']['global_molecules'] == 32 * world and d['config']['finite']
@@ -960,7 +970,7 @@ def test_forward_matches_reference_fixture_directly(golden_dir, name):
 
 def test_philox_mode_on_gpu_is_batch_composition_independent():
     """rng='philox' on the GPU at BASELINE-like sizes: 48 GEOM-sized molecules sampled together vs. two of them sampled alone
-    (as another shard would) with their global ids -- identical tokens, coordinates to float summation order; no mask tokens left."""
+    (as another shard would) with their global ids -- identical tokens AND bit-identical coordinates (canonical arithmetic); no mask tokens left."""
     import flowmol_amd as flowmol
     model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
     torch.manual_seed(3)
@@ -976,10 +986,41 @@ def test_philox_mode_on_gpu_is_batch_composition_independent():
     for i in ids.tolist():
         n, u = int(sizes[i]), int(pairs[i])
         flips += int((part['a'][o_n:o_n + n] != full['a'][noff[i]:noff[i] + n]).sum() + (part['e'][o_p:o_p + u] != full['e'][poff[i]:poff[i] + u]).sum())
-        torch.testing.assert_close(part['x'][o_n:o_n + n], full['x'][noff[i]:noff[i] + n], rtol=1e-4, atol=1e-4)
+        assert torch.equal(part['x'][o_n:o_n + n], full['x'][noff[i]:noff[i] + n])
+        assert torch.equal(part['c'][o_n:o_n + n], full['c'][noff[i]:noff[i] + n])
         o_n += n; o_p += u
     _report('philox_composition', {'flips': flips})
     assert flips == 0
+
+
+def test_a_molecule_alone_equals_the_same_molecule_in_a_1024_batch_bit_for_bit():
+    """Canonical arithmetic at the headline size: molecules 0, 517 and 1023 of BASELINE configs[2]'s 1024 x 47-atom batch -- which runs
+    32-row edge and node tiles, 64-row MLP tiles and the pair slab -- sampled ALONE (16-row tiles everywhere, 1024-thread CTMC workgroups) with their
+    Philox ids give the same coordinates and tokens bit for bit over 12 steps; so does a ragged GEOM-sized batch against its members alone.  In
+    latency mode (canonical=False) the launch choices follow the batch size and the same comparison agrees to f32 summation order only."""
+    import flowmol_amd as flowmol
+    model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
+    T = 12
+    for sizes, ids in ((torch.full((1024,), 47), [0, 517, 1023]), (None, [3, 40, 95])):
+        if sizes is None:
+            torch.manual_seed(11)
+            sizes = model.sample_n_atoms(96)
+        full, _ = model.sample(sizes, n_timesteps=T, return_tensors=True, rng='philox', _philox=77)
+        pairs = sizes * (sizes - 1) // 2
+        noff, poff = torch.cumsum(sizes, 0) - sizes, torch.cumsum(pairs, 0) - pairs
+        for i in ids:
+            one, _ = model.sample(sizes[i:i + 1], n_timesteps=T, return_tensors=True, rng='philox', _philox=77, _mol_ids=torch.tensor([i]))
+            n, u = int(sizes[i]), int(pairs[i])
+            for k in 'xac':
+                assert torch.equal(one[k], full[k][noff[i]:noff[i] + n]), (k, i)
+            assert torch.equal(one['e'], full['e'][poff[i]:poff[i] + u]), i
+    lat = flowmol.FlowMol.from_preset('flowmol3', canonical=False).cuda().eval()
+    sizes = torch.full((256,), 47)
+    full, _ = lat.sample(sizes, n_timesteps=T, return_tensors=True, rng='philox', _philox=77)
+    one, _ = lat.sample(sizes[:1], n_timesteps=T, return_tensors=True, rng='philox', _philox=77, _mol_ids=torch.tensor([0]))
+    rel = float((one['x'] - full['x'][:47]).abs().max() / full['x'][:47].abs().max())
+    _report('latency_mode_composition', {'x_rel': rel, 'bitwise': bool(torch.equal(one['x'], full['x'][:47]))})
+    assert rel < 1e-4
 
 
 def test_cosine_schedule_trajectory_matches_reference_golden(golden_dir):
