@@ -294,7 +294,8 @@ def test_endpoint_parameterization_matches_reference(golden_dir):
 
 LONG = [('flowmol3_47x8_T250', 'flowmol3'), ('flowmol3_mixed_T250_w2', 'flowmol3'), ('geom_ctmc_mixed_T500', 'geom_ctmc'),
         ('flowmol3_geom64_T250', 'flowmol3'),       # 64 GEOM-sized molecules (r4): 3 steps here (1.3 s of oracle per evaluation)
-        ('flowmol3_geom16_T250_pos128', 'flowmol3')]       # 16 GEOM-sized molecules, position heads x128 (r5): the coordinates move 4.6 % per evaluation
+        ('flowmol3_geom16_T250_pos128', 'flowmol3'),       # 16 GEOM-sized molecules, position heads x128 (r5): the coordinates move 4.6 % per evaluation
+        ('flowmol3_geom16_T250_heads256', 'flowmol3')]     # the same sizes, categorical heads x256 (r6): the trained-model regime -- exact zeros, p == 1, denormals, log 0 = -inf
 
 
 @pytest.mark.parametrize('tag,name', LONG)
