@@ -76,6 +76,7 @@ struct fm_ctx {
     // no 4-row node MLPs, the pair slab in every evaluation that can use it -- so that a molecule's result does not depend on the size or composition of
     // its batch (see FM_CHUNK_E in fm_kernels.h for the aggregation order); -1: those three follow the batch size (lowest latency for batches of a few molecules)
     bool canonical = true;
+    bool edge_wide = false;   // fm_config.edge_threads = 1024 (A/B only, with tile_edge = 64): the edge-message tile on ONE 16-wave workgroup per CU (every weight fragment serves four row tiles)
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
     float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
@@ -522,7 +523,16 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         dim3 gmsg = get;
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
         if constexpr (HX == 0) {
-            if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
+            bool wide_done = false;
+            if constexpr (V == 32 && TE == 64) {
+                if (c->edge_wide) {
+                    if (cf.precision == FM_PREC_F16X3) L("edge_message", fm_k_edge_message<32, 64, 1024, 0, 3>, gmsg, dim3(1024), lds_gvp_sp(32, 64), m);
+                    else L("edge_message", fm_k_edge_message<32, 64, 1024, 0, 0>, gmsg, dim3(1024), lds_gvp(32, 64, true, 0), m);
+                    wide_done = true;
+                }
+            }
+            if (wide_done) {}
+            else if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
             else if (cf.precision == FM_PREC_F16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 3>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
             else if (cf.precision == FM_PREC_BF16X6) {
                 if constexpr (TE <= 32) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 2>, gmsg, dim3(512), lds_gvp_sp(V, TE, 3), m);
@@ -1046,6 +1056,11 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     c->n_pq = 0;
     c->pq_forced = cfg->pair_slab > 0;
     c->canonical = cfg->canonical >= 0;
+    c->edge_wide = cfg->edge_threads == 1024;
+    if (cfg->edge_threads != 0 && cfg->edge_threads != 512 && cfg->edge_threads != 1024) { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.edge_threads must be 0, 512 or 1024"); }
+    if (c->edge_wide && (cfg->tile_edge != 64 || V != 32 || HX != 0 || (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_F16X3)))
+        { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: edge_threads = 1024 is built for tile_edge = 64, 32 vector channels, f32 / f16x3, no destination features"); }
+    if (c->edge_wide) c->n_pq = 0;      // the pair-slab rows are laid out for 8 waves x 2 column tiles
     if (cfg->pair_slab >= 0 && HX == 0 && cfg->precision == FM_PREC_F32 && cfg->self_conditioning)
         for (int i = 0; i < cfg->n_convs && i < 2; ++i) {
             bool clean = true;
@@ -1074,6 +1089,7 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
     set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
+    set_lds(fm_k_edge_message<32, 64, 1024, 0, 0>, lds_gvp(32, 64, true)); set_lds(fm_k_edge_message<32, 64, 1024, 0, 3>, lds_gvp_sp(32, 64));
     set_lds(fm_k_edge_message<32, 16, 512, 0, 3>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 3>, lds_gvp_sp(32, 32));
     set_lds(fm_k_edge_message<16, 16, 512, 0, 3>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 3>, lds_gvp_sp(16, 32));
     set_lds(fm_k_edge_message<32, 64, 512, 0, 3>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 3>, lds_gvp_sp(16, 64));

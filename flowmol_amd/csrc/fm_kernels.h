@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // broadcast + v_readfirstlane) only at the 2-5 segment ends of a tile.  Round 1 made all 2*TM ids wave-uniform with
     // v_readlane: 64 VALU per wave and tile, each of which costs matrix-pipe time (profiles/r02a ablation).  Rows past the end
     // of the edge list (ragged last tile) come after the last set bit, so whatever they add to `run` is never stored.
-    static_assert(NTH == 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns");
+    static_assert(NTH >= 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns (the others idle here)");
     if (!(FM_ABLATE & 8)) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int lr = lane < TM ? lane : TM - 1;
