@@ -35,11 +35,11 @@ class fm_config(C.Structure):
         ('tile_edge', C.c_int32), ('tile_node', C.c_int32), ('tile_edge_update', C.c_int32), ('xcd_swizzle', C.c_int32),
         ('fuse_node', C.c_int32), ('pair_mlps', C.c_int32), ('mlp_small_tiles', C.c_int32), ('pair_slab', C.c_int32),
         # ABI 7: 0 / 1 = canonical arithmetic (a molecule's bits do not depend on its batch), -1 = latency mode
-        ('canonical', C.c_int32), ('edge_threads', C.c_int32),
+        ('canonical', C.c_int32),
     ]
 
 
-TUNING_FIELDS = ('tile_edge', 'tile_node', 'tile_edge_update', 'xcd_swizzle', 'fuse_node', 'pair_mlps', 'mlp_small_tiles', 'pair_slab', 'canonical', 'edge_threads')
+TUNING_FIELDS = ('tile_edge', 'tile_node', 'tile_edge_update', 'xcd_swizzle', 'fuse_node', 'pair_mlps', 'mlp_small_tiles', 'pair_slab', 'canonical')
 
 
 class fm_tensor_desc(C.Structure):

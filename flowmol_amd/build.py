@@ -24,6 +24,15 @@ ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', f'--offload-arch={ARCH}', '-ffp-contract=off', '-Wno-pass-failed']
 
 
+UNITY = 'fm_all_units.cpp'          # dev-only single-unit build (tools/build_variant.sh); never part of the parallel build
+
+
+def units():
+    """The translation units of the library: compiled separately and in parallel (one hipcc per unit), then linked.  Every unit carries its own
+    gfx950 code object; the engine reaches the other units' kernels through plain host launcher functions (csrc/fm_host.h)."""
+    return sorted(p for p in SRC.glob('*.cpp') if p.name != UNITY)
+
+
 def _sources():
     return sorted(list(SRC.glob('*.cpp')) + list(SRC.glob('*.h')) + [PKG.parent / 'include' / 'flowmol_hip.h'])
 
@@ -47,10 +56,23 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             # e.g. the GPU box: the prebuilt library travelled with the snapshot
             return OUT
         raise RuntimeError('hipcc not found and no prebuilt libflowmol_hip.so present')
-    cmd = [hipcc, *FLAGS, '-x', 'hip', str(SRC / 'fm_engine.cpp'), '-o', str(OUT)]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cflags = [f for f in FLAGS if f != '-shared']
+    with tempfile.TemporaryDirectory(prefix='fm_build_') as tmp:
+        jobs = [([hipcc, *cflags, '-c', '-x', 'hip', str(u), '-o', str(Path(tmp) / (u.stem + '.o'))], Path(tmp) / (u.stem + '.o')) for u in units()]
+
+        def compile_one(job):
+            if verbose:
+                print(' '.join(job[0]), flush=True)
+            subprocess.run(job[0], check=True)
+            return job[1]
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, jobs))
+        link = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', *[str(o) for o in objs], '-o', str(OUT)]
+        if verbose:
+            print(' '.join(link), flush=True)
+        subprocess.run(link, check=True)
     STAMP.write_text(dig)
     return OUT
 

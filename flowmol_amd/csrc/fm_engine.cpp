@@ -4,134 +4,11 @@
 //  - fm_batch_bind: carves the caller's workspace, builds the destination-sorted edge layout on device
 //  - fm_forward / fm_ctmc_step / fm_integrate: enqueue the kernel sequence on the caller's stream
 // Compiled as HIP for gfx950 (flowmol_amd/build.py).  No host synchronisation on the hot path.
-#include <hip/hip_runtime.h>
+#include "fm_host.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/flowmol_hip.h"
-#include "fm_kernels.h"
+namespace fmh { thread_local std::string g_create_error; }
 
 namespace {
-
-constexpr int FM_TAB_SLOTS = 32;      // embedding tables kept per bound batch: fm_integrate builds those of up to 32 steps in one launch
-
-thread_local std::string g_create_error;
-
-struct ProfEvent { int kid; hipEvent_t a, b; };
-
-struct MlpW { const float2* W1; const float* b1; const float2* W2; const float* b2; int K1p, H, O; };
-
-struct ConvW {
-    const float2* Wps; const float2* Wpv; const float* w0;
-    const float2* Ws_slab = nullptr;   // pair-slab convolutions: [rbf | ef] rows of GVP0's scalar linear (K = 160), multiplied per pair in the SC_EDGE kernel
-    const float2* Ws_sh = nullptr;     //                         and its remaining rows, the hidden-vector norms (K = KU0)
-    const void* Wps_sp = nullptr;      // split precision
-    const void* Wps4 = nullptr;        // quad-row packed (4-node tiles)
-    FmGvpW dproj{}; const float2* Wsd = nullptr; const float2* Wpvd = nullptr;     // use_dst_feats: projection GVP + hoisted destination terms
-    FmGvpW msg[3]; FmGvpW upd[3];
-    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-};
-struct UpdW {
-    FmGvpW pos[3];
-    const float2* Wasd; const float2* W1; const float* b1; const float2* W2; const float* b2;
-    const float *ln_g, *ln_b;
-    const void *W1_sp = nullptr, *W2_sp = nullptr, *Wasd_sp = nullptr;      // split-precision builds
-    const void* Wasd4 = nullptr;       // quad-row packed (4-node tiles)
-};
-
-}  // namespace
-
-struct fm_ctx {
-    fm_config cfg{};
-    std::string err;
-    int V = 32, S = 256, F = 128, na = 0, nc = 0, ne = 0;
-    int HX = 0, SD = 0, PVW = 48;     // use_dst_feats: destination vectors / scalars per message; width of the hoisted hidden-vector rows
-    // Rows per workgroup tile of the GVP kernels, chosen per bound batch (ws_layout): 32 once the chip is full, 16 while
-    // the 32-row tiling would leave CUs idle (fewer tiles than CUs) - half the work per tile, i.e. lower step latency
-    // for small batches.  fm_config.tile_edge / tile_node (16|32|64) force a size; tile_edge_update (32|64) for EdgeUpdate.
-    int tm_edge = 32, tm_node = 32, tm_eupd = 32;
-    int tm_edge_forced = 0, tm_node_forced = 0;
-    int n_cus = 256;
-    int pair_mlps_forced = -1;      // fm_config.pair_mlps
-    int small_mlp_forced = -1;      // fm_config.mlp_small_tiles
-    int mlp4_forced = -1;           // fm_config.mlp_small_tiles = 2: the node-side MLPs on 4-row tiles (fm_k_mlp4) whatever the batch; 1 / -1: never
-    const void *sc_node_W1q = nullptr, *sc_node_W2q = nullptr, *node_head_W1q = nullptr, *node_head_W2q = nullptr;      // quad-row packed copies for fm_k_mlp4
-    int fuse_head = 1;        // the evaluation's last EdgeUpdate also runs the edge output head on its pairs (fm_k_edge_update<32, false, true>; fm_config.fuse_node = 2 | -1: separate)
-    int fuse_node = 1;        // node_update also runs the next conv's projections, EdgeUpdate's node terms and NodePositionUpdate (fm_config.fuse_node = -1: separate launches)
-    int n_pq = 0;             // leading convolutions (0..2) whose [rbf | ef] slab is computed per unordered pair (self-conditioned models; fm_config.pair_slab = -1: 0)
-    int node_rg = 0;          // this batch runs the node kernel on tiles of 4 * node_rg nodes (RG instances; 1, 2, 3 in the 16-row frame, 5 in the 32-row
-                              // frame): chosen per bound batch, fm_config.tile_node = 4 / 8 / 12 / 20 forces it
-    int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
-    // fm_config.canonical >= 0 (default): every launch choice that selects another f32 summation order is FIXED -- regular node tiles (no 4 RG-node instances),
-    // no 4-row node MLPs, the pair slab in every evaluation that can use it -- so that a molecule's result does not depend on the size or composition of
-    // its batch (see FM_CHUNK_E in fm_kernels.h for the aggregation order); -1: those three follow the batch size (lowest latency for batches of a few molecules)
-    bool canonical = true;
-    bool edge_wide = false;   // fm_config.edge_threads = 1024 (A/B only, with tile_edge = 64): the edge-message tile on ONE 16-wave workgroup per CU (every weight fragment serves four row tiles)
-    float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
-    int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)
-    float rbf_mu_step = 0.f, rbf_inv_sigma = 0.f;
-    // ---- weights (one device arena)
-    char* arena = nullptr; size_t arena_bytes = 0;
-    const float *emb_a = nullptr, *emb_c = nullptr;
-    MlpW node_embed{}, edge_embed{}, sc_node{}, sc_edge{}, node_head{}, edge_head{};
-    const float *node_ln_g = nullptr, *node_ln_b = nullptr, *edge_ln_g = nullptr, *edge_ln_b = nullptr;
-    const float *ef_tab = nullptr, *T1 = nullptr;          // (ne+1,128) each
-    std::vector<ConvW> conv;
-    std::vector<UpdW> upd;
-    int tab_rows = 0, tab_kp = 0;
-    // ---- batch binding
-    bool bound = false;
-    int nmax = 0;             // atoms of the largest molecule of the bound batch
-    FmBatch b{};
-    int n_tiles_e = 0, n_tiles_n = 0, n_tiles_u = 0;
-    int n_tiles_msg = 0;      // molecule-aligned edge-message tiles of the bound batch (FmBatch::n_tiles)
-    float *s = nullptr, *v = nullptr, *xw = nullptr, *ef = nullptr, *Ps = nullptr, *Asd = nullptr, *PV = nullptr;
-    float *part_s = nullptr, *part_v = nullptr, *s_tab = nullptr, *Psd = nullptr, *PVd = nullptr;
-    float* s_tab_base = nullptr; size_t tab_slot_floats = 0;      // FM_TAB_SLOTS embedding tables (one per step of a chunk); s_tab = the current step's
-    float *tap_s = nullptr, *tap_v = nullptr;    // scratch of the aggregated-message taps (parity runs only)
-    fm_dst boot{};
-    int32_t *sa1 = nullptr, *sc1 = nullptr, *se1 = nullptr;
-    int* mol_gid = nullptr;   // [B] global molecule ids of the Philox noise streams
-    // ---- pinned host staging of the per-molecule descriptor arrays (fm_batch_bind / fm_set_molecule_ids: 16 B per molecule).  The copies
-    // read it asynchronously; `stage_ev` marks their completion, so the next writer waits for THAT event only (long complete by then) and
-    // no entry point ever synchronises the stream.
-    int32_t* stage = nullptr; size_t stage_cap = 0; hipEvent_t stage_ev = nullptr; bool stage_busy = false;
-    // ---- taps / profiling
-    std::map<std::string, void*> taps;
-    bool prof = false;
-    std::vector<hipEvent_t> ev_pool;          // recycled timing events: creating a pair per launch made the host the bottleneck of a profiled step
-    std::vector<ProfEvent> prof_events;
-    std::vector<std::string> prof_names;
-    std::map<std::string, std::pair<double, int64_t>> prof_acc;
-};
-
-namespace {
-
-int fail(fm_ctx* c, int code, const char* fmt, ...) {
-    char buf[1024];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
-    return code;
-}
-
-#define FM_HIP(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
-    return fail((c), FM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-
-inline bool prec_two_plane(int p) { return p == FM_PREC_BF16X3 || p == FM_PREC_F16X3; }      // the modes whose node / EdgeUpdate kernels run split precision too
-inline int pad8(int k) { return (k + 7) / 8 * 8; }
-inline int pad16(int k) { return (k + 15) / 16 * 16; }
-inline int ld_for(int k) { int ld = (k + 3) / 4 * 4; while (((ld / 4) & 1) == 0) ld += 4; return ld; }
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------- weight blob access
 struct Blob {
@@ -301,62 +178,6 @@ bool pack_gvp(Builder& B, Blob& bl, const std::string& key, int V, int S, int vo
     return true;
 }
 
-template <class F> void set_lds(F f, size_t bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
-
-int pvw_of(int V, int HX) { return (pad8(V + 1 + HX + 4) + 8 + 15) / 16 * 16; }     // FmGvpTile::PVW
-size_t lds_gvp_sp(int V, int TM, int npl = 2) {       // split-precision edge message: npl bf16 planes instead of the f32 scalar tile, gates inside Vh
-    size_t fl = (size_t)TM * FM_LDP * npl / 2 + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, 0) + 4);
-    return fl * 4 + (size_t)TM * 9 * 4;
-}
-size_t lds_gvp(int V, int TM, bool with_meta, int HX = 0) {
-    size_t fl = (size_t)TM * FM_LDX + 3 * TM * (V + 4) + 3 * TM * (pvw_of(V, HX) + 4) + TM * FM_LDG;
-    return fl * 4 + (with_meta ? (size_t)TM * 9 * 4 + 64 : 0);      // + one slot for the tile's smallest pair id (PQ instances)
-}
-size_t lds_mlp(int ldx, int ldh, int tm = FM_TM) { return ((size_t)tm * ldx + (size_t)tm * ldh) * 4 + 5 * (size_t)tm * 4; }
-size_t lds_proj(int V, int tm = FM_TM) { return ((size_t)tm * 260 + 3 * (size_t)tm * (V + 4)) * 4; }
-size_t lds_edge_upd(int TM) { return ((size_t)TM * 164 + TM * 132) * 4 + TM * 4 * 4 + 16; }
-size_t lds_edge_upd_sp(int TM) { return (size_t)TM * 132 * 4 + (size_t)TM * 176 * 2 * 2 + TM * 3 * 4; }
-
-// ---------------------------------------------------------------------------------------- launch helper
-int kid_of(fm_ctx* c, const char* name) {
-    for (size_t i = 0; i < c->prof_names.size(); ++i) if (c->prof_names[i] == name) return (int)i;
-    c->prof_names.push_back(name);
-    return (int)c->prof_names.size() - 1;
-}
-
-struct Launch {
-    fm_ctx* c; hipStream_t st; int rc = FM_OK;
-    template <class K, class... Args>
-    void operator()(const char* name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
-        if (rc != FM_OK || grid.x == 0) return;
-        ProfEvent pe{};
-        if (c->prof) {
-            pe.kid = kid_of(c, name);
-            auto take = [&](hipEvent_t& e) { if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else (void)hipEventCreate(&e); };
-            take(pe.a); take(pe.b);
-            (void)hipEventRecord(pe.a, st);
-        }
-        hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
-        hipError_t e = hipGetLastError();
-        if (c->prof) { (void)hipEventRecord(pe.b, st); c->prof_events.push_back(pe); }
-        if (e != hipSuccess) rc = fail(c, FM_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e));
-    }
-    void copy(void* dst, const void* src, size_t bytes) {
-        if (rc != FM_OK || bytes == 0) return;
-        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) rc = fail(c, FM_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
-    }
-    void zero(void* dst, size_t bytes) {
-        if (rc != FM_OK || bytes == 0) return;
-        hipError_t e = hipMemsetAsync(dst, 0, bytes, st);
-        if (e != hipSuccess) rc = fail(c, FM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
-    }
-    void tap(const std::string& name, const void* src, size_t bytes) {
-        auto it = c->taps.find(name);
-        if (it != c->taps.end()) copy(it->second, src, bytes);
-    }
-};
-
 void fill_mlp(FmMlpArgs& a, const MlpW& w, int rows) {
     a.rows = rows; a.K1p = w.K1p; a.H = w.H; a.O = w.O;
     a.W1 = w.W1; a.b1 = w.b1; a.W2 = w.W2; a.b2 = w.b2;
@@ -396,10 +217,19 @@ inline int pq_convs(const fm_ctx* c, long long U) {
 }
 
 // ---------------------------------------------------------------------------------------- one network evaluation
-template <int V, int TE, int TN, int HX>
+// node_proj instances (small kernels of this unit): V = 16 | 32 vector channels, 64- or 16-row tiles
+void launch_node_proj(Launch& L, const char* name, int V, bool small, int N, const FmProjArgs& pa) {
+    const dim3 blk(FM_THREADS);
+    if (V == 32) { if (small) L(name, fm_k_node_proj<32, 16>, dim3((N + 15) / 16), blk, lds_proj(32, 16), pa); else L(name, fm_k_node_proj<32>, dim3((N + FM_TM - 1) / FM_TM), blk, lds_proj(32), pa); }
+    else { if (small) L(name, fm_k_node_proj<16, 16>, dim3((N + 15) / 16), blk, lds_proj(16, 16), pa); else L(name, fm_k_node_proj<16>, dim3((N + FM_TM - 1) / FM_TM), blk, lds_proj(16), pa); }
+}
+
+// One network evaluation of the bound batch.  The kernel instances are selected from the context's run-time parameters (vector channels V, edge / node tile heights
+// TE / TN chosen at fm_batch_bind, destination-feature vectors HX); the heavy families live in translation units of their own (fm_host.h).
 int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out,
              bool taps_on, const fm_dense_state* dense = nullptr, const float* temb = nullptr) {
     Launch L{c, st};
+    const int V = c->V, TE = c->tm_edge, TN = c->tm_node, HX = c->HX;
     const FmBatch& b = c->b;
     const int N = b.N, E = b.E, U = b.U;
     const fm_config& cf = c->cfg;
@@ -503,15 +333,14 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
                 p4.N = N; p4.in = c->s; p4.Wps4 = cw.Wps4; p4.Ps = c->Ps; p4.PV = c->PV; p4.pv_w = c->PVW; p4.v_init = c->v; p4.V = V; p4.x_src = x_t; p4.x_dst = c->xw;
                 L("node_proj", fm_k_mlp4<FM_MLP4_PROJ0>, dim3(tiles4), blk, (size_t)FM_MLP4_LDS_BYTES, p4);
             }
-            else if (small_node) L("node_proj", fm_k_node_proj<V, 16>, dim3((N + 15) / 16), blk, lds_proj(V, 16), pa);
-            else L("node_proj", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa);
+            else launch_node_proj(L, "node_proj", V, small_node, N, pa);
         }
         FmMsgArgs m{};
         m.b = b; m.x = c->xw; m.ef = c->ef; m.Ps = c->Ps; m.PV = c->PV; m.w0 = cw.w0;
-        if constexpr (HX > 0) {       // use_dst_feats: projection GVP of the conv's input features + its per-node hoists
+        if (HX > 0) {       // use_dst_feats: projection GVP of the conv's input features + its per-node hoists
             FmDstProjArgs dp{};
             dp.N = N; dp.s = c->s; dp.v = c->v; dp.g = cw.dproj; dp.Wsd = cw.Wsd; dp.Psd = c->Psd; dp.Wpvd = cw.Wpvd; dp.PVd = c->PVd; dp.pv_w = c->PVW;
-            L("dst_proj", fm_k_dst_proj<V, TN, HX>, gnt, blk, lds_gvp(V, TN, false), dp);
+            fm_launch_dst_proj(L, V, TN, HX, gnt, dp);
             m.Psd = c->Psd; m.PVd = c->PVd;
         }
         m.g0 = cw.msg[0]; m.g1 = cw.msg[1]; m.g2 = cw.msg[2];
@@ -522,30 +351,9 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
         m.dbg_s = dbg ? (float*)c->taps["conv0.msg.s"] : nullptr; m.dbg_v = dbg ? (float*)c->taps["conv0.msg.v"] : nullptr;
         dim3 gmsg = get;
         if (c->xcd_swizzle) { m.xcd_chunk = ((int)get.x + 7) / 8; gmsg = dim3(8 * m.xcd_chunk); }
-        if constexpr (HX == 0) {
-            bool wide_done = false;
-            if constexpr (V == 32 && TE == 64) {
-                if (c->edge_wide) {
-                    if (cf.precision == FM_PREC_F16X3) L("edge_message", fm_k_edge_message<32, 64, 1024, 0, 3>, gmsg, dim3(1024), lds_gvp_sp(32, 64), m);
-                    else L("edge_message", fm_k_edge_message<32, 64, 1024, 0, 0>, gmsg, dim3(1024), lds_gvp(32, 64, true, 0), m);
-                    wide_done = true;
-                }
-            }
-            if (wide_done) {}
-            else if (cf.precision == FM_PREC_BF16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 1>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
-            else if (cf.precision == FM_PREC_F16X3) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 3>, gmsg, dim3(512), lds_gvp_sp(V, TE), m);
-            else if (cf.precision == FM_PREC_BF16X6) {
-                if constexpr (TE <= 32) L("edge_message", fm_k_edge_message<V, TE, 512, 0, 2>, gmsg, dim3(512), lds_gvp_sp(V, TE, 3), m);
-                else return fail(c, FM_ERR_INVALID, "the three-term split precision runs 16- or 32-row edge tiles (three planes of a 64-row tile exceed the LDS)");
-            }
-            else if (it < n_pq) {
-                m.Q = c->Q[it]; m.g0.Ws = cw.Ws_sh;          // GVP0's scalar GEMM: K = KU0 (hidden-vector norms); the rest arrives through Q
-                L("edge_message_pq", fm_k_edge_message<V, TE, 512, 0, 0, 1>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
-            }
-            else L("edge_message", fm_k_edge_message<V, TE, 512, 0, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, 0), m);
-        } else {
-            L("edge_message", fm_k_edge_message<V, TE, 512, HX, 0>, gmsg, dim3(512), lds_gvp(V, TE, true, HX), m);
-        }
+        const bool pq = HX == 0 && cf.precision == FM_PREC_F32 && it < n_pq;
+        if (pq) { m.Q = c->Q[it]; m.g0.Ws = cw.Ws_sh; }          // GVP0's scalar GEMM: K = KU0 (hidden-vector norms); the rest arrives through Q
+        fm_launch_edge_message(L, V, TE, HX, cf.precision, pq, gmsg, m);
         const int u = cf.update_after[i];
         FmNodeUpdArgs nu{};
         nu.b = b; nu.s = c->s; nu.v = c->v; nu.part_s = c->part_s; nu.part_v = c->part_v; nu.inv_z = cf.msg_z < 0.f ? -1.0f : 1.0f / cf.msg_z;
@@ -564,34 +372,19 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             }
         }
         nu.s_real = c->S;
-        bool launched = false;
-        if constexpr (HX == 0 && TN <= 32) {
-            if (prec_two_plane(cf.precision) && fuse) {      // split-precision node kernel (fused sequence only)
+        {   // instance of the node kernel: split precision (fused sequence only), 4 rg nodes per workgroup (small batches in latency mode), narrow, or the regular one
+            const bool spn = HX == 0 && TN <= 32 && prec_two_plane(cf.precision) && fuse;
+            const int rg = (!spn && HX == 0 && (TN == 16 || TN == 32) && c->node_rg && fuse && c->S == 256 && cf.precision == FM_PREC_F32) ? c->node_rg : 0;
+            if (spn) {
                 if (it + 1 < n_pass) nu.Wps_sp = c->conv[(i + 1) % cf.n_convs].Wps_sp;
                 if (u >= 0) nu.Wasd_sp = c->upd[u].Wasd_sp;
-                if (cf.precision == FM_PREC_F16X3) L("node_update", fm_k_node_update<V, TN, true, 3>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
-                else L("node_update", fm_k_node_update<V, TN, true, 1>, gnt, blk, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
-                launched = true;
+                fm_launch_node_update(L, V, TN, true, cf.precision == FM_PREC_F16X3 ? 3 : 1, 0, gnt, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
+            } else if (rg) {        // one tile per CU; + the exchange tile of the two K halves
+                fm_launch_node_update(L, V, TN, false, 0, rg, dim3((N + 4 * rg - 1) / (4 * rg)), lds_gvp(V, TN, false) + (size_t)rg * 4096, nu);
+            } else {
+                fm_launch_node_update(L, V, TN, c->S != 256, 0, 0, gnt, lds_gvp(V, TN, false), nu);
             }
         }
-        if constexpr (HX == 0 && (TN == 16 || TN == 32)) {
-            if (!launched && c->node_rg && fuse && c->S == 256 && cf.precision == FM_PREC_F32) {      // small batches: 4 * node_rg nodes per workgroup, one tile per CU
-                const int rg = c->node_rg;
-                const dim3 grg((N + 4 * rg - 1) / (4 * rg));
-                const size_t lds_rg = lds_gvp(V, TN, false) + (size_t)rg * 4096;                       // + the exchange tile of the two K halves
-                if constexpr (TN == 16) {
-                    if (rg == 1) L("node_update", fm_k_node_update<V, 16, false, 0, 1>, grg, blk, lds_rg, nu);
-                    else if (rg == 2) L("node_update", fm_k_node_update<V, 16, false, 0, 2>, grg, blk, lds_rg, nu);
-                    else L("node_update", fm_k_node_update<V, 16, false, 0, 3>, grg, blk, lds_rg, nu);
-                } else {
-                    L("node_update", fm_k_node_update<V, 32, false, 0, 5>, grg, blk, lds_rg, nu);
-                }
-                launched = true;
-            }
-        }
-        if (launched) {}
-        else if (c->S == 256) L("node_update", fm_k_node_update<V, TN, false, 0>, gnt, blk, lds_gvp(V, TN, false), nu);
-        else L("node_update", fm_k_node_update<V, TN, true, 0>, gnt, blk, lds_gvp(V, TN, false), nu);
         if (tagg) { tap(ci + ".agg.s", c->tap_s, (size_t)N * 256 * 4); tap(ci + ".agg.v", c->tap_v, (size_t)N * 3 * V * 4); }
         tap(ci + ".s", c->s, (size_t)N * 256 * 4);
         tap(ci + ".v", c->v, (size_t)N * 3 * V * 4);
@@ -600,11 +393,10 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             if (!fuse) {
                 FmPosArgs pp{};
                 pp.N = N; pp.s = c->s; pp.v = c->v; pp.x = c->xw; pp.g0 = uw.pos[0]; pp.g1 = uw.pos[1]; pp.g2 = uw.pos[2];
-                L("pos_update", fm_k_pos_update<V, TN>, gnt, blk, lds_gvp(V, TN, false), pp);
+                fm_launch_pos_update(L, V, TN, gnt, pp);
                 FmProjArgs pa2{};
                 pa2.N = N; pa2.s = c->s; pa2.v = c->v; pa2.Wasd = uw.Wasd; pa2.Asd = c->Asd;
-                if (small_node) L("node_proj_asd", fm_k_node_proj<V, 16>, dim3((N + 15) / 16), blk, lds_proj(V, 16), pa2);
-                else L("node_proj_asd", fm_k_node_proj<V>, gn, blk, lds_proj(V), pa2);
+                launch_node_proj(L, "node_proj_asd", V, small_node, N, pa2);
             }
             FmEdgeUpdArgs eu{};
             eu.b = b; eu.x = c->xw; eu.Asd = c->Asd; eu.ef = c->ef; eu.W1 = uw.W1; eu.b1 = uw.b1; eu.W2 = uw.W2; eu.b2 = uw.b2;
@@ -658,18 +450,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
 }
 
 int evaluate_dispatch(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* prev, int remove_com, const fm_dst* out, bool taps_on) {
-#define FM_EVAL_H(V_, TE_, TN_, H_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_ && c->HX == H_) return evaluate<V_, TE_, TN_, H_>(c, st, state, prev, remove_com, out, taps_on);
-#define FM_EVAL(V_, TE_, TN_) FM_EVAL_H(V_, TE_, TN_, 0)
-#define FM_EVAL_V(V_) FM_EVAL(V_, 16, 16) FM_EVAL(V_, 16, 32) FM_EVAL(V_, 16, 64) FM_EVAL(V_, 32, 16) FM_EVAL(V_, 32, 32) FM_EVAL(V_, 32, 64) \
-                      FM_EVAL(V_, 64, 16) FM_EVAL(V_, 64, 32) FM_EVAL(V_, 64, 64)
-    FM_EVAL_V(32) FM_EVAL_V(16)
-    // use_dst_feats models (configs/dev.yml): destination vectors = V/4; 16- and 32-row tiles only
-    FM_EVAL_H(16, 16, 16, 4) FM_EVAL_H(16, 16, 32, 4) FM_EVAL_H(16, 32, 16, 4) FM_EVAL_H(16, 32, 32, 4)
-    FM_EVAL_H(32, 16, 16, 8) FM_EVAL_H(32, 16, 32, 8) FM_EVAL_H(32, 32, 16, 8) FM_EVAL_H(32, 32, 32, 8)
-#undef FM_EVAL_V
-#undef FM_EVAL
-#undef FM_EVAL_H
-    return fail(c, FM_ERR_INVALID, "no kernel instantiation for V=%d tile_edge=%d tile_node=%d dst_vectors=%d", c->V, c->tm_edge, c->tm_node, c->HX);
+    return evaluate(c, st, state, prev, remove_com, out, taps_on);
 }
 
 // The (atom type, charge) embedding table(s) of `n_tables` consecutive time points (temb: n_tables x time_embedding_dim) into the
@@ -1056,11 +837,6 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
     c->n_pq = 0;
     c->pq_forced = cfg->pair_slab > 0;
     c->canonical = cfg->canonical >= 0;
-    c->edge_wide = cfg->edge_threads == 1024;
-    if (cfg->edge_threads != 0 && cfg->edge_threads != 512 && cfg->edge_threads != 1024) { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: fm_config.edge_threads must be 0, 512 or 1024"); }
-    if (c->edge_wide && (cfg->tile_edge != 64 || V != 32 || HX != 0 || (cfg->precision != FM_PREC_F32 && cfg->precision != FM_PREC_F16X3)))
-        { (void)hipFree(c->arena); delete c; return fail(nullptr, FM_ERR_INVALID, "fm_create: edge_threads = 1024 is built for tile_edge = 64, 32 vector channels, f32 / f16x3, no destination features"); }
-    if (c->edge_wide) c->n_pq = 0;      // the pair-slab rows are laid out for 8 waves x 2 column tiles
     if (cfg->pair_slab >= 0 && HX == 0 && cfg->precision == FM_PREC_F32 && cfg->self_conditioning)
         for (int i = 0; i < cfg->n_convs && i < 2; ++i) {
             bool clean = true;
@@ -1079,34 +855,10 @@ int fm_create(const fm_config* cfg, const fm_tensor_desc* tensors, int n_tensors
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->n_cus = prop.multiProcessorCount;
     }
-#define FM_SET(V_, T_) set_lds(fm_k_edge_message<V_, T_, 512, 0, 0>, lds_gvp(V_, T_, true)); set_lds(fm_k_edge_message<V_, T_, 512, 0, 0, 1>, lds_gvp(V_, T_, true)); set_lds(fm_k_node_update<V_, T_, false, 0>, lds_gvp(V_, T_, false)); set_lds(fm_k_node_update<V_, T_, true, 0>, lds_gvp(V_, T_, false)); \
-    set_lds(fm_k_pos_update<V_, T_>, lds_gvp(V_, T_, false));
-    FM_SET(32, 16) FM_SET(32, 32) FM_SET(32, 64) FM_SET(16, 16) FM_SET(16, 32) FM_SET(16, 64)
-#undef FM_SET
-#define FM_SETH(V_, T_, H_) set_lds(fm_k_edge_message<V_, T_, 512, H_, 0>, lds_gvp(V_, T_, true, H_)); set_lds(fm_k_dst_proj<V_, T_, H_>, lds_gvp(V_, T_, false));
-    FM_SETH(16, 16, 4) FM_SETH(16, 32, 4) FM_SETH(32, 16, 8) FM_SETH(32, 32, 8)
-#undef FM_SETH
-    set_lds(fm_k_edge_message<32, 16, 512, 0, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 1>, lds_gvp_sp(32, 32));
-    set_lds(fm_k_edge_message<16, 16, 512, 0, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 1>, lds_gvp_sp(16, 32));
-    set_lds(fm_k_edge_message<32, 64, 512, 0, 1>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 1>, lds_gvp_sp(16, 64));
-    set_lds(fm_k_edge_message<32, 64, 1024, 0, 0>, lds_gvp(32, 64, true)); set_lds(fm_k_edge_message<32, 64, 1024, 0, 3>, lds_gvp_sp(32, 64));
-    set_lds(fm_k_edge_message<32, 16, 512, 0, 3>, lds_gvp_sp(32, 16)); set_lds(fm_k_edge_message<32, 32, 512, 0, 3>, lds_gvp_sp(32, 32));
-    set_lds(fm_k_edge_message<16, 16, 512, 0, 3>, lds_gvp_sp(16, 16)); set_lds(fm_k_edge_message<16, 32, 512, 0, 3>, lds_gvp_sp(16, 32));
-    set_lds(fm_k_edge_message<32, 64, 512, 0, 3>, lds_gvp_sp(32, 64)); set_lds(fm_k_edge_message<16, 64, 512, 0, 3>, lds_gvp_sp(16, 64));
-    set_lds(fm_k_node_update<32, 16, true, 3>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 3>, lds_gvp_sp(32, 32));
-    set_lds(fm_k_node_update<16, 16, true, 3>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 3>, lds_gvp_sp(16, 32));
-    set_lds(fm_k_edge_update_sp<32, 1>, lds_edge_upd_sp(32));
-    set_lds(fm_k_edge_message<32, 16, 512, 0, 2>, lds_gvp_sp(32, 16, 3)); set_lds(fm_k_edge_message<32, 32, 512, 0, 2>, lds_gvp_sp(32, 32, 3));
-    set_lds(fm_k_edge_message<16, 16, 512, 0, 2>, lds_gvp_sp(16, 16, 3)); set_lds(fm_k_edge_message<16, 32, 512, 0, 2>, lds_gvp_sp(16, 32, 3));
-    set_lds(fm_k_node_update<32, 16, true, 1>, lds_gvp_sp(32, 16)); set_lds(fm_k_node_update<32, 32, true, 1>, lds_gvp_sp(32, 32));
-    set_lds(fm_k_node_update<16, 16, true, 1>, lds_gvp_sp(16, 16)); set_lds(fm_k_node_update<16, 32, true, 1>, lds_gvp_sp(16, 32));
-#define FM_SET_RG(V_) set_lds(fm_k_node_update<V_, 16, false, 0, 1>, lds_gvp(V_, 16, false) + 4096); set_lds(fm_k_node_update<V_, 16, false, 0, 2>, lds_gvp(V_, 16, false) + 8192); \
-    set_lds(fm_k_node_update<V_, 16, false, 0, 3>, lds_gvp(V_, 16, false) + 12288); set_lds(fm_k_node_update<V_, 32, false, 0, 5>, lds_gvp(V_, 32, false) + 20480);
-    FM_SET_RG(32) FM_SET_RG(16)
-#undef FM_SET_RG
+    fm_set_lds_msg_v32(); fm_set_lds_msg_v16(); fm_set_lds_node();      // the heavy families' instances, in their own translation units
     set_lds(fm_k_node_proj<32>, lds_proj(32)); set_lds(fm_k_node_proj<16>, lds_proj(16));
     set_lds(fm_k_node_proj<32, 16>, lds_proj(32, 16)); set_lds(fm_k_node_proj<16, 16>, lds_proj(16, 16));
-    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32));
+    set_lds(fm_k_edge_update_sp<32>, lds_edge_upd_sp(32)); set_lds(fm_k_edge_update_sp<32, 1>, lds_edge_upd_sp(32));
     set_lds(fm_k_edge_update<32, false>, lds_edge_upd(32)); set_lds(fm_k_edge_update<64, false>, lds_edge_upd(64)); set_lds(fm_k_edge_update<32, true>, lds_edge_upd(32)); set_lds(fm_k_edge_update<32, false, true>, lds_edge_upd(32));
     const size_t mlp_max = lds_mlp(ld_for(pad8(256 + 16 + 16 + 32)), 260);
     set_lds(fm_k_mlp2<FM_MLP_TABLE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_SC_NODE>, mlp_max); set_lds(fm_k_mlp2<FM_MLP_NODE_HEAD>, mlp_max);
@@ -1337,11 +1089,7 @@ int fm_forward_dense(fm_ctx* c, void* stream, const fm_dense_state* state, const
     if (!c || !state || !temb || !out) return fail(c, FM_ERR_INVALID, "fm_forward_dense: null argument");
     if (!c->bound) return fail(c, FM_ERR_STATE, "fm_forward_dense: no batch bound");
     if (c->cfg.has_mask) return fail(c, FM_ERR_INVALID, "fm_forward_dense: this is a CTMC model (token inputs): use fm_forward");
-#define FM_EVAL_D(V_, TE_, TN_) if (c->V == V_ && c->tm_edge == TE_ && c->tm_node == TN_ && c->HX == 0) \
-        return evaluate<V_, TE_, TN_, 0>(c, (hipStream_t)stream, nullptr, nullptr, remove_com ? 1 : 0, out, true, state, temb);
-    FM_EVAL_D(32, 16, 16) FM_EVAL_D(32, 16, 32) FM_EVAL_D(32, 32, 16) FM_EVAL_D(32, 32, 32) FM_EVAL_D(16, 16, 16) FM_EVAL_D(16, 16, 32) FM_EVAL_D(16, 32, 16) FM_EVAL_D(16, 32, 32)
-#undef FM_EVAL_D
-    return fail(c, FM_ERR_INVALID, "fm_forward_dense: no kernel instantiation for V=%d tile_edge=%d tile_node=%d dst_vectors=%d", c->V, c->tm_edge, c->tm_node, c->HX);
+    return evaluate(c, (hipStream_t)stream, nullptr, nullptr, remove_com ? 1 : 0, out, true, state, temb);
 }
 
 int fm_endpoint_step(fm_ctx* c, void* stream, const fm_dense_state* state, const fm_dst* dst, const fm_endpoint_scalars* sc) {

@@ -3,6 +3,7 @@
 // row tiles whose height TM is a template parameter (fm_device.h: 32 / 16 rows for the GVP kernels,
 // four nodes in a 16-row frame for the node kernel of a few molecules, 64 / 32 / 16 rows for the MLPs);
 // weights come pre-packed in MFMA fragment order.
+// The header is included by several translation units (fm_host.h): the non-template kernels are `static` (only the engine unit launches them; the others drop them).
 #pragma once
 #include <type_traits>
 
@@ -43,7 +44,7 @@ struct FmBatch {
 // off + i*(n-1) + (j - (j>i)).  The reference's order (upper triangle row-major, then the same pairs
 // swapped; flowmol/data_processing/utils.py:4-17) only matters at the boundary, where edge state is
 // exchanged per unordered pair p(a,b) = a*(2n-a-1)/2 + (b-a-1), a<b.
-__global__ void __launch_bounds__(256) fm_k_batch_setup(FmBatch b) {
+static __global__ void __launch_bounds__(256) fm_k_batch_setup(FmBatch b) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < b.N) {
         int lo = 0, hi = b.B;               // largest m with node_off[m] <= gid
@@ -520,7 +521,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp4_pair(FmMlp4Args a, FmMlp
 }
 
 // gather-only initialisation when there is no self-conditioning input (bootstrap pass / non-SC models)
-__global__ void __launch_bounds__(256) fm_k_gather_rows(float* __restrict__ out, const float* __restrict__ tab, int width,
+static __global__ void __launch_bounds__(256) fm_k_gather_rows(float* __restrict__ out, const float* __restrict__ tab, int width,
                                                          int rows, const int* __restrict__ tok_a, const int* __restrict__ tok_c,
                                                          int n_c1, const int* __restrict__ e_pair) {
     // node rows: tok = tok_a*n_c1+tok_c ; edge rows (e_pair != null): tok = tok_a[e_pair[row]]
@@ -877,7 +878,7 @@ __global__ void __launch_bounds__(NTH) fm_k_edge_message(FmMsgArgs a) {
     // broadcast + v_readfirstlane) only at the 2-5 segment ends of a tile.  Round 1 made all 2*TM ids wave-uniform with
     // v_readlane: 64 VALU per wave and tile, each of which costs matrix-pipe time (profiles/r02a ablation).  Rows past the end
     // of the edge list (ragged last tile) come after the last set bit, so whatever they add to `run` is never stored.
-    static_assert(NTH >= 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns (the others idle here)");
+    static_assert(NTH >= 512 && 3 * V <= 128 && TM <= 64, "waves 0..3 own the 256 scalar columns, waves 4..5 the 3*V vector columns (the others idle here; 1024-thread instances were measured in round 6: profiles/r06d_*)");
     if (!(FM_ABLATE & 8)) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const int lr = lane < TM ? lane : TM - 1;
@@ -1551,7 +1552,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_edge_update_sp(FmEdgeUpdArgs 
 // small element-wise kernels
 // ------------------------------------------------------------------------------------------------
 // endpoint-parameterised models: node rows of the scalar embedding's input [a_t | c_t | temb | 0] (vector_field.py:228-243)
-__global__ void __launch_bounds__(256) fm_k_dense_node_in(float* __restrict__ out, int ld, int N, const float* __restrict__ a, int na,
+static __global__ void __launch_bounds__(256) fm_k_dense_node_in(float* __restrict__ out, int ld, int N, const float* __restrict__ a, int na,
                                                            const float* __restrict__ c, int nc, const float* __restrict__ temb, int tt) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)N * ld; idx += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / ld), k = (int)(idx % ld);
@@ -1566,7 +1567,7 @@ __global__ void __launch_bounds__(256) fm_k_dense_node_in(float* __restrict__ ou
 // EndpointVectorField.step (vector_field.py:528-543) for one flat feature array per blockIdx.y:
 //   vf = coef * (x_1 - x_t);  vf = vf * scale;  x_s = x_t + vf * dt      (never-contracted, as torch's separately rounded ops)
 struct FmEndpointStepArgs { float* xt[4]; const float* x1[4]; int n[4]; float coef[4]; float scale, dt; };
-__global__ void __launch_bounds__(256) fm_k_endpoint_step(FmEndpointStepArgs a) {
+static __global__ void __launch_bounds__(256) fm_k_endpoint_step(FmEndpointStepArgs a) {
     const int f = blockIdx.y;
     float* xt = a.xt[f]; const float* x1 = a.x1[f];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[f]; i += gridDim.x * blockDim.x) {
@@ -1576,7 +1577,7 @@ __global__ void __launch_bounds__(256) fm_k_endpoint_step(FmEndpointStepArgs a) 
 }
 
 // x -= per-molecule mean (vector_field.py:347-350); one 64-lane workgroup per molecule
-__global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, const int* __restrict__ mol_node_off) {
+static __global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, const int* __restrict__ mol_node_off) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const int n0 = mol_node_off[m], n1 = mol_node_off[m + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -1590,7 +1591,7 @@ __global__ void __launch_bounds__(64) fm_k_remove_com(float* __restrict__ x, con
 
 // Euler step for positions (ctmc_vector_field.py:331-334): x_t += dt * (coef * (x1 - x_t)), coef = alpha'/(1-alpha)
 //   scale = inv_temp_func(t_i), 1 by default (multiplying by 1.0f is exact)
-__global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, const float* __restrict__ x1, float coef, float dt, float scale, int n3) {
+static __global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, const float* __restrict__ x1, float coef, float dt, float scale, int n3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n3) {
         const float vf = fm_mul_rn(coef, fm_sub_rn(x1[i], x_t[i]));
@@ -1600,7 +1601,7 @@ __global__ void __launch_bounds__(256) fm_k_x_step(float* __restrict__ x_t, cons
 
 // Position prior of the Philox mode: x0 ~ N(0, I) per atom from the molecule's own stream (Box-Muller on draw block
 // (atom, 0xFFFFFFFF, 0)), then minus the molecule's mean (priors.py:27-35) -- one 64-lane workgroup per molecule.
-__global__ void __launch_bounds__(64) fm_k_prior_philox(float* __restrict__ x, const int* __restrict__ mol_node_off,
+static __global__ void __launch_bounds__(64) fm_k_prior_philox(float* __restrict__ x, const int* __restrict__ mol_node_off,
                                                          const int* __restrict__ mol_gid, unsigned seed_lo, unsigned seed_hi) {
     const int m = blockIdx.x, lane = threadIdx.x;
     const int n0 = mol_node_off[m], n1 = mol_node_off[m + 1];
@@ -1787,7 +1788,7 @@ struct FmGatArgs {
     float temp, cf, cb, fw, bw, dt;
 };
 
-__global__ void __launch_bounds__(256) fm_k_ctmc_gat(FmGatArgs a) {
+static __global__ void __launch_bounds__(256) fm_k_ctmc_gat(FmGatArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.rows) return;
     float lp[17];
@@ -1837,7 +1838,7 @@ struct FmStabArgs {
     int* out;                                      // (B,4)
 };
 
-__global__ void __launch_bounds__(64) fm_k_stability(FmStabArgs s) {
+static __global__ void __launch_bounds__(64) fm_k_stability(FmStabArgs s) {
     HIP_DYNAMIC_SHARED(int, sm)
     const int m = blockIdx.x, tid = threadIdx.x;
     const int n0 = s.b.mol_node_off[m], n = s.b.mol_node_off[m + 1] - n0, p0 = s.b.mol_pair_off[m];

@@ -128,8 +128,6 @@ typedef struct fm_config {
      * -1: latency mode -- those three choices follow the batch size (round 5's behaviour: one molecule 0.54 instead of ~0.65 ms per step); results then agree
      * between differently composed batches to f32 summation order only. */
     int32_t canonical;
-    int32_t edge_threads;         /* A/B only: 0 / 512 = 8-wave workgroups | 1024 with tile_edge = 64: the edge-message tile on ONE 16-wave workgroup per CU, every weight
-                                   * fragment fetched once per 64 rows (f32 without the pair slab, f16x3; same summation order, i.e. bit-identical results) */
 } fm_config;
 
 enum fm_precision { FM_PREC_F32 = 0, FM_PREC_BF16X3 = 1, FM_PREC_BF16X6 = 2, FM_PREC_F16X3 = 3 };

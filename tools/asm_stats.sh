@@ -1,7 +1,7 @@
 #!/bin/bash
 # static instruction mix of the GVP kernels (device asm of the current sources)
 D=${TMPDIR:-/tmp}/fm_asm; mkdir -p $D
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-pass-failed ${FM_ASM_FLAGS--ffp-contract=off} -x hip "$(dirname "$0")/../flowmol_amd/csrc/fm_engine.cpp" -S --cuda-device-only -o $D/e.s || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-pass-failed ${FM_ASM_FLAGS--ffp-contract=off} -x hip "$(dirname "$0")/../flowmol_amd/csrc/fm_all_units.cpp" -S --cuda-device-only -o $D/e.s || exit 1
 python3 - "$D/e.s" <<'PY'
 import re, sys
 cur = None; stats = {}

@@ -4,5 +4,5 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); N=$1; shift
 mkdir -p $R/build_ab/$N
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -Wno-pass-failed "$@" -x hip $R/flowmol_amd/csrc/fm_engine.cpp -o $R/build_ab/$N/libflowmol_hip.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -Wno-pass-failed "$@" -x hip $R/flowmol_amd/csrc/fm_all_units.cpp -o $R/build_ab/$N/libflowmol_hip.so
 echo built build_ab/$N "$@"

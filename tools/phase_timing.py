@@ -1,7 +1,7 @@
 """Dev aid: per-phase shader cycles inside fm_k_edge_message (thread 0 of every workgroup), from a
 -DFM_PHASE_TIMING build of the library:
 
-    hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -DFM_PHASE_TIMING -x hip flowmol_amd/csrc/fm_engine.cpp -o /path/lib_timing.so
+    hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -DFM_PHASE_TIMING -x hip flowmol_amd/csrc/fm_all_units.cpp -o /path/lib_timing.so
     python tools/phase_timing.py /path/lib_timing.so
 """
 import ctypes

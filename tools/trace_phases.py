@@ -1,5 +1,5 @@
 """Dev aid: how do the phases of workgroups that share a CU line up?  Needs a -DFM_TRACE build:
-    hipcc ... -DFM_TRACE -x hip flowmol_amd/csrc/fm_engine.cpp -o lib_trace.so ; python tools/trace_phases.py lib_trace.so out.npz"""
+    hipcc ... -DFM_TRACE -x hip flowmol_amd/csrc/fm_all_units.cpp -o lib_trace.so ; python tools/trace_phases.py lib_trace.so out.npz"""
 import ctypes
 import sys
 from pathlib import Path
