@@ -830,8 +830,10 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
         f32x4 acc[RG];
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{b4, b4, b4, b4};
-        if (half) fm_wave_gemm4<KQH, KQ, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
-        else fm_wave_gemm4<0, KQH, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
+        if (!(FM_ABLATE & 32)) {
+            if (half) fm_wave_gemm4<KQH, KQ, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
+            else fm_wave_gemm4<0, KQH, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
+        }
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);

@@ -1147,7 +1147,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
             f32x4 acc[RG];
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
-            fm_wave_gemm4<0, 64, RG>(acc, X, FM_LDX, wq, wave & 3, lane);
+            if (!(FM_ABLATE & 32)) fm_wave_gemm4<0, 64, RG>(acc, X, FM_LDX, wq, wave & 3, lane);
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll

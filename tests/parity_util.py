@@ -64,6 +64,17 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
     state = eng.make_state(x, a, c, eu)
     V = cfg.n_vec_channels
     bufs = {}
+    prev_d = {k: v.to(dev).contiguous() for k, v in prev.items()} if prev is not None else None
+    bootstrap = (t_val == 0) and prev is None
+    # The evaluation's LAST EdgeUpdate may run the edge head as its epilogue and then does not store its rows (fm_k_edge_update<32, false, true>); asking for
+    # that tap selects the separate kernels instead.  Whether the fused kernel runs is the ENGINE's decision (fm_engine.cpp:evaluate) and is asked of the engine
+    # (no copy of its predicate here): a tap-free pass under the profiler -- did `edge_update_head` launch?  Where it did, the tap is not requested,
+    # `out.e` is what checks the fused kernel, and the instrumented pass below must launch it again.
+    eng.profile(True)
+    eng.forward(state, t_val, prev=prev_d, bootstrap=bootstrap, remove_com=True)
+    eng.synchronize()
+    fused_head = eng.profile_get('edge_update_head')[1] > 0
+    eng.profile(False)
     if taps:
         for i in range(cfg.n_convs):
             bufs[f'conv{i}.s'] = torch.zeros(N, 256, device=dev)
@@ -72,11 +83,7 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
             bufs[f'conv{i}.agg.v'] = torch.zeros(N, 3, V, device=dev)
             if cfg.update_schedule()[i] >= 0:
                 bufs[f'upd{i}.x'] = torch.zeros(N, 3, device=dev)
-                # the evaluation's LAST EdgeUpdate runs the edge head as its epilogue and does not store its rows (fm_k_edge_update<32, false, true>); asking
-                # for that tap selects the separate kernels instead, so it is only requested where the fusion is off anyway (fuse_node = 2 | -1, narrow
-                # models, split precision) -- everywhere else the fused kernel is what runs and `out.e` is what checks it
                 last = i == cfg.n_convs - 1 and getattr(cfg, 'n_recycles', 1) <= 1
-                fused_head = eng.tuning.get('fuse_node', 0) in (0, 1) and cfg.n_hidden_edge_feats == 128 and eng.precision == 'f32' and eng.tuning.get('tile_edge_update', 0) != 64
                 if not (last and fused_head):
                     bufs[f'upd{i}.ef'] = torch.zeros(E, 128, device=dev)
         bootstrap_ = (t_val == 0) and prev is None and cfg.self_conditioning
@@ -85,10 +92,12 @@ def forward_compare(eng, orc, cfg, n_atoms, t_val, with_prev, seed=3, frac_maske
         bufs[f'{first}.ef'] = torch.zeros(E, 128, device=dev)
         bufs['conv0.msg.s'] = torch.zeros(E, 256, device=dev)
         bufs['conv0.msg.v'] = torch.zeros(E, 3, V, device=dev)
-    prev_d = {k: v.to(dev).contiguous() for k, v in prev.items()} if prev is not None else None
-    bootstrap = (t_val == 0) and prev is None
+    eng.profile(True)
     out = eng.forward(state, t_val, prev=prev_d, bootstrap=bootstrap, remove_com=True, taps=bufs)
     eng.synchronize()
+    last_ef_tapped = f'upd{cfg.n_convs - 1}.ef' in bufs          # (recycled stacks tap every pass's rows: the tap un-fuses the last pass on purpose)
+    assert (eng.profile_get('edge_update_head')[1] > 0) == (fused_head and not last_ef_tapped), 'the instrumented pass must run the kernels the plain pass runs'
+    eng.profile(False)
     perm = edge_perm(eng, batch) if taps else None
     errs = {}
 

@@ -1037,6 +1037,13 @@ def test_a_molecule_alone_equals_the_same_molecule_in_a_1024_batch_bit_for_bit()
             for k in 'xac':
                 assert torch.equal(one[k], full[k][noff[i]:noff[i] + n]), (k, i)
             assert torch.equal(one['e'], full['e'][poff[i]:poff[i] + u]), i
+    # the opt-in split precision runs the same aggregation / LayerNorm / gate orders: canonical too (another arithmetic, the same guarantee)
+    half = flowmol.FlowMol.from_preset('flowmol3', precision='f16x3').cuda().eval()
+    sizes = torch.full((256,), 47)
+    full, _ = half.sample(sizes, n_timesteps=T, return_tensors=True, rng='philox', _philox=77)
+    one, _ = half.sample(sizes[200:201], n_timesteps=T, return_tensors=True, rng='philox', _philox=77, _mol_ids=torch.tensor([200]))
+    assert torch.equal(one['x'], full['x'][200 * 47:201 * 47]) and torch.equal(one['a'], full['a'][200 * 47:201 * 47])
+    del half
     lat = flowmol.FlowMol.from_preset('flowmol3', canonical=False).cuda().eval()
     sizes = torch.full((256,), 47)
     full, _ = lat.sample(sizes, n_timesteps=T, return_tensors=True, rng='philox', _philox=77)
