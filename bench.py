@@ -266,7 +266,8 @@ def cpu_baseline(cfg, sd, all_sizes, cpu_mols, steps, T, evals, ref_batch=128, r
         return {'value': B / (evals * per_step) * ratio, 'molecules': B, 'cores': best, 'ms_per_step': per_step * 1e3,
                 'timed_runs_ms_per_step': [r * 1e3 for r in runs] if runs else None,
                 'sample_cost_over_workload_cost': ratio, 'thread_probe_ms_per_step': {str(k): v * 1e3 for k, v in probe.items()},
-                'sample': f'{describe(sizes)}, {n_timed} timed integration steps' + (' (two runs of ' + str(probe_steps) + ', each' if runs else ' (') + f' after 1 warm-up step; {per_step * 1e3:.0f} ms/step) with {best} torch threads '
+                'sample': f'{describe(sizes)}, {n_timed} timed integration steps' + (' (two runs of ' + str(probe_steps) + ', each' if runs else ' (')
+                          + f' after 1 warm-up step; {per_step * 1e3:.0f} ms/step) with {best} torch threads '
                           f'(best of {sorted(probe)}, each probed with {probe_steps} step(s) of the same batch)'}
     small = one(_cost_sample(all_sizes, cpu_mols), sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu < 8 else set())), 2, steps)
     out = dict(small)
@@ -411,7 +412,8 @@ def message_roofline(cfg, E, N, us, pmc=None, lib_digest=None, pq=None, us_corre
            'executed_frac': ex_flops / (us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS,
            'mfma_busy_frac': busy,
            'mfma_busy_source': (f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs), {pmc['source_sq']} (library digest {pmc.get('library_digest')})" if busy else None),
-           'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, x E edges per launch) / launch time / peak; '
+           'note': f'frac = ALGORITHMIC FLOPs (2*{conv_message_flops_per_edge(cfg.n_vec_channels) // 2:,} MAC per directed edge, the reference-executed count, '
+                   'x E edges per launch) / launch time / peak; '
                    'executed_frac = the MFMA FLOPs the kernel really issues (padded GEMM shapes after hoisting the per-source terms, '
                    f"{ex['edge_message_per_edge']} MAC/edge) / launch time / peak -- the matrix-pipe occupancy by construction; "
                    'avg_launch_us = the RAW HIP-event pair around the launch on the launch stream (every fraction here is quoted on it: conservative by the ~3 us a pair adds); '
@@ -480,11 +482,13 @@ def secondary_legs(engines, dev, lib_digest, steps):
     out = {}
     sd_sizes, _, _ = job_sizes(1, 1024, None, 'geom_full_kekulized')
     out['geom_size_dist'] = leg('geom_size_dist', 'flowmol3', sd_sizes, 250, False,
-                                f'flowmol3 model, 1024 molecules with sizes ~ the shipped GEOM-drugs histogram (seed 1000: mean {float(sd_sizes.double().mean()):.1f}, max {int(sd_sizes.max())} atoms), n_timesteps=250 '
+                                'flowmol3 model, 1024 molecules with sizes ~ the shipped GEOM-drugs histogram '
+                                f'(seed 1000: mean {float(sd_sizes.double().mean()):.1f}, max {int(sd_sizes.max())} atoms), n_timesteps=250 '
                                 '(the metric\'s "GEOM-drugs size dist"; reference flowmol.py:461-471)', steps)
     out['c2'] = leg('c2', 'qm9', torch.full((256,), 18, dtype=torch.int64), 100, False, 'qm9 model, 256 molecules x 18 atoms, n_timesteps=100 (BASELINE.json configs[1])', 4 * steps)
     c5_sizes, _, _ = job_sizes(1, 128, None, None)
-    out['c5'] = leg('c5', 'geom_ctmc', c5_sizes, 500, True, 'geom_ctmc model, 128 molecules with sizes randint(5, 61, seed 0), n_timesteps=500, trajectory sink on (BASELINE.json configs[4])', 4 * steps)
+    out['c5'] = leg('c5', 'geom_ctmc', c5_sizes, 500, True,
+                    'geom_ctmc model, 128 molecules with sizes randint(5, 61, seed 0), n_timesteps=500, trajectory sink on (BASELINE.json configs[4])', 4 * steps)
     # per-step latency in BOTH arithmetic modes: the default (canonical: a molecule's bits do not depend on its batch; launch choices that select another
     # summation order are fixed) and the latency mode (FlowMol(canonical=False) / fm_config.canonical = -1: 4-node tiles, K-sliced 4-row node MLPs and the
     # pair slab follow the batch size -- round 5's behaviour)
@@ -492,7 +496,8 @@ def secondary_legs(engines, dev, lib_digest, steps):
         sweep = []
         for B in (1, 8, 32, 128):
             o = leg(f'latency_{B}', 'flowmol3', torch.full((B,), 47, dtype=torch.int64), 250, False,
-                    f"flowmol3 model, {B} molecule(s) x 47 atoms, {what}: per-step latency of network evaluation + CTMC update, in-kernel Philox noise (sample(rng='philox'): no torch RNG launches between the steps)",
+                    f"flowmol3 model, {B} molecule(s) x 47 atoms, {what}: per-step latency of network evaluation + CTMC update, "
+                    "in-kernel Philox noise (sample(rng='philox'): no torch RNG launches between the steps)",
                     64, warm=8, philox=True, tuning=tuning)
             sweep.append({k: o[k] for k in ('molecules', 'ms_per_step', 'value', 'steps', 'launches_per_step', 'kernels_us', 'event_pair_overhead_us', 'workload')
                           } | {'roofline': o.get('roofline')})
@@ -551,12 +556,21 @@ def size_dist_leg(eng, cfg, world, rank, dev, B, T, steps, warm=3):
     finite = bool(torch.isfinite(L.state['x_t']).all().item())
     del L
     return {'value_geom_size_dist': B * world / (evals * ms / 1e3), 'ms_per_step_geom_size_dist': ms,
-            'workload_size_dist': f'flowmol3 model, {B * world} molecules with sizes ~ the shipped GEOM-drugs histogram (seed 1000: mean {float(sizes.double().mean()):.1f}, max {int(sizes.max())} atoms), '
+            'workload_size_dist': f'flowmol3 model, {B * world} molecules with sizes ~ the shipped GEOM-drugs histogram '
+                                  f'(seed 1000: mean {float(sizes.double().mean()):.1f}, max {int(sizes.max())} atoms), '
                                   f'n_timesteps={T}, dealt to {world} rank(s) by shard.partition_lpt; {steps} timed steps after {warm} warm-up steps, max over ranks',
             'size_dist_shard_cost_max_over_mean': float(sc.max() / sc.mean()), 'size_dist_finite': finite}
 
 
 PARITY_MOLS_PER_RANK, PARITY_T, PARITY_SEED = 8, 12, 1234
+DTYPE_LABEL = {       # `dtype` of the line: the arithmetic the path computes in
+    'f32': 'f32',
+    'bf16x3': 'bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)',
+    'f16x3': 'f16x3 split precision (opt-in; f32 operands as hi+lo IEEE half = 22 mantissa bits, 3 products per term on v_mfma_f32_16x16x32_f16, f32 accumulate; '
+             '|activations| clamped to 65504)',
+    'bf16x6': 'bf16x6 three-term split precision of the edge-message GEMMs (opt-in; f32 operands as hi+mid+lo bf16, 6 products per term, f32 accumulate; '
+              'node kernels and EdgeUpdate f32)',
+}
 
 
 def parity_job_sizes(world):
@@ -719,13 +733,15 @@ def main():
                          "(QM9 model, 256 x 18 atoms, T=100); c5 = configs[4] (geom_full_kekulized model, 128 molecules of randint(5,61,seed 0) atoms, T=500, trajectory sink on)")
     ap.add_argument('--mols-per-gpu', type=int, default=None)
     ap.add_argument('--n-atoms', type=int, default=None)
-    ap.add_argument('--size-dist', default=None, help="draw the molecule sizes from a shipped training-set histogram (e.g. geom_full_kekulized) instead of --n-atoms; secondary measurement, the headline line uses fixed sizes")
+    ap.add_argument('--size-dist', default=None, help="draw the molecule sizes from a shipped training-set histogram (e.g. geom_full_kekulized) instead of --n-atoms; "
+                                                      "secondary measurement, the headline line uses fixed sizes")
     ap.add_argument('--timesteps', type=int, default=None)
     ap.add_argument('--preset', default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', choices=('f32', 'bf16x3', 'bf16x6', 'f16x3'), default='f32',
                     help="arithmetic of the edge-message GEMMs: 'f32' (default, the reference's arithmetic, the headline) or the OPT-IN split precision "
-                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) / 'bf16x6' (hi+mid+lo, six products, edge messages only) / 'f16x3' (hi+lo IEEE half, three products) -- separately reported modes")
+                         "'bf16x3' (f32 operands as hi+lo bf16, three products on the bf16 matrix cores) / 'bf16x6' (hi+mid+lo, six products, edge messages only) / "
+                         "'f16x3' (hi+lo IEEE half, three products) -- separately reported modes")
     ap.add_argument('--no-api-e2e', action='store_true', help='skip the secondary end-to-end FlowMol.sample() timing')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary legs (size distribution, C2, C5, latency sweep) of the default one-GPU run')
     ap.add_argument('--secondary-steps', type=int, default=10, help='timed steps of the size-distribution leg (C2 / C5: 4x, latency sweep: 64)')
@@ -890,17 +906,19 @@ def main():
     except Exception:
         rccl = None
     out = {
-        'metric': (f'molecules/sec at {T} timesteps ' + ('(GEOM-drugs-sized graphs)' if args.workload == 'c3' else f'[secondary workload {args.workload}]')) + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
+        'metric': (f'molecules/sec at {T} timesteps ' + ('(GEOM-drugs-sized graphs)' if args.workload == 'c3' else f'[secondary workload {args.workload}]'))
+                  + ('' if args.precision == 'f32' else ' [opt-in split-precision mode]'), 'value': mols_per_s, 'unit': 'molecules/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.precision == 'f32' else ('bf16x3 split precision (opt-in; f32 operands as hi+lo bf16, 3 products per term, f32 accumulate)' if args.precision == 'bf16x3' else
-                                                         'f16x3 split precision (opt-in; f32 operands as hi+lo IEEE half = 22 mantissa bits, 3 products per term on v_mfma_f32_16x16x32_f16, f32 accumulate; |activations| clamped to 65504)' if args.precision == 'f16x3' else
-                                                         'bf16x6 three-term split precision of the edge-message GEMMs (opt-in; f32 operands as hi+mid+lo bf16, 6 products per term, f32 accumulate; node kernels and EdgeUpdate f32)'), 'data': 'synthetic',
-        'config': {'workload': f'{args.preset} model, {B} molecules/GPU x ' + (f'{n} atoms' if not ragged else (f'sizes ~ {args.size_dist} histogram' if args.size_dist else 'sizes randint(5, 61, seed 0)') + f' (mean {float(all_sizes.double().mean()):.1f}, max {int(all_sizes.max())}; ONE global list dealt to the ranks by shard.partition_lpt)') + f', n_timesteps={T} '
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_LABEL[args.precision], 'data': 'synthetic',
+        'config': {'workload': f'{args.preset} model, {B} molecules/GPU x '
+                               + (f'{n} atoms' if not ragged else (f'sizes ~ {args.size_dist} histogram' if args.size_dist else 'sizes randint(5, 61, seed 0)')
+                                  + f' (mean {float(all_sizes.double().mean()):.1f}, max {int(all_sizes.max())}; ONE global list dealt to the ranks by shard.partition_lpt)') + f', n_timesteps={T} '
                                f"({wl['label']})",
                    'shard_cost_max_over_mean': float(shard_cost.max() / shard_cost.mean()), 'molecules_per_rank': [int(len(p_)) for p_ in parts],
                    'global_molecules': B * world, 'nodes_per_gpu': N, 'directed_edges_per_gpu': E, 'parallelism': f'molecule-shard x{world}',
                    'step': 'one integration step = 1 network evaluation + Euler/CTMC update of the whole batch',
-                   'value_formula': 'global_molecules / (network_evaluations_per_sample * ms_per_step/1000)', 'network_evaluations_per_sample': evals, 'trajectory_sink': bool(wl['traj']), 'weights': 'synthetic by name (seed 0)',
+                   'value_formula': 'global_molecules / (network_evaluations_per_sample * ms_per_step/1000)', 'network_evaluations_per_sample': evals,
+                   'trajectory_sink': bool(wl['traj']), 'weights': 'synthetic by name (seed 0)',
                    'finite': finite, 'library_digest': lib_digest,
                    'process_group': {'size': world, 'backend': (dist.get_backend() if world > 1 else None), 'rccl_version': rccl, 'ranks': rank_info}},
         'network_eval_ms': ms_per_step, 'ms_per_step_windows': windows, 'per_rank_ms_per_step': per_rank_ms, 'final_gather_ms': gather_ms,
@@ -913,7 +931,8 @@ def main():
                                'the kernels issue (per-source terms hoisted to per-node GEMMs, few-input embeddings tabulated); only executed_frac is a '
                                'fraction of the f32 peak -- the algorithmic rate may exceed the peak because fewer FLOPs are executed'},
         'kernels': kern,
-        'kernels_note': f'per-kernel averages come from a separate HIP-event-instrumented pass of 2 steps after the timed region; avg_us = event pair minus the pair overhead measured in the same pass on an empty kernel ({ev_overhead:.1f} us)',
+        'kernels_note': 'per-kernel averages come from a separate HIP-event-instrumented pass of 2 steps after the timed region; '
+                        f'avg_us = event pair minus the pair overhead measured in the same pass on an empty kernel ({ev_overhead:.1f} us)',
     }
     if roofline:
         out['roofline'] = roofline

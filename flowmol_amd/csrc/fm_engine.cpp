@@ -539,8 +539,10 @@ int ctmc_impl(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* ds
     if (frame) { f.sink_x = frame->x; f.sink_x1 = frame->x1; }
     if (sc->noise_mode == FM_NOISE_PHILOX) { f.philox = 1; f.seed_lo = sc->philox_seed_lo; f.seed_hi = sc->philox_seed_hi; f.step = sc->step_index; f.mol_gid = c->mol_gid; }
     else if (!nz->q_a || !nz->u1_a || !nz->q_e) return fail(c, FM_ERR_INVALID, "fm_ctmc_step: noise tensors missing (noise_mode FM_NOISE_TENSORS)");
-    // a few molecules: 1024-thread workgroups (one per molecule and modality is all the parallelism there is); else 256
-    if (b.B * 4 <= c->n_cus && c->nmax > 23) L("ctmc", fm_k_ctmc_fused<1024>, dim3(b.B, 4), dim3(1024), 0, f);
+    // a few molecules: 1024-thread workgroups (one per molecule and modality is all the parallelism there is) -- and batches whose LARGEST molecule has more
+    // than 4096 pairs (n >= 92): its pair rows are one workgroup's serial loop, 35 rounds of 256 threads at 134 atoms (GEOM size distribution: 135 us of a
+    // 67.8-ms step against 39 us at 1024 x 47 atoms); else 256.  Same arithmetic either way (integer counts, per-row decisions).
+    if ((b.B * 4 <= c->n_cus && c->nmax > 23) || c->nmax >= 92) L("ctmc", fm_k_ctmc_fused<1024>, dim3(b.B, 4), dim3(1024), 0, f);
     else L("ctmc", fm_k_ctmc_fused<256>, dim3(b.B, 4), dim3(256), 0, f);
     return L.rc;
 }
