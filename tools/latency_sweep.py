@@ -12,10 +12,12 @@ from flowmol_amd import presets, weights                 # noqa: E402
 from flowmol_amd.engine import Engine, IntegrationRun, StepNoise, make_step_plan   # noqa: E402
 
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 8, 32, 128, 512]
-tuning = {a.split('=')[0]: int(a.split('=')[1]) for a in sys.argv[1:] if '=' in a}      # fm_config launch-tuning overrides, e.g. fuse_node=-1
+tuning = {a.split('=')[0]: int(a.split('=')[1]) for a in sys.argv[1:] if '=' in a and not a.startswith('lib=')}      # fm_config launch-tuning overrides, e.g. fuse_node=-1
+libarg = [a[4:] for a in sys.argv[1:] if a.startswith('lib=')]       # lib=<path relative to the repository root>: an A/B build (tools/build_variant.sh)
 philox = 'philox' in sys.argv[1:]          # in-kernel noise: no torch RNG launches between the steps
 cfg = presets.flowmol3()
-eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', tuning=tuning)
+from flowmol_amd import _lib                             # noqa: E402
+eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', tuning=tuning, lib=_lib.load(str(ROOT / libarg[0])) if libarg else None)
 dev = eng.device
 for B in sizes:
     eng.bind(torch.full((B,), 47, dtype=torch.int64))
@@ -45,5 +47,5 @@ for B in sizes:
         if cnt:
             per_kernel[k] = round(ms / cnt * 1e3, 1)       # us per launch
     eng.profile(False)
-    print(json.dumps({'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
+    print(json.dumps({'lib': libarg[0] if libarg else 'flowmol_amd/libflowmol_hip.so', 'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
                       'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2), 'us_per_launch': per_kernel}))
