@@ -489,10 +489,11 @@ def secondary_legs(engines, dev, lib_digest, steps):
     c5_sizes, _, _ = job_sizes(1, 128, None, None)
     out['c5'] = leg('c5', 'geom_ctmc', c5_sizes, 500, True,
                     'geom_ctmc model, 128 molecules with sizes randint(5, 61, seed 0), n_timesteps=500, trajectory sink on (BASELINE.json configs[4])', 4 * steps)
-    # per-step latency in BOTH arithmetic modes: the default (canonical: a molecule's bits do not depend on its batch; launch choices that select another
-    # summation order are fixed) and the latency mode (FlowMol(canonical=False) / fm_config.canonical = -1: 4-node tiles, K-sliced 4-row node MLPs and the
-    # pair slab follow the batch size -- round 5's behaviour)
-    for key, tuning, what in (('latency_sweep', None, 'canonical arithmetic (default)'), ('latency_sweep_latency_mode', {'canonical': -1}, 'latency mode (canonical=False)')):
+    # per-step latency in BOTH arithmetic modes: the default (canonical: a molecule's bits do not depend on its batch; small batches run 4-node tiles and
+    # 4-row node MLPs whose GEMMs keep the regular tiles' summation order) and FlowMol(canonical=False) / fm_config.canonical = -1, where the pair slab
+    # follows the batch size too (round 5's "latency mode": since the 4-row kernels are canonical the two differ by ~1 %)
+    for key, tuning, what in (('latency_sweep', None, 'canonical arithmetic (default)'),
+                              ('latency_sweep_latency_mode', {'canonical': -1}, 'canonical=False (the pair slab follows the batch size)')):
         sweep = []
         for B in (1, 8, 32, 128):
             o = leg(f'latency_{B}', 'flowmol3', torch.full((B,), 47, dtype=torch.int64), 250, False,

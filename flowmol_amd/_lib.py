@@ -34,7 +34,7 @@ class fm_config(C.Structure):
         # ABI 5: launch-tuning overrides, 0 = automatic (see include/flowmol_hip.h)
         ('tile_edge', C.c_int32), ('tile_node', C.c_int32), ('tile_edge_update', C.c_int32), ('xcd_swizzle', C.c_int32),
         ('fuse_node', C.c_int32), ('pair_mlps', C.c_int32), ('mlp_small_tiles', C.c_int32), ('pair_slab', C.c_int32),
-        # ABI 7: 0 / 1 = canonical arithmetic (a molecule's bits do not depend on its batch), -1 = latency mode
+        # ABI 7: 0 / 1 = canonical arithmetic (a molecule's bits do not depend on its batch), -1 = the pair slab follows the batch size (results then equal to f32 summation order)
         ('canonical', C.c_int32),
     ]
 

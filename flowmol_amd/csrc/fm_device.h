@@ -264,25 +264,26 @@ __device__ __forceinline__ void fm_wave_gemm(f32x4 (&acc)[MT][NT], const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// 4-row GEMM on v_mfma_f32_4x4x1_16B_f32 for the node kernels of small batches (RG instances): a tile of 4 RG nodes (RG groups of four rows), so
-// that the nodes spread over more CUs and a 4-node tile's scalar GEMM is 1.0 us of matrix time instead of 3.9 (the instruction runs at the full f32 rate:
-// 8.5 cycles per 512 FLOP, profiles/r04h).  Sixteen 4x4 blocks per instruction; with A_b = X[0..3][k] for every block and B_b = W[k][4b..4b+3]
+// 4-row GEMM on v_mfma_f32_4x4x1_16B_f32 for the node kernels of small batches (RG instances of fm_k_node_update, fm_k_mlp4): a tile of 4 RG nodes (RG groups
+// of four rows), so that the nodes spread over more CUs and a 4-node tile's scalar GEMM is ~1 us of matrix time instead of 3.9 (the instruction runs at the
+// full f32 rate: 8.5 cycles per 512 FLOP, profiles/r04h).  Sixteen 4x4 blocks per instruction; with A_b = X[0..3][k] for every block and B_b = W[k][4b..4b+3]
 // one instruction adds X[0..3][k] (x) W[k][0..63] to a 4 x 64 output tile held as acc[r] = out[r][lane] (layout verified on the device:
-// tools/ubench/mfma_4x4_layout.cpp).  Weights are quad-row packed, Wq4[(kq * 4 + g) * 64 + lane] = W[4kq .. 4kq+3][64g + lane]: one 1-KB
-// buffer_load_dwordx4 per four k and wave -- a CU's L2 port delivers 150 GB/s with such loads, 76 GB/s with the 512-byte loads of
-// fm_wave_gemm, and the weight stream (303 KB per scalar GEMM whatever the tile height) is what bounds a 4-row tile.  A operands: one
-// ds_read_b128 (four k of row lane & 3; the 16 lanes of a row read the same address).  KQ quad steps, software-pipelined PD deep.
-// ---------------------------------------------------------------------------------------------
-// Quad steps [KQ0, KQ1) of the product; PD loads of 1 KB in flight per wave: the L2 answers in ~0.4 us under load, so the stream rate of a CU is
-// (bytes in flight) / latency -- eight waves x eight loads = 64 KB reach the port's 150 GB/s, four waves x four loads would reach a quarter of it
-// (first version of this path, profiles/r04o).
-// RG row groups of four (rows 4g .. 4g+3 of the frame): every weight fragment is loaded once and multiplied with RG A operands.
-template <int KQ0, int KQ1, int RG>
+// tools/ubench/mfma_4x4_layout.cpp).  Weights are quad-row packed, Wq4[(kq * GS + g) * 64 + lane] = W[4kq .. 4kq+3][64g + lane] (GS column groups): one 1-KB
+// buffer_load_dwordx4 per four k and wave.  A operands: one ds_read_b128 (four k of row lane & 3; the 16 lanes of a row read the same address).
+//
+// THE SUMMATION ORDER IS THE REGULAR TILES' (round 6): a 16x16x4 accumulator of fm_wave_gemm is ONE fma chain from its initial value over the k-slots
+// 8s + {0, 2, 4, 6} (first pass of superstep s: lanes 16 j .. 16 j + 15 hold k = 8s + 2j) and then 8s + {1, 3, 5, 7} (second pass) -- fm_frag_mma; measured on the
+// MI355X: the hardware's 16x16x4 and 4x4x1 chains give identical bits (profiles/r06m_*, r06n_*).  Here the same chain runs with one k per instruction: quads 2s and
+// 2s + 1, elements 0, 2 of both, then 1, 3 of both.  One accumulator per row group (no even / odd pair, no K split over waves -- rounds 4-5 had both: another order, faster by
+// <= 1 us per launch): a 4 RG-node tile gives the bits of the regular 16- / 32-row tiles, so the tile height may follow the batch size in
+// canonical mode.  All-zero products of padded k-slots add exactly 0: the padded tail needs no special case.  KQ even; PD quads of weights in flight.
+template <int KQ, int RG, int PD = 8, int GS = 4>
 __device__ __forceinline__ void fm_wave_gemm4(f32x4 (&acc)[RG], const float* X, int ldx, const void* Wq4, int g, int lane) {
-    constexpr int PD = 8, PA = 2, N = KQ1 - KQ0;       // weight fragments (L2) eight quad steps ahead, A operands (LDS) two
-    const float* ap = X + (lane & 3) * ldx + 4 * KQ0;
+    static_assert(KQ % 2 == 0 && PD % 2 == 0, "whole k-supersteps (two quads each)");
+    constexpr int PA = 4;                            // A operands (LDS): two supersteps in flight
+    const float* ap = X + (lane & 3) * ldx;
     const auto rs = fm_buf(Wq4);
-    const int s0 = (KQ0 * 4 + g) * 1024;             // wave-uniform byte offset of the first fragment; the others are compile-time multiples of 4 KB away
+    const int s0 = g * 1024;                         // wave-uniform byte offset of the first fragment; the others are compile-time multiples of GS KB away (GS column groups in the packing)
     f32x4 a[PA][RG];
     float4 b[PD];
     auto load_a = [&](int q, int k) {
@@ -290,90 +291,53 @@ __device__ __forceinline__ void fm_wave_gemm4(f32x4 (&acc)[RG], const float* X, 
         for (int rg = 0; rg < RG; ++rg) a[q][rg] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + rg * 4 * ldx + 4 * k);
     };
 #pragma unroll
-    for (int q = 0; q < PD; ++q) if (q < N) b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * 4096);
+    for (int q = 0; q < PD; ++q) if (q < KQ) b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * GS * 1024);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) if (q < N) load_a(q, q);
-    f32x4 acc1[RG];                                // two accumulators per group: consecutive MFMAs never depend on each other
+    for (int q = 0; q < PA; ++q) if (q < KQ) load_a(q, q);
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) acc1[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KQ; k += 2) {                // fully unrolled: every offset an immediate, exact wait counts
+        const float4 b0 = b[k % PD], b1 = b[(k + 1) % PD];
+        f32x4 a0[RG], a1[RG];
 #pragma unroll
-    for (int k = 0; k < N; ++k) {                  // fully unrolled: every offset an immediate, exact wait counts
-        const float4 bv = b[k % PD];
-        f32x4 av[RG];
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) av[rg] = a[k % PA][rg];
-        if (k + PD < N) b[k % PD] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * 4096);
-        if (k + PA < N) load_a(k % PA, k + PA);
+        for (int rg = 0; rg < RG; ++rg) { a0[rg] = a[k % PA][rg]; a1[rg] = a[(k + 1) % PA][rg]; }
+        if (k + PD < KQ) { b[k % PD] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * GS * 1024); b[(k + 1) % PD] = fm_buf_f32x4(rs, lane * 16, s0 + (k + 1 + PD) * GS * 1024); }
+        if (k + PA < KQ) { load_a(k % PA, k + PA); load_a((k + 1) % PA, k + 1 + PA); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][0], bv.x, acc[rg], 0, 0, 0);
-            acc1[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][1], bv.y, acc1[rg], 0, 0, 0);
-        }
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rg][0], b0.x, acc[rg], 0, 0, 0);
 #pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][2], bv.z, acc[rg], 0, 0, 0);
-            acc1[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rg][3], bv.w, acc1[rg], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rg][2], b0.z, acc[rg], 0, 0, 0);
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) acc[rg] += acc1[rg];
-}
-
-// The same 4-row product for the node-side MLP kernels of small batches (fm_k_mlp4): quad steps [kq0, kq0 + NQ) with a run-time, wave-uniform kq0 (each of
-// the eight waves takes its own K slice), and G column groups of 64 in the packing -- Wq4[(kq * G + g) * 64 + lane] = W[4kq .. 4kq+3][64g + lane] -- so that a
-// narrow second layer (N = 64: G = 1) splits its K over all eight waves.  Up to eight 1-KB fragment loads in flight per wave, fully unrolled.
-template <int NQ, int G>
-__device__ __forceinline__ f32x4 fm_wave_gemm4_at(const float* X, int ldx, const void* Wq4, int kq0, int g, int lane) {
-    constexpr int PD = NQ < 8 ? NQ : 8, PA = 2;
-    const float* ap = X + (lane & 3) * ldx + 4 * kq0;
-    const auto rs = fm_buf(Wq4);
-    const int s0 = (kq0 * G + g) * 1024;             // wave-uniform byte offset of the first fragment; consecutive quad steps are G KB apart
-    f32x4 a[PA];
-    float4 b[PD];
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rg][0], b1.x, acc[rg], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < PD; ++q) b[q] = fm_buf_f32x4(rs, lane * 16, s0 + q * G * 1024);
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rg][2], b1.z, acc[rg], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) if (q < NQ) a[q] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * q);
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rg][1], b0.y, acc[rg], 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const float4 bv = b[k % PD];
-        const f32x4 av = a[k % PA];
-        if (k + PD < NQ) b[k % PD] = fm_buf_f32x4(rs, lane * 16, s0 + (k + PD) * G * 1024);
-        if (k + PA < NQ) a[k % PA] = *(const volatile __attribute__((address_space(3))) f32x4*)(ap + 4 * (k + PA));
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv.w, acc1, 0, 0, 0);
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[rg][3], b0.w, acc[rg], 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rg][1], b1.y, acc[rg], 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[rg][3], b1.w, acc[rg], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
-    return acc0 + acc1;
 }
 
-// out[4][64 G] = X[4][4 KQ] * W for a 512-thread workgroup: wave w takes column group w % G and K slice w / G (8 / G slices); the slices meet in the
-// exchange tile S [8 / G][4][64 G] and epi(row, column, sum) is called once per output element.  Ends with a barrier (S and whatever epi wrote are settled).
+// out[4][64 G] = X[4][4 KQ] * W for a 512-thread workgroup: wave g < G owns column group g and runs ONE fma chain per output element from 0 over all of K in the
+// regular MLP tiles' order (fm_block_gemm starts at 0 and adds the bias in its epilogue, as epi does here) -- the bits of fm_mlp2_tile, so the 4-row tiles may
+// be chosen by batch size in canonical mode.  epi(row, column, sum) runs on the accumulator registers; ends with a barrier.
 template <int KQ, int G, class Epi>
-__device__ __forceinline__ void fm_rows4_linear(const float* X, int ldx, const void* Wq4, float* S, Epi epi) {
-    constexpr int KS = 8 / G, NQ = KQ / KS, W = 64 * G;
-    static_assert(KQ % KS == 0 && (G == 1 || G == 2 || G == 4), "K quads must split evenly over the wave slices");
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave % G, slice = wave / G;
-    const f32x4 acc = fm_wave_gemm4_at<NQ, G>(X, ldx, Wq4, slice * NQ, g, lane);
+__device__ __forceinline__ void fm_rows4_linear(const float* X, int ldx, const void* Wq4, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < G) {
+        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        fm_wave_gemm4<KQ, 1, 16, G>(acc, X, ldx, Wq4, wave, lane);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(slice * 4 + r) * W + 64 * g + lane] = acc[r];
-    __syncthreads();
-    for (int idx = tid; idx < 4 * W; idx += FM_THREADS) {
-        const int r = idx / W, c = idx % W;
-        float v = S[r * W + c];
-#pragma unroll
-        for (int sl = 1; sl < KS; ++sl) v += S[(sl * 4 + r) * W + c];
-        epi(r, c, v);
+        for (int r = 0; r < 4; ++r) epi(r, 64 * wave + lane, acc[0][r]);
     }
     __syncthreads();
 }
+
 
 // Single-tile (16x16) GEMM with compile-time K and chunked prefetch: all A/B fragments of chunk c+1 (CH k-supersteps)
 // are requested before the MFMAs of chunk c.  A 1x1 tile has only 2 MFMAs (64 cycles) per k-superstep, far less
@@ -702,8 +666,8 @@ struct FmGvpTile {
 // PQ (FIRST only): the [rbf | ef] slab of the scalar linear arrives inside `pre` (per-pair table Q, FmMlpArgs::slabQ0): X holds only the hidden-vector
 // norms sh at columns [0, KU0) and the scalar GEMM has K = KU0.
 // RG > 0 (node kernels of small batches): only rows 0 .. 4 RG - 1 of the TM-row frame are nodes; the scalar GEMM -- the one phase whose cost
-// scales with the tile height -- runs on those rows with fm_wave_gemm4 (64 columns per wave, K split over the two wave groups, the halves
-// meeting in an exchange tile behind G); every other phase is the TM-row code over the frame.
+// scales with the tile height -- runs on those rows with fm_wave_gemm4 (64 columns on each of waves 0..3, one fma chain per output element in the k-order of the
+// regular tiles' 16x16x4 MFMAs: the bits of the regular 16- / 32-row tiles); every other phase is the TM-row code over the frame.
 template <int V, int VOUT, bool FIRST, bool SIGMOID, int TM, int NTH, int HX = 0, int SP = 0, bool LAST = false, bool PQ = false, int RG = 0>
 __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, float* G, const FmGvpW& w,
                                             float (&pre)[TM / 16][1024 / NTH][4] FM_MARK_ARG) {
@@ -820,35 +784,24 @@ __device__ __forceinline__ void fm_gvp_core(float* X, float* Vin, float* Vh, flo
     // scalar linear: TM x K -> 256, wave w owns column tiles NTW*w .. NTW*w+NTW-1 for all MT row tiles
     float keep[(SP && LAST) ? MT : 1][(SP && LAST) ? NTW : 1][4];     // split precision, last GVP: the f32 scalar output for the aggregation
     if constexpr (RG > 0) {
-        // waves 0..3: k quads [0, KQ/2) of their 64 columns (starting from the bias), waves 4..7: the other half; the halves meet in the exchange
-        // tile S [4 RG][256] that the RG instances allocate behind G
-        constexpr int KQ = (SOFF + KUC) / 4, KQH = (KQ + 1) / 2;
-        float* S = G + TM * FM_LDG;
-        const int g = wave & 3, half = wave >> 2;
+        constexpr int KQ = (SOFF + KUC) / 4;
+        const int g = wave & 3;
         FM_MARKB(2);
-        const float b4 = half ? 0.f : w.bs[64 * g + lane];
         f32x4 acc[RG];
+        if (wave < 4) {
+            const float b4 = w.bs[64 * g + lane];
 #pragma unroll
-        for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{b4, b4, b4, b4};
-        if (!(FM_ABLATE & 32)) {
-            if (half) fm_wave_gemm4<KQH, KQ, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
-            else fm_wave_gemm4<0, KQH, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
+            for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{b4, b4, b4, b4};
+            if (!(FM_ABLATE & 32)) fm_wave_gemm4<KQ, RG>(acc, X, FM_LDX, w.Ws4, g, lane);
         }
         FM_MARKB(3);
         __syncthreads();                      // every wave has finished reading X (and Vh)
         FM_MARKB(4);
-        if (half) {
+        if (wave < 4) {
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[(4 * rg + r) * 256 + 64 * g + lane] = acc[rg][r];
-        }
-        __syncthreads();
-        if (!half) {
-#pragma unroll
-            for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[(4 * rg + r) * FM_LDX + 64 * g + lane] = fm_silu(acc[rg][r] + S[(4 * rg + r) * 256 + 64 * g + lane]);
+                for (int r = 0; r < 4; ++r) X[(4 * rg + r) * FM_LDX + 64 * g + lane] = fm_silu(acc[rg][r]);
         }
         __syncthreads();
     } else {

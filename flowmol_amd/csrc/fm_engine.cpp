@@ -249,7 +249,7 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
     const bool small_mlp = small_node && small_pair;                                                                   // shared launches
     // node-side MLPs on 4-row tiles (fm_k_mlp4) while such tiles fit one per CU: a 16-row tile's two 256-wide layers are ~7 us of matrix time on one CU
     // whatever the batch, four rows on v_mfma_f32_4x4x1 are the layers' weight stream; fm_config.mlp_small_tiles = 2 forces it (1 / -1: never)
-    const bool mlp4 = c->node_head_W1q && !dense && (c->mlp4_forced >= 0 ? c->mlp4_forced != 0 : (!c->canonical && (N + 3) / 4 <= c->n_cus));      // K slices: another summation order -> never in canonical mode
+    const bool mlp4 = c->node_head_W1q && !dense && (c->mlp4_forced >= 0 ? c->mlp4_forced != 0 : (N + 3) / 4 <= c->n_cus);      // the regular tiles' bits (fm_rows4_linear): the choice may follow the batch size in canonical mode
     const int tiles4 = (N + 3) / 4;
     // pair-slab convolutions of this evaluation (first pass only; FmMlpArgs::slabQ0): self-conditioned evaluations with at least four rounds of
     // 32-row pair tiles (measured neutral on small batches: the table costs a kernel phase, the saving is matrix-pipe time they are not bound by)
@@ -372,15 +372,15 @@ int evaluate(fm_ctx* c, hipStream_t st, const fm_state* state, const fm_dst* pre
             }
         }
         nu.s_real = c->S;
-        {   // instance of the node kernel: split precision (fused sequence only), 4 rg nodes per workgroup (small batches in latency mode), narrow, or the regular one
+        {   // instance of the node kernel: split precision (fused sequence only), 4 rg nodes per workgroup (small batches), narrow, or the regular one
             const bool spn = HX == 0 && TN <= 32 && prec_two_plane(cf.precision) && fuse;
             const int rg = (!spn && HX == 0 && (TN == 16 || TN == 32) && c->node_rg && fuse && c->S == 256 && cf.precision == FM_PREC_F32) ? c->node_rg : 0;
             if (spn) {
                 if (it + 1 < n_pass) nu.Wps_sp = c->conv[(i + 1) % cf.n_convs].Wps_sp;
                 if (u >= 0) nu.Wasd_sp = c->upd[u].Wasd_sp;
                 fm_launch_node_update(L, V, TN, true, cf.precision == FM_PREC_F16X3 ? 3 : 1, 0, gnt, lds_gvp_sp(V, TN) - (size_t)TN * 9 * 4, nu);
-            } else if (rg) {        // one tile per CU; + the exchange tile of the two K halves
-                fm_launch_node_update(L, V, TN, false, 0, rg, dim3((N + 4 * rg - 1) / (4 * rg)), lds_gvp(V, TN, false) + (size_t)rg * 4096, nu);
+            } else if (rg) {        // one tile per CU
+                fm_launch_node_update(L, V, TN, false, 0, rg, dim3((N + 4 * rg - 1) / (4 * rg)), lds_gvp(V, TN, false), nu);
             } else {
                 fm_launch_node_update(L, V, TN, c->S != 256, 0, 0, gnt, lds_gvp(V, TN, false), nu);
             }
@@ -920,7 +920,7 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     int tn = c->tm_node_forced;
     if (!tn) {
         tn = (N + 31) / 32 <= c->n_cus ? 16 : 32;
-        if (rg_ok && !c->canonical) {      // the RG instances split K over two wave groups: another summation order -> latency mode only (or forced)
+        if (rg_ok) {      // the 4 RG-node instances keep the regular tiles' summation order (fm_wave_gemm4): the choice may follow the batch size in canonical mode
             static const int cand[] = {4, 8, 12, 16, 20};
             for (int r : cand) if ((N + r - 1) / r <= c->n_cus) { tn = r; break; }
         }

@@ -72,9 +72,10 @@ struct fm_ctx {
     int node_rg = 0;          // this batch runs the node kernel on tiles of 4 * node_rg nodes (RG instances; 1, 2, 3 in the 16-row frame, 5 in the 32-row
                               // frame): chosen per bound batch, fm_config.tile_node = 4 / 8 / 12 / 20 forces it
     int pq_forced = 0;        // fm_config.pair_slab = 1: also for batches whose pair tiles do not fill the chip
-    // fm_config.canonical >= 0 (default): every launch choice that selects another f32 summation order is FIXED -- regular node tiles (no 4 RG-node instances),
-    // no 4-row node MLPs, the pair slab in every evaluation that can use it -- so that a molecule's result does not depend on the size or composition of
-    // its batch (see FM_CHUNK_E in fm_kernels.h for the aggregation order); -1: those three follow the batch size (lowest latency for batches of a few molecules)
+    // fm_config.canonical >= 0 (default): the ONE launch choice that selects another f32 summation order -- the pair slab (slab + K = 40 chain instead of one K = 200
+    // chain) -- is FIXED: computed in every evaluation that can use it, so that a molecule's result does not depend on the size or composition of its batch (see
+    // FM_CHUNK_E in fm_kernels.h for the aggregation order).  Tile heights -- incl. the 4 RG-node instances and the 4-row node MLPs, whose GEMMs keep the regular
+    // tiles' order since round 6 (fm_wave_gemm4) -- follow the batch size in both modes.  -1: the pair slab follows the batch size too (round 5's rule).
     bool canonical = true;
     float* Q[2] = {nullptr, nullptr};      // (U,256) each, in the workspace
     int xcd_swizzle = 1;      // edge-message tile -> workgroup mapping: contiguous tile range per XCD (fm_config.xcd_swizzle = -1 disables)

@@ -409,13 +409,14 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_mlp2_pair(FmMlpArgs a, FmMlpA
 // two dependent 256-wide layers are 4 + 3.4 us of matrix time on ONE CU whatever the batch (v_mfma_f32_16x16x4 multiplies 16 rows or none); on four rows
 // with v_mfma_f32_4x4x1_16B_f32 a layer is its 0.3 MB weight stream at a CU's 150 GB/s, and a 47-atom molecule spreads over 12 CUs instead of 3 -- the
 // treatment round 4 gave fm_k_node_update (fm_wave_gemm4), here for the self-conditioning node layer (self_conditioning.py:49-58), the node output
-// head (vector_field.py:336-339) and the first convolution's hoisted projection.  Arithmetic per element as in fm_mlp2_tile / fm_k_node_proj; the K order of
-// the sums differs (two or eight K slices meeting in LDS), which f32 parity tolerates like every other tile shape.
+// head (vector_field.py:336-339) and the first convolution's hoisted projection.  Arithmetic per element AND summation order as in fm_mlp2_tile / fm_k_node_proj
+// (round 6: fm_rows4_linear runs the regular tiles' fma chains, one column group of 64 per wave; rounds 4-5 split K over the eight waves -- another order):
+// bit-identical to the 16- / 64-row MLP tiles, so the choice follows the batch size in canonical mode too.
 // ------------------------------------------------------------------------------------------------
 enum FmMlp4Mode { FM_MLP4_SC_NODE = 0, FM_MLP4_NODE_HEAD = 1, FM_MLP4_PROJ0 = 2 };
 struct FmMlp4Args {
     int N;
-    const void* W1q; const float* b1;          // quad-row packed (fm_wave_gemm4_at): SC_NODE K = 320 ([s_tab (256) | p_a | p_c | rbf | 0]), NODE_HEAD K = 256; N = 256
+    const void* W1q; const float* b1;          // quad-row packed (fm_wave_gemm4): SC_NODE K = 320 ([s_tab (256) | p_a | p_c | rbf | 0]), NODE_HEAD K = 256; N = 256
     const void* W2q; const float* b2;          // SC_NODE: K = 256, N = 256 (G = 4); NODE_HEAD: K = 256, N = 64 (G = 1; na + nc real columns)
     // SC_NODE
     const float* s_tab; const int* tok_a; const int* tok_c; int n_c1;
@@ -428,15 +429,14 @@ struct FmMlp4Args {
 };
 #define FM_MLP4_LDX 324          // >= 320 columns, 16-byte rows
 #define FM_MLP4_LDH 260
-#define FM_MLP4_LDS_BYTES ((4 * FM_MLP4_LDX + 4 * FM_MLP4_LDH + 2048 + 16) * 4)
+#define FM_MLP4_LDS_BYTES ((4 * FM_MLP4_LDX + 4 * FM_MLP4_LDH + 16) * 4)
 
 template <int MODE>
 __device__ __forceinline__ void fm_mlp4_tile(const FmMlp4Args& a, int tile, float* lds) {
     constexpr int LDX = FM_MLP4_LDX, LDH = FM_MLP4_LDH;
     float* X = lds;                               // [4][324]
     float* Hb = X + 4 * LDX;                      // [4][260]
-    float* S = Hb + 4 * LDH;                      // [8 / G][4][64 G]: K-slice exchange
-    int* meta = reinterpret_cast<int*>(S + 2048); // [4] token row
+    int* meta = reinterpret_cast<int*>(Hb + 4 * LDH); // [4] token row
     float* dd = reinterpret_cast<float*>(meta + 4);
     const int tid = threadIdx.x, row0 = tile * 4;
     const int rows = a.N - row0 < 4 ? a.N - row0 : 4;
@@ -475,20 +475,20 @@ __device__ __forceinline__ void fm_mlp4_tile(const FmMlp4Args& a, int tile, floa
     }
     __syncthreads();
     if (MODE == FM_MLP4_PROJ0) {
-        fm_rows4_linear<64, 4>(X, LDX, a.Wps4, S, [&](int r, int c, float v) { if (r < rows) a.Ps[(size_t)(row0 + r) * 256 + c] = v; });
+        fm_rows4_linear<64, 4>(X, LDX, a.Wps4, [&](int r, int c, float v) { if (r < rows) a.Ps[(size_t)(row0 + r) * 256 + c] = v; });
         return;
     }
     if (MODE == FM_MLP4_SC_NODE)
-        fm_rows4_linear<80, 4>(X, LDX, a.W1q, S, [&](int r, int c, float v) { Hb[r * LDH + c] = fm_silu(v + a.b1[c]); });
+        fm_rows4_linear<80, 4>(X, LDX, a.W1q, [&](int r, int c, float v) { Hb[r * LDH + c] = fm_silu(v + a.b1[c]); });
     else
-        fm_rows4_linear<64, 4>(X, LDX, a.W1q, S, [&](int r, int c, float v) { Hb[r * LDH + c] = fm_silu(v + a.b1[c]); });
+        fm_rows4_linear<64, 4>(X, LDX, a.W1q, [&](int r, int c, float v) { Hb[r * LDH + c] = fm_silu(v + a.b1[c]); });
     if (MODE == FM_MLP4_SC_NODE) {
-        fm_rows4_linear<64, 4>(Hb, LDH, a.W2q, S, [&](int r, int c, float v) {
+        fm_rows4_linear<64, 4>(Hb, LDH, a.W2q, [&](int r, int c, float v) {
             if (r < rows) a.out[(size_t)(row0 + r) * 256 + c] = a.s_tab[(size_t)meta[r] * 256 + c] + fm_silu(v + a.b2[c]);
         });
     } else {
         const int no = a.na + a.nc;
-        fm_rows4_linear<64, 1>(Hb, LDH, a.W2q, S, [&](int r, int c, float v) { if (c < no) X[r * LDX + c] = v + a.b2[c]; });
+        fm_rows4_linear<64, 1>(Hb, LDH, a.W2q, [&](int r, int c, float v) { if (c < no) X[r * LDX + c] = v + a.b2[c]; });
         if (tid < rows) {        // softmax heads (vector_field.py:336-339,364-367): one lane per row, the arithmetic of fm_mlp2_tile
             const float* lg = X + tid * LDX;
             const int n = row0 + tid;
@@ -1147,7 +1147,7 @@ __global__ void __launch_bounds__(FM_THREADS) fm_k_node_update(FmNodeUpdArgs a) 
             f32x4 acc[RG];
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) acc[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!(FM_ABLATE & 32)) fm_wave_gemm4<0, 64, RG>(acc, X, FM_LDX, wq, wave & 3, lane);
+            if (!(FM_ABLATE & 32)) fm_wave_gemm4<64, RG>(acc, X, FM_LDX, wq, wave & 3, lane);
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll

@@ -13,7 +13,7 @@ static void node_update_v(Launch& L, int TN, bool narrow, int sp, int rg, dim3 g
 #define FM_NODE_SP(TN_) if (TN == TN_) { if (sp == 3) L(nm, fm_k_node_update<V, TN_, true, 3>, grid, blk, lds, nu); else L(nm, fm_k_node_update<V, TN_, true, 1>, grid, blk, lds, nu); return; }
         FM_NODE_SP(16) FM_NODE_SP(32)
 #undef FM_NODE_SP
-    } else if (rg) {
+    } else if (rg) {      // 4 RG-node instances (fm_wave_gemm4: the regular tiles' summation order)
         if (TN == 16 && rg == 1) { L(nm, fm_k_node_update<V, 16, false, 0, 1>, grid, blk, lds, nu); return; }
         if (TN == 16 && rg == 2) { L(nm, fm_k_node_update<V, 16, false, 0, 2>, grid, blk, lds, nu); return; }
         if (TN == 16 && rg == 3) { L(nm, fm_k_node_update<V, 16, false, 0, 3>, grid, blk, lds, nu); return; }
@@ -58,8 +58,8 @@ void fm_set_lds_node() {
 #define FM_SET_SP(V_, T_) set_lds(fm_k_node_update<V_, T_, true, 1>, lds_gvp_sp(V_, T_)); set_lds(fm_k_node_update<V_, T_, true, 3>, lds_gvp_sp(V_, T_));
     FM_SET_SP(32, 16) FM_SET_SP(32, 32) FM_SET_SP(16, 16) FM_SET_SP(16, 32)
 #undef FM_SET_SP
-#define FM_SET_RG(V_) set_lds(fm_k_node_update<V_, 16, false, 0, 1>, lds_gvp(V_, 16, false) + 4096); set_lds(fm_k_node_update<V_, 16, false, 0, 2>, lds_gvp(V_, 16, false) + 8192); \
-    set_lds(fm_k_node_update<V_, 16, false, 0, 3>, lds_gvp(V_, 16, false) + 12288); set_lds(fm_k_node_update<V_, 32, false, 0, 5>, lds_gvp(V_, 32, false) + 20480);
+#define FM_SET_RG(V_) set_lds(fm_k_node_update<V_, 16, false, 0, 1>, lds_gvp(V_, 16, false)); set_lds(fm_k_node_update<V_, 16, false, 0, 2>, lds_gvp(V_, 16, false)); \
+    set_lds(fm_k_node_update<V_, 16, false, 0, 3>, lds_gvp(V_, 16, false)); set_lds(fm_k_node_update<V_, 32, false, 0, 5>, lds_gvp(V_, 32, false));
     FM_SET_RG(32) FM_SET_RG(16)
 #undef FM_SET_RG
     set_lds(fm_k_dst_proj<16, 16, 4>, lds_gvp(16, 16, false)); set_lds(fm_k_dst_proj<16, 32, 4>, lds_gvp(16, 32, false));

@@ -130,8 +130,9 @@ class FlowMol:
                  n_atoms_hist: Optional[str] = None, _engine_lib=None, precision: Optional[str] = None, canonical: bool = True):
         self.cfg = cfg.validate()
         # canonical arithmetic (fm_config.canonical, default on): a molecule's coordinates and tokens are bit-for-bit independent of the batch it is sampled in
-        # (size, position, sharding over GPUs) -- the reference's semantics, where every reduction is per molecule.  canonical=False = latency mode: launch
-        # choices follow the batch size (one molecule ~0.54 instead of ~0.65 ms per step); differently composed batches then agree to f32 summation order only.
+        # (size, position, sharding over GPUs) -- the reference's semantics, where every reduction is per molecule.  canonical=False: the one launch
+        # choice that selects another summation order (the pair slab) follows the batch size too; differently composed batches then agree to f32 summation
+        # order only.  (Up to round 5 this was a "latency mode"; since the small-batch kernels keep the canonical order it gains ~1 %: 0.55 vs 0.56 ms per step.)
         self.canonical = bool(canonical)
         self.precision = precision or 'f32'  # 'f16x3' / 'bf16x3' / 'bf16x6' = opt-in split precision (Engine); explicit argument only, recorded in last_timing
         self._sd = state_dict

@@ -121,12 +121,13 @@ typedef struct fm_config {
      * molecule (flowmol/models/gvp.py:491-492, flowmol/utils/ctmc_utils.py:11-20, flowmol/models/vector_field.py:347-350).  0 / 1 (default): the library gives the
      * same guarantee BIT FOR BIT: the f32 summation order of everything computed for a molecule depends on the molecule alone -- edge-message tiles start at the
      * molecule's first edge row and in-edges are summed in 16-row chunks counted from it, LayerNorm statistics and gate sums have one order for every tile
-     * height, and the launch choices that would select another order (4-row node tiles, K-sliced 4-row node MLPs, pair slab on / off) are fixed instead of
-     * following the batch size.  A molecule alone, inside a 1024-batch, in any shard of it and on 1 or 8 GPUs gives identical coordinates and tokens for
-     * identical noise.  Holds for the automatic tile heights (16 / 32 rows) and across explicit tile_edge / tile_node 16 | 32; 64-row tiles and forced
-     * tile_node 4..20 / mlp_small_tiles 2 / pair_slab -1 are other (self-consistent) orders.
-     * -1: latency mode -- those three choices follow the batch size (round 5's behaviour: one molecule 0.54 instead of ~0.65 ms per step); results then agree
-     * between differently composed batches to f32 summation order only. */
+     * height, the 4-row instances of the node kernels (small batches) run the regular tiles' fma chains, and the one launch choice that selects another order
+     * (pair slab on / off) is fixed instead of following the batch size.  A molecule alone, inside a 1024-batch, in any shard of it and on 1 or 8 GPUs gives
+     * identical coordinates and tokens for identical noise.  Holds for every automatic tile height and across explicit tile_edge 16 | 32, tile_node 4 .. 32,
+     * mlp_small_tiles; 64-row tiles, pair_slab -1 and fuse_node 2 | -1 (the edge head as a kernel of its own, also taken by batches with a molecule of >= 2048
+     * atoms) are other (self-consistent) orders.
+     * -1: the pair slab follows the batch size (round 5's rule); results then agree between differently composed batches to f32 summation order only.  (Up to
+     * round 5 this was a "latency mode" with its own 4-row kernels; since the 4-row kernels are canonical it gains nothing measurable: one molecule 0.55 vs 0.56 ms.) */
     int32_t canonical;
 } fm_config;
 

@@ -452,9 +452,9 @@ def test_small_node_tiles_on_emulation(emu_lib, name, sizes, t, prev):
     """fm_config.tile_node = 4 / 8 / 12 / 20 (chosen automatically as the smallest tile that fits one per CU): the node kernel on 4 RG nodes per
     workgroup in a 16- or 32-row frame, its scalar GEMMs and the two 256 x 256 projections on v_mfma_f32_4x4x1_16B_f32 with quad-row packed
     weights (RG instances of fm_k_node_update; the emulation executes the instruction with the operand layout verified on the device,
-    tools/ubench/mfma_4x4_layout.cpp).  Every stage against the oracle for every tile; the 4 / 8 / 12-node tiles share the arithmetic of a row
-    (bit-identical results), the regular 16-row tile is other arithmetic, and models the instances do not exist for (dev_narrow) fall back to
-    the frame's regular tile."""
+    tools/ubench/mfma_4x4_layout.cpp).  Every stage against the oracle for every tile; since round 6 the 4-row GEMMs run the regular tiles' fma
+    chains (fm_wave_gemm4), so 4 / 8 / 12 / 20-node tiles AND the regular 16-row tile give bit-identical results (on the MI355X too:
+    profiles/r06m_*); models the instances do not exist for (dev_narrow) fall back to the frame's regular tile."""
     from flowmol_amd.engine import Engine
     cfg = presets.PRESETS[name]()
     sd = weights.synth_state_dict(cfg, 0)
@@ -465,9 +465,9 @@ def test_small_node_tiles_on_emulation(emu_lib, name, sizes, t, prev):
         bad = {k: v for k, v in errs.items() if not v < 2e-5}
         assert not bad, (tile, bad)
         outs[tile] = {k: v.clone() for k, v in out.items()}
-    full_width = cfg.n_hidden_scalars == 256
-    assert all(torch.equal(outs[4][k], outs[8][k]) and torch.equal(outs[4][k], outs[12][k]) for k in 'xace')
-    assert all(torch.equal(outs[4][k], outs[16][k]) for k in 'xace') == (not full_width), name
+    for tile in (8, 12, 16, 20):
+        for k in 'xace':
+            assert torch.equal(outs[4][k], outs[tile][k]), (name, tile, k)
 
 
 def test_traj_frames_reference_format_on_emulation(emu_lib, golden_dir):
@@ -630,7 +630,7 @@ def test_canonical_arithmetic_a_molecules_bits_do_not_depend_on_its_batch(emu_li
     """fm_config.canonical (default): the f32 summation order of everything computed for a molecule is a function of the molecule alone, as every reduction of
     the reference is per molecule (gvp.py:491-492, ctmc_utils.py:11-20, vector_field.py:347-350) -- edge-message tiles start at the molecule's first edge
     row, in-edges are summed in 16-row chunks counted from it, LayerNorm / gate sums have one order for every tile height.  One network evaluation of a
-    molecule ALONE, first / in the middle / last in other batches, and under 16- vs 32-row edge and node tiles must give identical bits (n = 40: 39
+    molecule ALONE, first / in the middle / last in other batches, under 16- vs 32-row edge and node tiles, 4 .. 20-node tiles and 4-row MLPs must give identical bits (n = 40: 39
     in-edges per destination span 3-4 chunks and every alignment of the molecule's first row).  The emulation executes the kernels' own index and
     reduction code lane by lane; the GPU suite repeats this at 1024 x 47 atoms over 12 integration steps."""
     from flowmol_amd.engine import Engine
@@ -639,9 +639,14 @@ def test_canonical_arithmetic_a_molecules_bits_do_not_depend_on_its_batch(emu_li
     A = _one_molecule_inputs(cfg, n, 1)
     others = [_one_molecule_inputs(cfg, k, 10 + k) for k in (5, 12, 3)]
     ref = None
-    for tuning in ({}, {'tile_edge': 32, 'tile_node': 32}, {'tile_edge': 16, 'tile_node': 32}, {'tile_edge': 32, 'tile_node': 16}):
+    batches = (([A], 0), ([A, others[0], others[1]], 0), ([others[0], A, others[2]], 1), ([others[1], others[2], others[0], A], 3))
+    for tuning, sel in (({}, batches), ({'tile_edge': 32, 'tile_node': 32}, batches), ({'tile_edge': 16, 'tile_node': 32}, batches), ({'tile_edge': 32, 'tile_node': 16}, batches),
+                        # round 6: the small-batch kernels run the regular tiles' fma chains -- 4 / 8 / 12 / 20-node tiles (fm_wave_gemm4), 4-row node MLPs
+                        # (fm_rows4_linear; mlp_small_tiles = 2) and 16-row MLP tiles (= 1): the molecule alone and in the middle of a batch
+                        ({'tile_node': 4}, batches[::2]), ({'tile_node': 8}, batches[:1]), ({'tile_node': 12, 'mlp_small_tiles': 2}, batches[2:3]), ({'tile_node': 20}, batches[:1]),
+                        ({'mlp_small_tiles': 2}, batches[::2]), ({'mlp_small_tiles': 1, 'tile_node': 4}, batches[:1])):
         eng = Engine(cfg, sd, device='cpu', lib=emu_lib, tuning=tuning)
-        for batch, idx in (([A], 0), ([A, others[0], others[1]], 0), ([others[0], A, others[2]], 1), ([others[1], others[2], others[0], A], 3)):
+        for batch, idx in sel:
             got = _forward_per_molecule(eng, cfg, batch)[idx]
             ref = ref or got
             for k in 'xace':

@@ -105,6 +105,27 @@ def test_forward_matches_oracle_under_every_accepted_tuning(name, sizes, t, prev
     eng.close()
 
 
+@pytest.mark.parametrize('name,sizes,t,prev', [('flowmol3', [47, 5, 130, 18], 0.3, True), ('geom_ctmc', [5, 17, 8, 30, 2], 0.5, False)])
+def test_every_tile_height_gives_the_same_bits_on_gpu(name, sizes, t, prev):
+    """Canonical arithmetic across tile heights ON THE HARDWARE (round 6): the 4 / 8 / 12 / 20-node tiles of the node kernel and the 4-row node MLPs run their GEMMs
+    on v_mfma_f32_4x4x1 as ONE fma chain per output element in the k-order of the regular tiles' v_mfma_f32_16x16x4 accumulators (fm_wave_gemm4) -- which
+    only gives the regular tiles' bits if the hardware's 16x16x4 instruction IS that chain.  One network evaluation under every node / edge / MLP tile
+    height: all outputs bit-identical (64-row tiles and pair_slab = -1 are documented as other orders and are not in the list)."""
+    from flowmol_amd.engine import Engine
+    cfg = presets.PRESETS[name]()
+    sd = weights.synth_state_dict(cfg, 0)
+    ref = None
+    for tuning in ({'tile_node': 16, 'tile_edge': 16, 'mlp_small_tiles': 1}, {}, {'tile_node': 4}, {'tile_node': 8}, {'tile_node': 12}, {'tile_node': 20}, {'tile_node': 32, 'tile_edge': 32},
+                   {'mlp_small_tiles': 2}, {'mlp_small_tiles': 2, 'pair_mlps': -1, 'tile_node': 4}, {'mlp_small_tiles': -1, 'tile_node': 8}):
+        eng = Engine(cfg, sd, device='cuda:0', precision='f32', tuning=tuning)
+        errs, out, _ = forward_compare(eng, cpu_ref.OracleVF(cfg, sd), cfg, torch.tensor(sizes), t, prev, taps=False)
+        got = {k: out[k].detach().cpu().clone() for k in 'xace'}
+        ref = ref or got
+        for k in 'xace':
+            assert torch.equal(got[k], ref[k]), (tuning, k, float((got[k] - ref[k]).abs().max()))
+        eng.close()
+
+
 @pytest.mark.parametrize('fname,name', [('integrate_flowmol3_F7.npz', 'flowmol3'), ('integrate_qm9_C1.npz', 'qm9'),
                                         ('integrate_geom_ctmc_C5s.npz', 'geom_ctmc'),
                                         ('integrate_geom_arom_T16.npz', 'geom_arom'), ('integrate_flowmol3_arom_T12.npz', 'flowmol3_arom')])
@@ -1018,9 +1039,10 @@ def test_philox_mode_on_gpu_is_batch_composition_independent():
 
 def test_a_molecule_alone_equals_the_same_molecule_in_a_1024_batch_bit_for_bit():
     """Canonical arithmetic at the headline size: molecules 0, 517 and 1023 of BASELINE configs[2]'s 1024 x 47-atom batch -- which runs
-    32-row edge and node tiles, 64-row MLP tiles and the pair slab -- sampled ALONE (16-row tiles everywhere, 1024-thread CTMC workgroups) with their
-    Philox ids give the same coordinates and tokens bit for bit over 12 steps; so does a ragged GEOM-sized batch against its members alone.  In
-    latency mode (canonical=False) the launch choices follow the batch size and the same comparison agrees to f32 summation order only."""
+    32-row edge and node tiles, 64-row MLP tiles and the pair slab -- sampled ALONE (16-row edge tiles, 4-node tiles of the node kernel and 4-row node MLPs on
+    v_mfma_f32_4x4x1, 1024-thread CTMC workgroups) with their Philox ids give the same coordinates and tokens bit for bit over 12 steps; so does a ragged
+    GEOM-sized batch against its members alone.  With canonical=False the pair slab follows the batch size (another summation order of the first scalar
+    GEMM of two convolutions) and the same comparison agrees to f32 summation order only."""
     import flowmol_amd as flowmol
     model = flowmol.FlowMol.from_preset('flowmol3').cuda().eval()
     T = 12
