@@ -6,7 +6,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
 [ -x "$CXX" ] || CXX=clang++
 TMP=$(mktemp -d /tmp/fm_emu_XXXXXX); trap 'rm -rf "$TMP"' EXIT
-FLAGS="-O2 -g -std=c++17 -fPIC -ffp-contract=off -mfma -Wno-unused-value -I $HERE"
+FLAGS="-O2 -std=c++17 -fPIC -ffp-contract=off -mfma -Wno-unused-value -I $HERE"
 pids=()
 for u in "$ROOT"/flowmol_amd/csrc/*.cpp; do
     [ "$(basename "$u")" == "fm_all_units.cpp" ] && continue
