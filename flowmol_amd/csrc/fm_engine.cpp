@@ -909,8 +909,17 @@ static int ws_layout(fm_ctx* c, const int32_t* n_atoms, int B, WsLayout& w) {
     if (N > 0x7fffffffLL / 1024) return fail(c, FM_ERR_INVALID, "batch too large: %lld nodes (limit %lld per bind; split the batch)", N, 0x7fffffffLL / 1024);
     const int V = c->V;
     w.B = B; w.N = (int)N; w.E = (int)E; w.U = (int)(E / 2);
-    // tile sizes of this batch: 16 rows while 32-row tiles would not even give every CU one workgroup
-    w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : ((E + 31) / 32 <= c->n_cus ? 16 : 32);
+    // tile sizes of this batch.  The edge-message kernel is bound by a CU's matrix pipe, so a launch takes (tiles per CU, rounded up) rounds of one tile time plus the
+    // first tile's latency: measured on the MI355X (flowmol3 model, 1 .. 64 molecules x 47 atoms, profiles/r06t_*, r06u_*) 11 + 18 r16 us with 16-row tiles and
+    // 13.5 + 31 r32 us with 32-row tiles, r = ceil(tiles / CUs) -- 32-row tiles do 16 rows in 15.5 instead of 18 us, 16-row tiles quantise in half the step.  The
+    // cheaper of the two by that model (one molecule: 16 rows; 4, 5, 8, 9 molecules: 16; everything from 14 molecules on: 32).  Both give the same bits (canonical
+    // arithmetic), so the choice is free to follow the batch size.
+    {
+        long long t16 = 0, t32 = 0;
+        for (int i = 0; i < B; ++i) { const long long e = (long long)n_atoms[i] * (n_atoms[i] - 1); t16 += (e + 15) / 16; t32 += (e + 31) / 32; }
+        const long long r16 = (t16 + c->n_cus - 1) / c->n_cus, r32 = (t32 + c->n_cus - 1) / c->n_cus;
+        w.tm_edge = c->tm_edge_forced ? c->tm_edge_forced : (36 * r16 + 22 < 62 * r32 + 27 ? 16 : 32);
+    }
     if ((c->HX || !c->cfg.has_mask) && (w.tm_edge > 32)) w.tm_edge = 32;
     // node tiles: 32 rows once the chip is full, 16 while 32-row tiles would leave CUs idle -- and, for full-width f32 models on the fused node
     // sequence, tiles of 4 / 8 / 12 nodes in the 16-row frame or 20 nodes in the 32-row frame (RG instances of fm_k_node_update) whenever such

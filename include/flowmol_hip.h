@@ -103,7 +103,7 @@ typedef struct fm_config {
     /* --- ABI 5: launch-tuning overrides -- 0 = automatic for every one of them (what the product always passes).  They exist for the
      * A/B measurements under profiles/ and for the parity tests that run every tile size; up to ABI 4 they were environment variables
      * read inside fm_create, which hid them from the interface.  The library reads NO environment variable. */
-    int32_t tile_edge;            /* rows per workgroup tile of the edge kernels: 0 = per batch (16 while 32-row tiles would leave CUs idle, else 32) | 16 | 32 | 64 */
+    int32_t tile_edge;            /* rows per workgroup tile of the edge kernels: 0 = per batch (the cheaper of 16 / 32 by a rounds-per-CU model: 16 for a few molecules, 32 for large batches; same bits) | 16 | 32 | 64 */
     int32_t tile_node;            /* same for the node kernels; additionally 4 | 8 | 12 (nodes per workgroup in the 16-row frame) | 20 (in the 32-row frame), scalar GEMMs
                                    * on v_mfma_f32_4x4x1: the automatic choice is the smallest of 4 / 8 / 12 / 16 / 20 whose tiles fit one per CU */
     int32_t tile_edge_update;     /* EdgeUpdate tile: 0 = 32 | 32 | 64 */
