@@ -19,8 +19,15 @@ cfg = presets.flowmol3()
 from flowmol_amd import _lib                             # noqa: E402
 eng = Engine(cfg, weights.synth_state_dict(cfg, 0), device='cuda:0', tuning=tuning, lib=_lib.load(str(ROOT / libarg[0])) if libarg else None)
 dev = eng.device
+geom = 'geom' in sys.argv[1:]              # molecule sizes drawn from the shipped GEOM-drugs histogram (seed 1000 + B) instead of 47 atoms each
 for B in sizes:
-    eng.bind(torch.full((B,), 47, dtype=torch.int64))
+    if geom:
+        from flowmol_amd.model import load_n_atoms_hist
+        vals, counts = load_n_atoms_hist('geom_full_kekulized')
+        n_atoms = vals[torch.multinomial(counts.double(), B, replacement=True, generator=torch.Generator().manual_seed(1000 + B))].to(torch.int64)
+    else:
+        n_atoms = torch.full((B,), 47, dtype=torch.int64)
+    eng.bind(n_atoms)
     N, U = eng.N, eng.U
     plan = make_step_plan(250, cfg.stochasticity, cfg.high_confidence_threshold, cfg.cat_temperature, philox_seed=11 if philox else None)
     x0 = torch.randn(N, 3, device=dev)
@@ -47,5 +54,5 @@ for B in sizes:
         if cnt:
             per_kernel[k] = round(ms / cnt * 1e3, 1)       # us per launch
     eng.profile(False)
-    print(json.dumps({'lib': libarg[0] if libarg else 'flowmol_amd/libflowmol_hip.so', 'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
+    print(json.dumps({'lib': libarg[0] if libarg else 'flowmol_amd/libflowmol_hip.so', 'sizes': 'geom' if geom else 47, 'edges': int((n_atoms * (n_atoms - 1)).sum()), 'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
                       'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2), 'us_per_launch': per_kernel}))
