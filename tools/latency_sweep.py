@@ -54,5 +54,7 @@ for B in sizes:
         if cnt:
             per_kernel[k] = round(ms / cnt * 1e3, 1)       # us per launch
     eng.profile(False)
-    print(json.dumps({'lib': libarg[0] if libarg else 'flowmol_amd/libflowmol_hip.so', 'sizes': 'geom' if geom else 47, 'edges': int((n_atoms * (n_atoms - 1)).sum()), 'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3), 'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
+    print(json.dumps({'lib': libarg[0] if libarg else 'flowmol_amd/libflowmol_hip.so', 'sizes': 'geom' if geom else 47, 'edges': int((n_atoms * (n_atoms - 1)).sum()),
+                      'mols': B, 'noise': 'philox' if philox else 'torch', 'tuning': tuning, 'ms_per_step_wall': round(dt * 1e3, 3),
+                      'sum_kernel_ms_per_step': round(gpu_ms / 2, 3),
                       'launches_per_step': nl / 2, 'mol_per_s_at_250': round(B / (250 * dt), 2), 'us_per_launch': per_kernel}))
